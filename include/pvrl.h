@@ -1,0 +1,122 @@
+/*
+ * pvrl.h -- C ABI of libpvrl_hip.so, the MI355X (gfx950) implementation of the
+ * ProcedureVRL video-narration pre-training hot path.
+ *
+ * The reference (facebookresearch/ProcedureVRL) has no FFI: its hot path is eager PyTorch
+ * below `MODEL_REGISTRY.get(name)(cfg)` (lib/models/build.py:36).  Each entry point here
+ * replaces the ATen op sequence of the cited reference lines.  The Python modules in
+ * procedurevrl_amd/ (same class names / state_dict keys as lib/models/vit.py) bind these
+ * through ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory + sizes; no torch types.  `stream` is a hipStream_t.
+ *   - the caller owns every buffer, including workspaces; nothing is allocated, nothing
+ *     synchronises, no global state; every call is asynchronous on `stream`.
+ *   - return 0 on success, PVRL_EINVAL (-1) on a bad argument, <= -2 on a HIP launch error.
+ *   - bf16 tensors are raw 16-bit brain floats; "ld*" are leading dimensions in ELEMENTS.
+ *   - token layout of the TimeSformer encoder (one buffer of B*N*T + B rows, C = 768):
+ *       rows [0, B*N*T)      patch tokens ordered (b, n, t), t innermost
+ *       rows [B*N*T, +B)     the cls token of each clip
+ *     (the reference keeps [B, 1 + N*T, C] with token index 1 + n*T + t, vit.py:396-407)
+ */
+#ifndef PVRL_H_
+#define PVRL_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GEMM epilogues (pvrl_gemm_nt_bf16) */
+#define PVRL_EPI_BF16 0      /* out0 bf16 = rowscale * (acc + bias)                                   */
+#define PVRL_EPI_GELU 1      /* u = acc + bias; out0 bf16 = u; out1 bf16 = GELU_erf(u)  (vit.py:54-60) */
+#define PVRL_EPI_QGELU 2     /* same with QuickGELU x*sigmoid(1.702x)          (tfm_model.py:27-29)   */
+#define PVRL_EPI_RESID_F32 3 /* out0 f32 = aux_f32[m % rowmod] + rowscale * (acc + bias)              */
+#define PVRL_EPI_F32 4       /* out0 f32 = rowscale * (acc + bias)                                    */
+#define PVRL_EPI_DGELU 5     /* out0 bf16 = rowscale * acc * GELU_erf'(aux_bf16)   (MLP backward)     */
+#define PVRL_EPI_DQGELU 6    /* out0 bf16 = rowscale * acc * QuickGELU'(aux_bf16)                     */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.
+ * Replaces nn.Linear forward (vit.py:54-60,75-92,133; tfm_model.py:35-41) and, with the
+ * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M. */
+int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                      int epilogue, const float* bias, const float* rowscale, const void* aux, int64_t aux_ld,
+                      int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, void* stream);
+
+/* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits
+ * `x @ label_emb.t() / temp` vit.py:307,334,340,432). */
+int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float alpha,
+                           float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* Weight gradient dW[N,K] = beta*dW + P[M,N]^T . Q[M,K]; dbias[N] = beta*dbias + colsum(P) (optional).
+ * Backward of nn.Linear / the patch-embed conv (loss.backward(), tools/train_net.py:176-181).
+ * N % 128 == 0, K % 128 == 0.  workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
+int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
+int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
+                      int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* LayerNorm over fp32 rows, C in {512, 768} (vit.py:104,109,116,228 eps 1e-6; tfm_model.py:18-24 eps 1e-5).
+ * fwd: y = (x - mean) * rstd * gamma + beta  -> bf16 (GEMM operand) or fp32.
+ * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows. */
+int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                       int64_t ldy, int out_is_f32, float* mean, float* rstd, int64_t M, int64_t C, void* stream);
+int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C);
+int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx, const float* mean,
+                       const float* rstd, const float* gamma, const float* dx_in, int64_t ldi, float* dx_out,
+                       int64_t ldo, float beta_acc, float* dgamma, float* dbeta, void* workspace,
+                       int64_t workspace_bytes, int64_t M, int64_t C, void* stream);
+
+/* Temporal attention for T = 8 (Block.forward temporal branch, vit.py:129-135 via Attention.forward
+ * vit.py:75-92): sequences are 8 consecutive rows of the packed qkv [rows][3*H*64]. */
+int pvrl_attn_t8_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t H, float scale, void* o, int64_t ldo,
+                     void* stream);
+int pvrl_attn_t8_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t H, float scale, const void* d_o, int64_t ldo,
+                     void* dqkv, int64_t ldd, void* stream);
+
+/* General MFMA attention, head_dim 64, S <= 208 (spatial branch vit.py:137-151; nn.MultiheadAttention in
+ * tfm_model.py:43-48 with key_padding_mask; CLIP text causal mask).
+ * mode 0: row(seq, j) = seq*S + j.   mode 1 (TimeSformer spatial, seq = b*T + t): token 0 = cls row
+ * cls_base + b, token j>=1 = row b*(S-1)*T + (j-1)*T + t; token-0 outputs go to the *_cls side buffers
+ * ([nseq] rows).  lse/dvec: [nseq][H][S] fp32. */
+int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
+                  int64_t cls_base, float scale, int causal, const void* key_padding_mask, void* o, void* o_cls,
+                  int64_t ldo, float* lse, void* stream);
+int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
+                  int64_t cls_base, float scale, int causal, const void* key_padding_mask, const void* o,
+                  const void* o_cls, const void* d_o, const void* d_o_cls, int64_t ldo, const float* lse, float* dvec,
+                  void* dqkv, void* dqkv_cls, int64_t ldd, void* stream);
+
+/* PatchEmbed im2col: frames fp32 [B,3,T,HI,WI] -> bf16 rows (b, n, t) x (c, py, px) (vit.py:174-180,396). */
+int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t HI, int64_t WI, void* out, int64_t ldo,
+                  void* stream);
+/* E[n*T+t] = bias + pos_embed[1+n] + time_embed[t]  (vit.py:370-407), and its batch-summed gradient. */
+int pvrl_embed_table(const float* pos, const float* time, const float* bias, float* E, int64_t N, int64_t T, int64_t C,
+                     void* stream);
+int pvrl_batch_sum(const float* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream);
+/* out bf16 = rowscale[m] * in fp32 (DropPath scaling lib/models/vit_utils.py:140-155; bf16 operand casts). */
+int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* rowscale, void* out, int64_t ldo, int64_t M,
+                         int64_t C, void* stream);
+int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, int64_t C, void* stream);
+/* cls-token bookkeeping of the spatial branch (vit.py:139-141,147-149):
+ * out[g] = resid[g] + alpha * sum_t scale[g*G+t] * in[g*G+t];   out[g*G+t] = alpha*scale[g*G+t]*in[g]. */
+int pvrl_group_reduce(const void* in, int in_is_f32, int64_t ldi, int64_t groups, int64_t G, int64_t C,
+                      const float* scale, float alpha, const float* resid, int64_t ldr, void* out, int out_is_f32,
+                      int64_t ldo, void* stream);
+int pvrl_group_bcast_bf16(const float* in, int64_t ldi, int64_t groups, int64_t G, int64_t C, const float* scale,
+                          float alpha, void* out, int64_t ldo, void* stream);
+
+/* Loss head (vit.py:300-303; tools/train_net.py:152-162). */
+int pvrl_l2norm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, float* inv_norm, int64_t M, int64_t D,
+                    void* stream);
+int pvrl_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm, float* dx,
+                    int64_t ldx, int64_t M, int64_t D, void* stream);
+int pvrl_kl_topk(const float* pred, int64_t ldp, const float* teacher, int64_t ldt, int64_t rows, int64_t K,
+                 int64_t topk, float grad_scale, float* row_loss, float* dpred, int64_t ldd, float* target_out,
+                 int64_t ldto, void* stream);
+int pvrl_mse(const float* a, const float* b, int64_t n, float grad_scale, float* loss, float* da, float* db,
+             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVRL_H_ */

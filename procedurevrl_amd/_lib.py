@@ -1,0 +1,80 @@
+"""ctypes binding of libpvrl_hip.so (the C ABI declared in include/pvrl.h).
+
+The prototypes are parsed from the header itself, so the header is the single source of
+truth and `tests/test_cabi.py` can check that every declared symbol is exported.
+There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(_HERE, "..", "include", "pvrl.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so")
+
+_CTYPES = {
+    "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
+    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+}
+_RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_name, [(ctype_name, argname), ...])}"""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"\b(int64_t|int)\s+(pvrl_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        parsed = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            mm = re.match(r"(.*?)(\w+)$", a)
+            ty = mm.group(1).strip().replace(" *", "*")
+            parsed.append((ty, mm.group(2)))
+        protos[name] = (ret, parsed)
+    return protos
+
+
+def header_constants(path=HEADER):
+    txt = open(path).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(PVRL_\w+)\s+(-?\d+)", txt)}
+
+
+class PvrlError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise PvrlError(
+                f"{LIB_PATH} is missing: build it with `python -m procedurevrl_amd.csrc.build_ext` "
+                "(there is no CPU or PyTorch fallback for the HIP path)")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self.cdll, name)  # AttributeError -> loud failure on a missing export
+            fn.restype = _RET[ret]
+            fn.argtypes = [_CTYPES[t] for t, _ in args]
+        for k, v in header_constants().items():
+            setattr(self, k, v)
+
+    def call(self, name, *args):
+        fn = getattr(self.cdll, name)
+        rc = fn(*args)
+        if self.protos[name][0] == "int" and rc != 0:
+            raise PvrlError(f"{name} failed with status {rc}")
+        return rc
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

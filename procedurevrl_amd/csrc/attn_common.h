@@ -1,0 +1,78 @@
+// Shared pieces of the MFMA attention kernels (forward, dQ, dK/dV).
+//
+// Sequence addressing.  The divided space-time attention of the reference
+// (lib/models/vit.py:129-151) gathers its sequences with einops rearranges + torch.cat, each a
+// full copy of the token tensor.  Here the packed QKV activations stay where the QKV GEMM wrote
+// them and the kernels address rows in place:
+//   mode 0 (contiguous): row(seq, j) = seq*S + j           -- temporal attention (b h w) t m,
+//                                                              order transformer, CLIP text
+//   mode 1 (TimeSformer spatial): seq = b*T + t, token 0 is the clip's cls row,
+//                                  token j>=1 is patch n=j-1 of frame t:
+//            row(seq, 0) = cls_base + b ; row(seq, j) = b*(S-1)*T + (j-1)*T + t
+//          outputs for token 0 go to a separate per-(b,t) buffer (the T cls copies of
+//          vit.py:139-141 differ after attention and are averaged later, vit.py:147-149).
+#pragma once
+#include "common.h"
+
+struct SeqMap {
+  int mode, S, T;
+  long cls_base;
+};
+
+__device__ __forceinline__ long seq_row(const SeqMap& mp, int seq, int j) {
+  if (mp.mode == 0) return (long)seq * mp.S + j;
+  const int b = seq / mp.T, t = seq - b * mp.T;
+  return j == 0 ? mp.cls_base + b : (long)b * (mp.S - 1) * mp.T + (long)(j - 1) * mp.T + t;
+}
+
+constexpr int ATT_MAX_TILES = 13;               // S <= 208
+constexpr int ATT_ROWS = ATT_MAX_TILES * 16;    // 208
+constexpr int ATT_ROWS_PAD = 224;               // rounded to 32 for the K=32 MFMA steps
+constexpr int ATT_RM_BYTES = ATT_ROWS_PAD * 128;  // row-major [224][64] bf16 tile, 28 KiB
+constexpr int ATT_BL_BYTES = ATT_ROWS_PAD * 128;  // blocked [56][4][4][16] bf16 tile, 28 KiB
+
+// row-major [rows][64] bf16 tile with 16-byte chunk swizzle (conflict-free ds_read_b128 fragments)
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// blocked tile for ds_read_b64_tr_b16: contiguous [4 rows][16 cols] 128-byte blocks
+__device__ __forceinline__ int bl_off(int row, int col) {
+  const int rb = row >> 2;
+  return (rb * 4 + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag8(const char* tile, int off0, int off1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// Transposed fragment for a K=32 MFMA step `ks2` (rows 32*ks2 .. 32*ks2+31 of a blocked tile):
+// lane (i = lane&15, q = lane>>4) receives column 16*ct + i at rows {32ks2+4q+0..3, 32ks2+16+4q+0..3}.
+__device__ __forceinline__ bf16x8 bl_frag(const char* tile, int ks2, int ct, int lane) {
+  const int q = lane >> 4, i = lane & 15;
+  const int rb0 = 8 * ks2 + q, rb1 = rb0 + 4;
+  const int o0 = (rb0 * 4 + (ct ^ (rb0 & 1))) * 128 + i * 8;
+  const int o1 = (rb1 * 4 + (ct ^ (rb1 & 1))) * 128 + i * 8;
+  return tr_frag8(tile, o0, o1);
+}
+
+// Cooperative load of one head slice [S rows][64] of a packed activation into LDS.
+// rm / bl may each be null.  Rows >= S (up to zero_rows) are zero-filled.
+__device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int col0, const SeqMap& mp, int seq,
+                                               char* rm, int rm_rows, char* bl, int bl_rows, int tid) {
+  const int maxrows = rm_rows > bl_rows ? rm_rows : bl_rows;
+  for (int idx = tid; idx < maxrows * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (row < mp.S) v = *reinterpret_cast<const u32x4*>(base + seq_row(mp, seq, row) * ld + col0 + c * 8);
+    if (rm && row < rm_rows) *reinterpret_cast<u32x4*>(rm + rm_off(row, c)) = v;
+    if (bl && row < bl_rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = v;
+  }
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  union { bf16x2 v; unsigned u; } x;
+  x.v[0] = (bf16)a; x.v[1] = (bf16)b;
+  return x.u;
+}

@@ -1,0 +1,402 @@
+// Multi-head self-attention (head_dim 64) on MFMA, forward + backward, S <= 208 tokens.
+//
+// Reference semantics: Attention.forward, lib/models/vit.py:75-92
+//     attn = softmax((q @ k^T) * scale);  x = attn @ v
+// used for the spatial branch of Block.forward (vit.py:137-151; 197 tokens per (clip, frame)),
+// and nn.MultiheadAttention inside ResidualAttentionBlock (lib/models/tfm_model.py:32-53; key padding
+// mask) / the CLIP text tower (causal mask).  Backward = autograd of the same expression.
+//
+// One workgroup (4 waves) per (sequence, head).  The whole K and V head slices of a sequence
+// fit in LDS (197 x 64 bf16 = 25 KiB each), so softmax is exact single-pass (no online rescale)
+// and the S x S score matrix never exists in memory (the reference materialises 477 MB of it).
+// MFMA operands are arranged "swapped" (a = keys, b = queries) so that a lane owns ONE query and
+// 4 keys per 16-key tile: the softmax row reduction is register-local plus two cross-lane
+// steps, and P feeds the second MFMA straight from registers as its b-operand.  V (and, in the
+// backward, K / Q / dO) is read through ds_read_b64_tr_b16 from a [4][16]-blocked LDS image, so
+// no transposed copies are ever built.
+#include "attn_common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16* qkv; long ld;   // packed [rows][3*H*64]: q | k | v, head h at columns h*64
+  int H, nseq;
+  SeqMap mp;
+  float scale;
+  int causal;
+  const unsigned char* kpm;   // [nseq][S], 1 = key masked, or null
+  // forward
+  bf16* o; bf16* o_cls; long ldo;
+  float* lse;                 // [nseq][H][S]
+  // backward
+  const bf16* d_o; const bf16* d_o_cls; const bf16* ofw; const bf16* ofw_cls;
+  float* dvec;                // [nseq][H][S]  rowsum(dO * O)
+  bf16* dqkv; bf16* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
+};
+
+__device__ __forceinline__ bool key_masked(const AttnArgs& p, int seq, int query, int key) {
+  if (key >= p.mp.S) return true;
+  if (p.causal && key > query) return true;
+  if (p.kpm && p.kpm[(long)seq * p.mp.S + key]) return true;
+  return false;
+}
+
+// row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
+template <typename T>
+__device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, int seq, int j) {
+  if (mp.mode == 1 && j == 0) return cls + (long)seq * ld;
+  return tok + seq_row(mp, seq, j) * ld;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[ATT_RM_BYTES + ATT_BL_BYTES];
+  char* Kr = smem;
+  char* Vb = smem + ATT_RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  const int S = p.mp.S;
+  const int nkt = (S + 15) >> 4;
+  const int nks2 = (nkt + 1) >> 1;
+  const int HD = p.H * 64;
+
+  load_head_tile(p.qkv, p.ld, HD + h * 64, p.mp, seq, Kr, nkt * 16, nullptr, 0, tid);
+  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, p.mp, seq, nullptr, 0, Vb, nks2 * 32, tid);
+  __syncthreads();
+
+  const int q4 = lane >> 4, i = lane & 15;
+  for (int qt = wave; qt < nkt; qt += 4) {
+    const int query = qt * 16 + i;
+    const int qrow = query < S ? query : S - 1;
+    const bf16* qp = p.qkv + seq_row(p.mp, seq, qrow) * p.ld + h * 64 + q4 * 8;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+
+    f32x4 sc[ATT_MAX_TILES];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nkt) {
+        const int krow = kt * 16 + i;
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * q4 + r;
+          const float v = key_masked(p, seq, query, key) ? -INFINITY : a[r] * p.scale;
+          a[r] = v;
+          mx = fmaxf(mx, v);
+        }
+        sc[kt] = a;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mref = (mx == -INFINITY) ? 0.f : mx;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(sc[kt][r] - mref);
+          sc[kt][r] = e;
+          sum += e;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks2 = 0; ks2 < (ATT_MAX_TILES + 1) / 2; ++ks2) {
+      if (ks2 < nks2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (bf16)(sc[2 * ks2][r] * inv);
+          pf[4 + r] = (2 * ks2 + 1 < ATT_MAX_TILES && 2 * ks2 + 1 < nkt) ? (bf16)(sc[(2 * ks2 + 1) % ATT_MAX_TILES][r] * inv)
+                                                                        : (bf16)0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 vf = bl_frag(Vb, ks2, dt, lane);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (query < S) {
+      bf16* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, seq, query) + h * 64 + 4 * q4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16)oacc[dt][r];
+        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+      }
+      if (q4 == 0 && p.lse) p.lse[((long)seq * p.H + h) * S + query] = mref + __logf(sum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, pass 1: dQ (and D = rowsum(dO * O)), one workgroup per (sequence, head),
+// waves own query tiles exactly as in the forward.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_RM_BYTES + ATT_BL_BYTES];
+  char* Kr = smem;
+  char* Vr = smem + ATT_RM_BYTES;
+  char* Kb = smem + 2 * ATT_RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  const int S = p.mp.S;
+  const int nkt = (S + 15) >> 4;
+  const int nks2 = (nkt + 1) >> 1;
+  const int HD = p.H * 64;
+
+  load_head_tile(p.qkv, p.ld, HD + h * 64, p.mp, seq, Kr, nkt * 16, Kb, nks2 * 32, tid);
+  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, p.mp, seq, Vr, nkt * 16, nullptr, 0, tid);
+  __syncthreads();
+
+  const int q4 = lane >> 4, i = lane & 15;
+  for (int qt = wave; qt < nkt; qt += 4) {
+    const int query = qt * 16 + i;
+    const int qj = query < S ? query : S - 1;
+    const bf16* qp = p.qkv + seq_row(p.mp, seq, qj) * p.ld + h * 64 + q4 * 8;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, seq, qj) + h * 64 + q4 * 8;
+    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop);
+    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32);
+    const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, seq, qj) + h * 64 + q4 * 8;
+    const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(ofp);
+    const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(ofp + 32);
+    float dsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum += (float)df0[e] * (float)of0[e] + (float)df1[e] * (float)of1[e];
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    const long stat = ((long)seq * p.H + h) * S + qj;
+    const float lse = p.lse[stat];
+    if (q4 == 0 && query < S) p.dvec[stat] = dsum;
+
+    f32x4 ds[ATT_MAX_TILES];
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nkt) {
+        const int krow = kt * 16 + i;
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, q4));
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, 4 + q4));
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
+        f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * q4 + r;
+          const bool msk = key_masked(p, seq, query, key) || query >= S;
+          const float pr = msk ? 0.f : __expf(s[r] * p.scale - lse);
+          s[r] = pr * (dp[r] - dsum) * p.scale;
+        }
+        ds[kt] = s;
+      }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks2 = 0; ks2 < (ATT_MAX_TILES + 1) / 2; ++ks2) {
+      if (ks2 < nks2) {
+        bf16x8 sf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sf[r] = (bf16)ds[2 * ks2][r];
+          sf[4 + r] = (2 * ks2 + 1 < ATT_MAX_TILES && 2 * ks2 + 1 < nkt) ? (bf16)ds[(2 * ks2 + 1) % ATT_MAX_TILES][r]
+                                                                        : (bf16)0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 kf = bl_frag(Kb, ks2, dt, lane);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (query < S) {
+      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, seq, query) + h * 64 + 4 * q4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16)dq[dt][r];
+        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, pass 2: dK and dV.  Waves own KEY tiles; the query dimension is the MFMA reduction.
+// Needs lse and dvec from the forward / pass 1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_RM_BYTES + 2 * ATT_BL_BYTES + 2 * ATT_ROWS_PAD * 4];
+  char* Qr = smem;
+  char* Dr = smem + ATT_RM_BYTES;
+  char* Qb = smem + 2 * ATT_RM_BYTES;
+  char* Db = Qb + ATT_BL_BYTES;
+  float* lse_s = reinterpret_cast<float*>(Db + ATT_BL_BYTES);
+  float* dv_s = lse_s + ATT_ROWS_PAD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  const int S = p.mp.S;
+  const int nkt = (S + 15) >> 4;
+  const int nks2 = (nkt + 1) >> 1;
+  const int HD = p.H * 64;
+
+  load_head_tile(p.qkv, p.ld, h * 64, p.mp, seq, Qr, nks2 * 32, Qb, nks2 * 32, tid);
+  {  // dO tile: token 0 may live in the side buffer (mode 1)
+    for (int idx = tid; idx < nks2 * 32 * 8; idx += 256) {
+      const int row = idx >> 3, c = idx & 7;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (row < S) v = *reinterpret_cast<const u32x4*>(tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, seq, row) + h * 64 + c * 8);
+      *reinterpret_cast<u32x4*>(Dr + rm_off(row, c)) = v;
+      *reinterpret_cast<u32x4*>(Db + bl_off(row, c * 8)) = v;
+    }
+    for (int idx = tid; idx < ATT_ROWS_PAD; idx += 256) {
+      const long stat = ((long)seq * p.H + h) * S + idx;
+      lse_s[idx] = idx < S ? p.lse[stat] : 0.f;
+      dv_s[idx] = idx < S ? p.dvec[stat] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int q4 = lane >> 4, i = lane & 15;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int key = kt * 16 + i;
+    const int kj = key < S ? key : S - 1;
+    const bf16* kp = p.qkv + seq_row(p.mp, seq, kj) * p.ld + HD + h * 64 + q4 * 8;
+    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp);
+    const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
+    const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(kp + HD);
+    const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(kp + HD + 32);
+    const bool kpad = p.kpm ? (p.kpm[(long)seq * S + kj] != 0) : false;
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int u = 0; u < nks2; ++u) {
+      bf16x8 pf, sf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qrow = (2 * u + half) * 16 + i;   // a-operand row: query
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Qr + rm_off(qrow, q4));
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Qr + rm_off(qrow, 4 + q4));
+        const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(Dr + rm_off(qrow, q4));
+        const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(Dr + rm_off(qrow, 4 + q4));
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf1, s, 0, 0, 0);
+        f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf1, dp, 0, 0, 0);
+        // s[r] = S[query = (2u+half)*16 + 4*q4 + r][key]
+        const int qb = (2 * u + half) * 16 + 4 * q4;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dv_s + qb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int query = qb + r;
+          const bool msk = query >= S || key >= S || kpad || (p.causal && key > query);
+          const float pr = msk ? 0.f : __expf(s[r] * p.scale - l4[r]);
+          pf[half * 4 + r] = (bf16)pr;
+          sf[half * 4 + r] = (bf16)(pr * (dp[r] - d4[r]) * p.scale);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 qtf = bl_frag(Qb, u, dt, lane);
+        const bf16x8 dtf = bl_frag(Db, u, dt, lane);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sf, dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pf, dv[dt], 0, 0, 0);
+      }
+    }
+    if (key < S) {
+      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, seq, key) + HD + h * 64 + 4 * q4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)dk[dt][r]; ov[r] = (bf16)dv[dt][r]; }
+        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ok;
+        *reinterpret_cast<bf16x4*>(op + HD + 16 * dt) = ov;
+      }
+    }
+  }
+}
+
+int check_common(const AttnArgs& p) {
+  if (!p.qkv || p.H <= 0 || p.nseq < 0 || p.mp.S <= 0 || p.mp.S > ATT_ROWS) return PVRL_EINVAL;
+  if ((p.ld % 8)) return PVRL_EINVAL;
+  if (p.mp.mode == 1 && (p.mp.T <= 0 || (p.nseq % p.mp.T))) return PVRL_EINVAL;
+  return PVRL_OK;
+}
+
+}  // namespace
+
+extern "C" int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
+                             int64_t cls_base, float scale, int causal, const void* key_padding_mask, void* o,
+                             void* o_cls, int64_t ldo, float* lse, void* stream) {
+  AttnArgs p = {};
+  p.qkv = (const bf16*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
+  p.mp.mode = mode; p.mp.S = (int)S; p.mp.T = (int)T; p.mp.cls_base = cls_base;
+  p.scale = scale; p.causal = causal; p.kpm = (const unsigned char*)key_padding_mask;
+  p.o = (bf16*)o; p.o_cls = (bf16*)o_cls; p.ldo = ldo; p.lse = lse;
+  if (nseq == 0) return PVRL_OK;
+  if (int e = check_common(p)) return e;
+  if (!o || (ldo % 4) || (mode == 1 && !o_cls)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, (hipStream_t)stream, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
+                             int64_t cls_base, float scale, int causal, const void* key_padding_mask, const void* o,
+                             const void* o_cls, const void* d_o, const void* d_o_cls, int64_t ldo, const float* lse,
+                             float* dvec, void* dqkv, void* dqkv_cls, int64_t ldd, void* stream) {
+  AttnArgs p = {};
+  p.qkv = (const bf16*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
+  p.mp.mode = mode; p.mp.S = (int)S; p.mp.T = (int)T; p.mp.cls_base = cls_base;
+  p.scale = scale; p.causal = causal; p.kpm = (const unsigned char*)key_padding_mask;
+  p.ofw = (const bf16*)o; p.ofw_cls = (const bf16*)o_cls; p.d_o = (const bf16*)d_o; p.d_o_cls = (const bf16*)d_o_cls;
+  p.ldo = ldo; p.lse = const_cast<float*>(lse); p.dvec = dvec;
+  p.dqkv = (bf16*)dqkv; p.dqkv_cls = (bf16*)dqkv_cls; p.ldd = ldd;
+  if (nseq == 0) return PVRL_OK;
+  if (int e = check_common(p)) return e;
+  if (!o || !d_o || !lse || !dvec || !dqkv || (ldo % 8) || (ldd % 4)) return PVRL_EINVAL;
+  if (mode == 1 && (!o_cls || !d_o_cls || !dqkv_cls)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

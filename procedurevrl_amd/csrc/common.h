@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the
+// ProcedureVRL video-narration training hot path.  Wave size is 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define PVRL_OK 0
+#define PVRL_EINVAL (-1)
+#define PVRL_EHIP (-2)
+
+#define PVRL_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return PVRL_EHIP - (int)e__ * 16;  \
+  } while (0)
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-byte async global->LDS copy.  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float u) {
+  return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+__device__ __forceinline__ float quick_gelu(float u) {
+  return u / (1.0f + __expf(-1.702f * u));
+}
+__device__ __forceinline__ float quick_gelu_grad(float u) {
+  const float s = 1.0f / (1.0f + __expf(-1.702f * u));
+  return s * (1.0f + 1.702f * u * (1.0f - s));
+}
+
+// XCD-aware bijective block remap: hardware places block b on XCD b % 8; give
+// each XCD a contiguous run of logical tile ids so neighbours share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

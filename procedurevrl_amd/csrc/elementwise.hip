@@ -1,0 +1,221 @@
+// HBM-bound layout / cast kernels around the GEMMs of the TimeSformer path.
+//  * patchify: frames -> bf16 im2col rows in (b, n, t) token order   (PatchEmbed.forward,
+//    lib/models/vit.py:174-180, and the '(b t) n m -> (b n) t m' regroup of vit.py:396)
+//  * embed table / batch-sum: pos_embed + time_embed prologue and its gradient (vit.py:370-407)
+//  * cast / scale / transpose helpers (bf16 GEMM operands from fp32 masters and fp32 gradients;
+//    DropPath row scaling, lib/models/vit_utils.py:140-155)
+//  * cls-token group mean / broadcast (vit.py:139-141,147-149)
+#include "common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+// frames fp32 [B][3][T][HI][WI]  ->  out bf16 [(b, n, t)][c*256 + py*16 + px]
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ frames, bf16* __restrict__ out, int B,
+                                                       int T, int HI, int WI, long ldo) {
+  const int xg = WI >> 3;  // groups of 8 pixels per image row
+  const long total = (long)B * 3 * T * HI * xg;
+  const int PW = WI >> 4, PH = HI >> 4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    long r = idx;
+    const int x8 = (int)(r % xg); r /= xg;
+    const int y = (int)(r % HI); r /= HI;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % 3);
+    const int b = (int)(r / 3);
+    const float* src = frames + idx * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)a[e]; o[4 + e] = (bf16)d[e]; }
+    const int n = (y >> 4) * PW + (x8 >> 1);
+    const long row = ((long)b * PH * PW + n) * T + t;
+    const int col = c * 256 + (y & 15) * 16 + (x8 & 1) * 8;
+    *reinterpret_cast<bf16x8*>(out + row * ldo + col) = o;
+  }
+}
+
+// E[n*T + t][c] = bias[c] + pos[1 + n][c] + time[t][c]
+__global__ __launch_bounds__(256) void embed_table_kernel(const float* __restrict__ pos, const float* __restrict__ time,
+                                                          const float* __restrict__ bias, float* __restrict__ E, int N,
+                                                          int T, int C) {
+  const long total = (long)N * T * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long nt = idx / C;
+    const int t = (int)(nt % T), n = (int)(nt / T);
+    E[idx] = (bias ? bias[c] : 0.f) + pos[(long)(1 + n) * C + c] + time[(long)t * C + c];
+  }
+}
+
+// G[r][c] = sum_b dx[b*rows + r][c]      (gradient of the broadcast embedding table)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ dx, long ld, int B, int rows, int C,
+                                                        float* __restrict__ G) {
+  const int c4n = C >> 2;
+  const long total = (long)rows * c4n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c4 = (int)(idx % c4n);
+    const long r = idx / c4n;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) a += *reinterpret_cast<const f32x4*>(dx + ((long)b * rows + r) * ld + c4 * 4);
+    *reinterpret_cast<f32x4*>(G + r * C + c4 * 4) = a;
+  }
+}
+
+// out bf16[m][c] = rowscale[m] * in fp32[m][c]
+__global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict__ in, long ldi,
+                                                         const float* __restrict__ rowscale, bf16* __restrict__ out,
+                                                         long ldo, long M, int C) {
+  const int c8n = C >> 3;
+  const long total = M * c8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long m = idx / c8n;
+    const float rs = rowscale ? rowscale[m] : 1.f;
+    const float* src = in + m * ldi + c8 * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)(rs * a[e]); o[4 + e] = (bf16)(rs * d[e]); }
+    *reinterpret_cast<bf16x8*>(out + m * ldo + c8 * 8) = o;
+  }
+}
+
+// W fp32 [R][C] -> Wt bf16 [C][R]   (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, bf16* __restrict__ out, int R,
+                                                             int C) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < R && c < C) out[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+  }
+}
+
+// out[g][c] = resid[g][c] + alpha * sum_t scale[g*G + t] * in[g*G + t][c]
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict__ in, long ldi, int groups, int G, int C,
+                                                           const float* __restrict__ scale, float alpha,
+                                                           const float* __restrict__ resid, long ldr,
+                                                           TOut* __restrict__ out, long ldo) {
+  const long total = (long)groups * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long g = idx / C;
+    float a = 0.f;
+    for (int t = 0; t < G; ++t) {
+      const long r = g * G + t;
+      a += (scale ? scale[r] : 1.f) * (float)in[r * ldi + c];
+    }
+    a *= alpha;
+    if (resid) a += resid[g * ldr + c];
+    out[g * ldo + c] = (TOut)a;
+  }
+}
+
+// out bf16[g*G + t][c] = alpha * scale[g*G + t] * in fp32[g][c]
+__global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ in, long ldi, int groups, int G, int C,
+                                                          const float* __restrict__ scale, float alpha,
+                                                          bf16* __restrict__ out, long ldo) {
+  const long total = (long)groups * G * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const long g = r / G;
+    out[r * ldo + c] = (bf16)(alpha * (scale ? scale[r] : 1.f) * in[g * ldi + c]);
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t HI, int64_t WI, void* out, int64_t ldo,
+                             void* stream) {
+  if (B <= 0) return PVRL_OK;
+  if (!frames || !out || (HI % 16) || (WI % 16) || (ldo % 8) || ldo < 768) return PVRL_EINVAL;
+  const long total = B * 3 * T * HI * (WI >> 3);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out,
+                     (int)B, (int)T, (int)HI, (int)WI, (long)ldo);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_embed_table(const float* pos, const float* time, const float* bias, float* E, int64_t N, int64_t T,
+                                int64_t C, void* stream) {
+  if (!pos || !time || !E) return PVRL_EINVAL;
+  hipLaunchKernelGGL(embed_table_kernel, dim3(grid_for(N * T * C)), dim3(256), 0, (hipStream_t)stream, pos, time, bias,
+                     E, (int)N, (int)T, (int)C);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_batch_sum(const float* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream) {
+  if (!dx || !G || (C % 4) || (ld % 4)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3(grid_for(rows * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dx,
+                     (long)ld, (int)B, (int)rows, (int)C, G);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* rowscale, void* out, int64_t ldo,
+                                    int64_t M, int64_t C, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!in || !out || (C % 8) || (ldi % 4) || (ldo % 8)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(cast_scale_kernel, dim3(grid_for(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, in, (long)ldi,
+                     rowscale, (bf16*)out, (long)ldo, (long)M, (int)C);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, int64_t C, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
+                     (hipStream_t)stream, in, (bf16*)out, (int)R, (int)C);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_group_reduce(const void* in, int in_is_f32, int64_t ldi, int64_t groups, int64_t G, int64_t C,
+                                 const float* scale, float alpha, const float* resid, int64_t ldr, void* out,
+                                 int out_is_f32, int64_t ldo, void* stream) {
+  if (groups <= 0) return PVRL_OK;
+  if (!in || !out) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_for(groups * C)), blk(256);
+#define GR(TI, TO)                                                                                                 \
+  hipLaunchKernelGGL((group_reduce_kernel<TI, TO>), grid, blk, 0, s, (const TI*)in, (long)ldi, (int)groups, (int)G, \
+                     (int)C, scale, alpha, resid, (long)ldr, (TO*)out, (long)ldo)
+  if (in_is_f32 && out_is_f32) GR(float, float);
+  else if (in_is_f32) GR(float, bf16);
+  else if (out_is_f32) GR(bf16, float);
+  else GR(bf16, bf16);
+#undef GR
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_group_bcast_bf16(const float* in, int64_t ldi, int64_t groups, int64_t G, int64_t C,
+                                     const float* scale, float alpha, void* out, int64_t ldo, void* stream) {
+  if (groups <= 0) return PVRL_OK;
+  if (!in || !out) return PVRL_EINVAL;
+  hipLaunchKernelGGL(group_bcast_kernel, dim3(grid_for(groups * G * C)), dim3(256), 0, (hipStream_t)stream, in,
+                     (long)ldi, (int)groups, (int)G, (int)C, scale, alpha, (bf16*)out, (long)ldo);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

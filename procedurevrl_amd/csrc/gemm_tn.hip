@@ -1,0 +1,215 @@
+// bf16 MFMA GEMM, "TN" form (weight gradients):
+//     dW[N,K] = sum_m P[m,N]^T . Q[m,K]        (+ optional column sums of P = bias gradient)
+// P = upstream gradient dY (bf16, [M,N]), Q = saved layer input (bf16, [M,K]); fp32 out.
+// This is the autograd backward of every nn.Linear on the reference hot path
+// (lib/models/vit.py:54-60, 75-92, 133, 174-180; tools/train_net.py:176-181 loss.backward()).
+//
+// gfx950 design: the reduction index m is the *row* index of both operands, so MFMA
+// fragments need 8 consecutive m per lane = a column walk of a row-major tile.  Tiles
+// are register-staged (global_load_dwordx4 -> ds_write_b128) into LDS as contiguous
+// [4 m][16 col] 128-byte blocks and fragments are fetched with the CDNA4 transposing
+// LDS read ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of its
+// block: 4 consecutive m).  Output tile 128(n) x 128(k), 4 waves 2x2, 32 m per step,
+// double-buffered.  M is split into `splits` slices (fills 256 CUs although N*K/128^2 is
+// only 36..144 tiles); slices write fp32 partial tiles that a second tiny kernel sums
+// (deterministic, no atomics).  Block order is slice-major so the workgroups alive at
+// one time stream the same rows of P and Q through L2 / Infinity Cache.
+#include "common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+struct GemmTN {
+  const bf16* P; long ldp;
+  const bf16* Q; long ldq;
+  int M, N, K, Ms, tiles_k, tiles_nk;
+  float* part;   // [splits][N][K]
+  float* cpart;  // [splits][N] or null
+};
+
+constexpr int TM = 32;
+constexpr int OP_BYTES = TM * 128 * 2;  // 8 KiB per operand tile
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0, int off1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * OP_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // wm: k half, wn: n half
+  const int wg = blockIdx.x;
+  const int s = wg / p.tiles_nk;
+  const int rem = wg - s * p.tiles_nk;
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int nsteps = (mend - mbeg + TM - 1) / TM;
+
+  // staging map: 2 chunks of 16 B per operand per thread
+  int srow[2], sc8[2], soff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 256 * j;
+    srow[j] = idx >> 4;
+    sc8[j] = idx & 15;
+    const int rb = srow[j] >> 2, cb = sc8[j] >> 1;
+    soff[j] = (rb * 8 + (cb ^ ((rb >> 1) & 1))) * 128 + (srow[j] & 3) * 32 + (sc8[j] & 1) * 16;
+  }
+  u32x4 rp[2], rq[2];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = mbeg + st * TM + srow[j];
+      if (m < mend) {
+        rp[j] = *reinterpret_cast<const u32x4*>(p.P + (long)m * p.ldp + n0 + sc8[j] * 8);
+        rq[j] = *reinterpret_cast<const u32x4*>(p.Q + (long)m * p.ldq + k0 + sc8[j] * 8);
+      } else {
+        rp[j] = (u32x4){0u, 0u, 0u, 0u};
+        rq[j] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto lwrite = [&](int buf) {
+    char* bp = smem + buf * 2 * OP_BYTES;
+    char* bq = bp + OP_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<u32x4*>(bp + soff[j]) = rp[j];
+      *reinterpret_cast<u32x4*>(bq + soff[j]) = rq[j];
+    }
+  };
+
+  // fragment offsets: lane (i, q); rows 8q..8q+3 (h=0) and 8q+4..8q+7 (h=1) of column tile cb
+  const int q = lane >> 4, i = lane & 15;
+  int poff[4][2], qoff[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rb = 2 * q + h;
+      poff[t][h] = (rb * 8 + ((wn * 4 + t) ^ (q & 1))) * 128 + i * 8;
+      qoff[t][h] = (rb * 8 + ((wm * 4 + t) ^ (q & 1))) * 128 + i * 8;
+    }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wm == 0);
+
+  if (nsteps > 0) {
+    gload(0);
+    lwrite(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) gload(st + 1);
+    const char* bp = smem + (st & 1) * 2 * OP_BYTES;
+    const char* bq = bp + OP_BYTES;
+    bf16x8 pf[4], qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pf[t] = tr_frag(bp, poff[t][0], poff[t][1]);
+      qf[t] = tr_frag(bq, qoff[t][0], qoff[t][1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kt], pf[nt], acc[nt][kt], 0, 0, 0);
+    if (do_csum) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[t] += (float)pf[t][e];
+    }
+    if (st + 1 < nsteps) lwrite((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // lane holds n = n0 + wn*64 + nt*16 + i, k = k0 + wm*64 + kt*16 + 4q + reg
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + wn * 64 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wm * 64 + kt * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
+    }
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = csum[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) p.cpart[(long)s * p.N + n0 + wn * 64 + t * 16 + i] = v;
+    }
+  }
+}
+
+// out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
+                                                        int splits, long NK, int N, float beta,
+                                                        float* __restrict__ out, float* __restrict__ bias_out) {
+  const long idx4 = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n4 = NK >> 2;
+  if (idx4 < n4) {
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[idx4];
+    for (int s = 1; s < splits; ++s) {
+      const f32x4 b = reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
+      a += b;
+    }
+    if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
+    reinterpret_cast<f32x4*>(out)[idx4] = a;
+  } else if (bias_out && idx4 - n4 < N) {
+    const int n = (int)(idx4 - n4);
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += cpart[(long)s * N + n];
+    if (beta != 0.f) a += beta * bias_out[n];
+    bias_out[n] = a;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits) {
+  return splits * (N * K + N) * (int64_t)sizeof(float);
+}
+
+extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
+                                 int64_t K, int64_t splits, float beta, float* dW, float* dbias, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
+    return PVRL_EINVAL;
+  if ((ldp % 8) || (ldq % 8)) return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_gemm_tn_workspace_bytes(N, K, splits)) return PVRL_EINVAL;
+  GemmTN p;
+  p.P = (const bf16*)P; p.ldp = ldp; p.Q = (const bf16*)Q; p.ldq = ldq;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  int ms = cdiv(M > 0 ? M : 1, splits);
+  p.Ms = cdiv(ms, TM) * TM;
+  p.tiles_k = (int)(K / 128);
+  p.tiles_nk = (int)(N / 128) * p.tiles_k;
+  p.part = (float*)workspace;
+  p.cpart = dbias ? p.part + splits * N * K : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  const long NK = N * K;
+  const long nthreads = (NK >> 2) + (dbias ? N : 0);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
+                     (int)splits, NK, (int)N, beta, dW, dbias);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

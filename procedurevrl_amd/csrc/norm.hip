@@ -1,0 +1,213 @@
+// LayerNorm forward / backward over fp32 residual-stream rows, one 64-lane wave per row.
+// Reference: nn.LayerNorm(eps=1e-6) in the TimeSformer blocks (lib/models/vit.py:104,109,116,
+// 228, ctor :488) and the fp32 LayerNorm subclass of the order / CLIP transformer
+// (lib/models/tfm_model.py:18-24, eps=1e-5).
+//
+// HBM-bound.  Forward reads fp32 x once (16 B per lane per load) and writes the bf16 GEMM
+// operand (or fp32 for the projection head) plus per-row mean / rstd.  Backward fuses the
+// residual-gradient add (dx_out = dx_in + dLN) and accumulates dgamma / dbeta in registers
+// across a grid-stride loop; per-block partials are summed by a second tiny kernel
+// (deterministic, no atomics).
+#include "common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4IO<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+    return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+    bf16x4 b;
+    b[0] = (bf16)v[0]; b[1] = (bf16)v[1]; b[2] = (bf16)v[2]; b[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = b;
+  }
+};
+
+template <int C, typename TOut>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, TOut* __restrict__ y,
+                                                     long ldy, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int M) {
+  constexpr int NV = C / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const float* xr = x + (long)row * ldx;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * lane + 256 * j);
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mu = wave_sum(s) * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; ss += d * d; }
+  const float rs = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  TOut* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = 4 * lane + 256 * j;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
+    Vec4IO<TOut>::store(yr + c, o);
+  }
+}
+
+template <int C, typename TDy>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                     long ldx, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dx_in, long ldi, float* __restrict__ dx_out,
+                                                     long ldo, float* __restrict__ part, int M) {
+  constexpr int NV = C / 256;
+  __shared__ float red[4][2][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    g[j] = *reinterpret_cast<const f32x4*>(gamma + 4 * lane + 256 * j);
+    dg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], gy[NV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = 4 * lane + 256 * j;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + c);
+      const f32x4 d = Vec4IO<TDy>::load(dy + (long)row * lddy + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[j][e] = (xv[e] - mu) * rs;
+        gy[j][e] = d[e] * g[j][e];
+        c1 += gy[j][e];
+        c2 += gy[j][e] * xh[j][e];
+        dg[j][e] += d[e] * xh[j][e];
+        db[j][e] += d[e];
+      }
+    }
+    c1 = wave_sum(c1) * (1.0f / C);
+    c2 = wave_sum(c2) * (1.0f / C);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = 4 * lane + 256 * j;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - c1 - xh[j][e] * c2);
+      if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + (long)row * ldi + c);
+      *reinterpret_cast<f32x4*>(dx_out + (long)row * ldo + c) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = 4 * lane + 256 * j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][0][c + e] = dg[j][e];
+      red[wave][1][c + e] = db[j][e];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+    const int w = idx / C, c = idx - w * C;
+    part[(long)blockIdx.x * 2 * C + idx] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+  }
+}
+
+// out[j] = beta*out[j] + sum_b part[b][j]   (j over 2*C: dgamma then dbeta)
+// 32 columns per block, 8 row groups per column, LDS tree at the end.
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta,
+                                                             float* __restrict__ out0, float* __restrict__ out1,
+                                                             int half) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  float a = 0.f;
+  if (j < n)
+    for (int b = g; b < nblk; b += 8) a += part[(long)b * n + j];
+  red[g][c] = a;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    float* o = (j < half) ? out0 + j : out1 + (j - half);
+    *o = (beta != 0.f ? beta * *o : 0.f) + t;
+  }
+}
+
+constexpr int LN_BWD_MAX_BLOCKS = 1024;
+
+}  // namespace
+
+extern "C" int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                  void* y, int64_t ldy, int out_is_f32, float* mean, float* rstd, int64_t M,
+                                  int64_t C, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!x || !gamma || !beta || !y || (ldx % 4) || (ldy % 4)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)cdiv(M, 4)), blk(256);
+#define LN_FWD(CC)                                                                                                  \
+  if (out_is_f32)                                                                                                   \
+    hipLaunchKernelGGL((ln_fwd_kernel<CC, float>), grid, blk, 0, s, x, (long)ldx, gamma, beta, eps, (float*)y,       \
+                       (long)ldy, mean, rstd, (int)M);                                                              \
+  else                                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<CC, bf16>), grid, blk, 0, s, x, (long)ldx, gamma, beta, eps, (bf16*)y,         \
+                       (long)ldy, mean, rstd, (int)M);
+  if (C == 768) { LN_FWD(768) } else if (C == 512) { LN_FWD(512) } else return PVRL_EINVAL;
+#undef LN_FWD
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C) {
+  const int64_t nblk = cdiv(M > 0 ? M : 1, 4) < LN_BWD_MAX_BLOCKS ? cdiv(M > 0 ? M : 1, 4) : LN_BWD_MAX_BLOCKS;
+  return nblk * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
+                                  const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                                  int64_t ldi, float* dx_out, int64_t ldo, float beta_acc, float* dgamma, float* dbeta,
+                                  void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta || !workspace) return PVRL_EINVAL;
+  if ((ldx % 4) || (lddy % 4) || (ldo % 4) || (dx_in && (ldi % 4))) return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_layernorm_bwd_workspace_bytes(M, C)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = cdiv(M, 4) < LN_BWD_MAX_BLOCKS ? cdiv(M, 4) : LN_BWD_MAX_BLOCKS;
+  float* part = (float*)workspace;
+#define LN_BWD(CC)                                                                                                   \
+  if (dy_is_f32)                                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<CC, float>), dim3(nblk), dim3(256), 0, s, (const float*)dy, (long)lddy, x,      \
+                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M);              \
+  else                                                                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<CC, bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)dy, (long)lddy, x,        \
+                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M);
+  if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
+#undef LN_BWD
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, s, part, nblk,
+                     (int)(2 * C), beta_acc, dgamma, dbeta, (int)C);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

@@ -1,0 +1,316 @@
+"""Tensor-level wrappers over the C ABI (include/pvrl.h).
+
+PyTorch is used for device memory and streams only: every function here takes CUDA(ROCm)
+tensors, passes raw pointers / leading dimensions to libpvrl_hip.so on torch's current
+stream and returns tensors.  No function has a PyTorch compute fallback.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, PvrlError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk2d(t, dtype=None):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise PvrlError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} stride {t.stride()}")
+    if not t.is_cuda:
+        raise PvrlError("the HIP path needs device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise PvrlError(f"expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ----------------------------------------------------------------------------------------
+# GEMMs
+# ----------------------------------------------------------------------------------------
+def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=None, out1=None):
+    """epilogue(A[M,K] @ W[N,K]^T).  Returns out0 (and out1 for the GELU epilogues)."""
+    L = lib()
+    _chk2d(A, BF16); _chk2d(W, BF16)
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    f32_out = epi in (L.PVRL_EPI_RESID_F32, L.PVRL_EPI_F32)
+    if out0 is None:
+        out0 = torch.empty((M, N), device=A.device, dtype=F32 if f32_out else BF16)
+    two = epi in (L.PVRL_EPI_GELU, L.PVRL_EPI_QGELU)
+    if two and out1 is None:
+        out1 = torch.empty((M, N), device=A.device, dtype=BF16)
+    L.call("pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
+           _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
+           _ptr(out1), _ld(out1) if out1 is not None else 0, _stream())
+    return (out0, out1) if two else out0
+
+
+def gemm_nt_f32(A, B, bias=None, alpha=1.0, out=None):
+    L = lib()
+    _chk2d(A, F32); _chk2d(B, F32)
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=F32)
+    L.call("pvrl_gemm_nt_f32_small", _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(bias), float(alpha), _ptr(out), _ld(out),
+           M, N, K, _stream())
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    key = (tag, str(device))
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = w
+    return w
+
+
+def tn_splits(M, N, K):
+    tiles = (N // 128) * (K // 128)
+    s = max(1, min(32, (1024 + tiles - 1) // tiles))
+    return max(1, min(s, (M + 255) // 256))
+
+
+def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None):
+    """dW[N,K] = beta*dW + P[M,N]^T @ Q[M,K]; dbias = beta*dbias + colsum(P)."""
+    L = lib()
+    _chk2d(P, BF16); _chk2d(Q, BF16)
+    M, N = P.shape
+    K = Q.shape[1]
+    assert Q.shape[0] == M and dW.shape == (N, K) and dW.is_contiguous() and dW.dtype == F32
+    if splits is None:
+        splits = tn_splits(M, N, K)
+    nbytes = L.call("pvrl_gemm_tn_workspace_bytes", N, K, splits)
+    ws = workspace(nbytes, P.device, "tn")
+    L.call("pvrl_gemm_tn_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), _ptr(dbias),
+           _ptr(ws), ws.numel(), _stream())
+    return dW
+
+
+# ----------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=BF16, out=None, save_stats=True):
+    L = lib()
+    _chk2d(x, F32)
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=out_dtype)
+    mean = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+    L.call("pvrl_layernorm_fwd", _ptr(x), _ld(x), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ld(out),
+           1 if out.dtype == F32 else 0, _ptr(mean), _ptr(rstd), M, C, _stream())
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0):
+    L = lib()
+    _chk2d(dy); _chk2d(x, F32)
+    M, C = x.shape
+    if dx_out is None:
+        dx_out = torch.empty((M, C), device=x.device, dtype=F32)
+    nbytes = L.call("pvrl_layernorm_bwd_workspace_bytes", M, C)
+    ws = workspace(nbytes, x.device, "ln")
+    L.call("pvrl_layernorm_bwd", _ptr(dy), _ld(dy), 1 if dy.dtype == F32 else 0, _ptr(x), _ld(x), _ptr(mean),
+           _ptr(rstd), _ptr(gamma), _ptr(dx_in), _ld(dx_in) if dx_in is not None else 0, _ptr(dx_out), _ld(dx_out),
+           float(beta_acc), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _stream())
+    return dx_out
+
+
+# ----------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------
+def attn_t8_fwd(qkv, nseq, H, scale, out=None):
+    L = lib()
+    _chk2d(qkv, BF16)
+    if out is None:
+        out = torch.empty((nseq * 8, H * 64), device=qkv.device, dtype=BF16)
+    L.call("pvrl_attn_t8_fwd", _ptr(qkv), _ld(qkv), nseq, H, float(scale), _ptr(out), _ld(out), _stream())
+    return out
+
+
+def attn_t8_bwd(qkv, d_o, nseq, H, scale, dqkv=None):
+    L = lib()
+    _chk2d(qkv, BF16); _chk2d(d_o, BF16)
+    if dqkv is None:
+        dqkv = torch.empty((nseq * 8, 3 * H * 64), device=qkv.device, dtype=BF16)
+    L.call("pvrl_attn_t8_bwd", _ptr(qkv), _ld(qkv), nseq, H, float(scale), _ptr(d_o), _ld(d_o), _ptr(dqkv), _ld(dqkv),
+           _stream())
+    return dqkv
+
+
+def attn_fwd(qkv, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=None, o=None, o_cls=None, lse=None):
+    """o / o_cls must share a leading dimension (o_cls may be a row-slice of the same buffer)."""
+    L = lib()
+    _chk2d(qkv, BF16)
+    if o is None:
+        o = torch.empty((nseq * S if mode == 0 else cls_base, H * 64), device=qkv.device, dtype=BF16)
+    if mode == 1 and o_cls is None:
+        o_cls = torch.empty((nseq, H * 64), device=qkv.device, dtype=BF16)
+    if lse is None:
+        lse = torch.empty((nseq, H, S), device=qkv.device, dtype=F32)
+    if o_cls is not None:
+        assert _ld(o_cls) == _ld(o)
+    L.call("pvrl_attn_fwd", _ptr(qkv), _ld(qkv), nseq, S, H, mode, T, cls_base, float(scale), 1 if causal else 0,
+           _ptr(kpm), _ptr(o), _ptr(o_cls), _ld(o), _ptr(lse), _stream())
+    return o, o_cls, lse
+
+
+def attn_bwd(qkv, o, o_cls, d_o, d_o_cls, lse, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=None,
+             dqkv=None, dqkv_cls=None):
+    L = lib()
+    _chk2d(qkv, BF16)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if mode == 1 and dqkv_cls is None:
+        dqkv_cls = torch.empty((nseq, qkv.shape[1]), device=qkv.device, dtype=BF16)
+    if dqkv_cls is not None:
+        assert _ld(dqkv_cls) == _ld(dqkv)
+    if o_cls is not None:
+        assert _ld(o_cls) == _ld(o) == _ld(d_o) == _ld(d_o_cls)
+    else:
+        assert _ld(o) == _ld(d_o)
+    dvec = torch.empty_like(lse)
+    L.call("pvrl_attn_bwd", _ptr(qkv), _ld(qkv), nseq, S, H, mode, T, cls_base, float(scale), 1 if causal else 0,
+           _ptr(kpm), _ptr(o), _ptr(o_cls), _ptr(d_o), _ptr(d_o_cls), _ld(o), _ptr(lse), _ptr(dvec), _ptr(dqkv),
+           _ptr(dqkv_cls), _ld(dqkv), _stream())
+    return dqkv, dqkv_cls
+
+
+# ----------------------------------------------------------------------------------------
+# layout / cast helpers
+# ----------------------------------------------------------------------------------------
+def patchify(frames, out=None):
+    """frames fp32 [B,3,T,H,W] -> bf16 [(b,n,t), 768]"""
+    L = lib()
+    assert frames.dtype == F32 and frames.is_contiguous() and frames.is_cuda and frames.shape[1] == 3
+    B, _, T, HI, WI = frames.shape
+    rows = B * (HI // 16) * (WI // 16) * T
+    if out is None:
+        out = torch.empty((rows, 768), device=frames.device, dtype=BF16)
+    L.call("pvrl_patchify", _ptr(frames), B, T, HI, WI, _ptr(out), _ld(out), _stream())
+    return out
+
+
+def embed_table(pos, time, bias, N, T):
+    L = lib()
+    C = pos.shape[-1]
+    E = torch.empty((N * T, C), device=pos.device, dtype=F32)
+    L.call("pvrl_embed_table", _ptr(pos), _ptr(time), _ptr(bias), _ptr(E), N, T, C, _stream())
+    return E
+
+
+def batch_sum(dx, B, rows):
+    L = lib()
+    _chk2d(dx, F32)
+    C = dx.shape[1]
+    G = torch.empty((rows, C), device=dx.device, dtype=F32)
+    L.call("pvrl_batch_sum", _ptr(dx), _ld(dx), B, rows, C, _ptr(G), _stream())
+    return G
+
+
+def cast_scale(x, rowscale=None, out=None):
+    L = lib()
+    _chk2d(x, F32)
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=BF16)
+    L.call("pvrl_cast_scale_bf16", _ptr(x), _ld(x), _ptr(rowscale), _ptr(out), _ld(out), M, C, _stream())
+    return out
+
+
+def cast_transpose(w, out=None):
+    L = lib()
+    assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous()
+    R, C = w.shape
+    if out is None:
+        out = torch.empty((C, R), device=w.device, dtype=BF16)
+    L.call("pvrl_cast_transpose_bf16", _ptr(w), _ptr(out), R, C, _stream())
+    return out
+
+
+def group_reduce(x, groups, G, scale=None, alpha=1.0, resid=None, out=None, out_dtype=F32):
+    L = lib()
+    _chk2d(x)
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((groups, C), device=x.device, dtype=out_dtype)
+    L.call("pvrl_group_reduce", _ptr(x), 1 if x.dtype == F32 else 0, _ld(x), groups, G, C, _ptr(scale), float(alpha),
+           _ptr(resid), _ld(resid) if resid is not None else 0, _ptr(out), 1 if out.dtype == F32 else 0, _ld(out),
+           _stream())
+    return out
+
+
+def group_bcast(x, groups, G, scale=None, alpha=1.0, out=None):
+    L = lib()
+    _chk2d(x, F32)
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((groups * G, C), device=x.device, dtype=BF16)
+    L.call("pvrl_group_bcast_bf16", _ptr(x), _ld(x), groups, G, C, _ptr(scale), float(alpha), _ptr(out), _ld(out),
+           _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# loss head
+# ----------------------------------------------------------------------------------------
+def l2norm_fwd(x):
+    L = lib()
+    _chk2d(x, F32)
+    M, D = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(M, device=x.device, dtype=F32)
+    L.call("pvrl_l2norm_fwd", _ptr(x), _ld(x), _ptr(y), _ld(y), _ptr(inv), M, D, _stream())
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    L = lib()
+    _chk2d(dy, F32)
+    M, D = y.shape
+    dx = torch.empty_like(y)
+    L.call("pvrl_l2norm_bwd", _ptr(dy), _ld(dy), _ptr(y), _ld(y), _ptr(inv), _ptr(dx), _ld(dx), M, D, _stream())
+    return dx
+
+
+def kl_topk(pred, teacher, topk, grad_scale=None, want_target=False):
+    """Returns (row_loss[rows], dpred or None, target or None).  loss1 = row_loss.sum() / rows."""
+    L = lib()
+    _chk2d(pred, F32); _chk2d(teacher, F32)
+    rows, K = pred.shape
+    row_loss = torch.empty(rows, device=pred.device, dtype=F32)
+    dpred = torch.empty_like(pred) if grad_scale is not None else None
+    target = torch.empty_like(pred) if want_target else None
+    L.call("pvrl_kl_topk", _ptr(pred), _ld(pred), _ptr(teacher), _ld(teacher), rows, K, topk,
+           float(grad_scale if grad_scale is not None else 0.0), _ptr(row_loss), _ptr(dpred),
+           _ld(dpred) if dpred is not None else 0, _ptr(target), _ld(target) if target is not None else 0, _stream())
+    return row_loss, dpred, target
+
+
+def mse(a, b, grad_scale=None):
+    L = lib()
+    assert a.dtype == F32 and b.dtype == F32 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    loss = torch.empty(1, device=a.device, dtype=F32)
+    da = torch.empty_like(a) if grad_scale is not None else None
+    db = torch.empty_like(b) if grad_scale is not None else None
+    L.call("pvrl_mse", _ptr(a), _ptr(b), a.numel(), float(grad_scale if grad_scale is not None else 0.0), _ptr(loss),
+           _ptr(da), _ptr(db), _stream())
+    return loss, da, db

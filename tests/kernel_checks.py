@@ -1,0 +1,348 @@
+"""Per-kernel parity checks: HIP kernel (through the C ABI) vs a CPU fp32 restatement.
+
+Each check returns a list of (label, error, tolerance) triples; `error` is the relative L2 error
+||hip - ref|| / ||ref|| unless stated.  bf16 operands carry 2^-9 relative rounding, so kernels
+that round operands / outputs to bf16 are held to 1e-2 (typically 2-4e-3 is observed); fp32
+kernels to 1e-5.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and tools/gpu_check.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF = torch.bfloat16
+TOL_BF16 = 1e-2
+TOL_F32 = 2e-5
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    d = (a - b).norm().item()
+    n = b.norm().item()
+    if not math.isfinite(d):
+        return float("inf")
+    return d / max(n, 1e-30)
+
+
+def bf(x):
+    """round to bf16 and back (what the kernels see)"""
+    return x.to(BF).float()
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def check_gemm_nt():
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    out = []
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(300, 128, 64), (1000, 768, 768), (257, 2304, 768), (130, 768, 3072)]:
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * 0.05
+        bias = torch.randn(N, generator=g)
+        rs = torch.rand(M, generator=g) + 0.5
+        resid = torch.randn(M, N, generator=g)
+        Ab, Wb = bf(A), bf(W)
+        ref = Ab @ Wb.t()
+        Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
+        bd, rsd = bias.to(dev()), rs.to(dev())
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_BF16, bias=bd, rowscale=rsd)
+        out.append((f"gemm_nt bf16 {M}x{N}x{K}", rel(o, rs[:, None] * (ref + bias)), TOL_BF16))
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_F32, bias=bd)
+        out.append((f"gemm_nt f32 {M}x{N}x{K}", rel(o, ref + bias), 1e-4))
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bd, rowscale=rsd, aux=resid.to(dev()))
+        out.append((f"gemm_nt resid {M}x{N}x{K}", rel(o, resid + rs[:, None] * (ref + bias)), 1e-4))
+        rm = 7
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bd, aux=resid[:rm].contiguous().to(dev()), aux_rowmod=rm)
+        out.append((f"gemm_nt resid-mod {M}x{N}x{K}", rel(o, resid[torch.arange(M) % rm] + ref + bias), 1e-4))
+        u, gl = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_GELU, bias=bd)
+        out.append((f"gemm_nt gelu(u) {M}x{N}x{K}", rel(u, ref + bias), TOL_BF16))
+        out.append((f"gemm_nt gelu(g) {M}x{N}x{K}", rel(gl, F.gelu(ref + bias)), TOL_BF16))
+        u2, g2 = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_QGELU, bias=bd)
+        z = ref + bias
+        out.append((f"gemm_nt qgelu {M}x{N}x{K}", rel(g2, z * torch.sigmoid(1.702 * z)), TOL_BF16))
+        upre = torch.randn(M, N, generator=g)
+        ub = bf(upre)
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_DGELU, aux=upre.to(dev(), BF))
+        ur = ub.clone().requires_grad_(True)
+        F.gelu(ur).sum().backward()
+        out.append((f"gemm_nt dgelu {M}x{N}x{K}", rel(o, ref * ur.grad), TOL_BF16))
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_DQGELU, aux=upre.to(dev(), BF))
+        ur = ub.clone().requires_grad_(True)
+        (ur * torch.sigmoid(1.702 * ur)).sum().backward()
+        out.append((f"gemm_nt dqgelu {M}x{N}x{K}", rel(o, ref * ur.grad), TOL_BF16))
+    # strided A (a column slice of a wider buffer) and row-sliced output
+    M, N, K = 200, 128, 128
+    big = torch.randn(M, 3 * K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    Ad = big.to(dev(), BF)[:, K:2 * K]
+    o = ops.gemm_nt(Ad, W.to(dev(), BF), L.PVRL_EPI_F32)
+    out.append(("gemm_nt strided-A", rel(o, bf(big[:, K:2 * K]) @ bf(W).t()), 1e-4))
+    return out
+
+
+def check_gemm_f32_small():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(2)
+    out = []
+    for (M, N, K) in [(32, 9871, 512), (104, 1000, 512), (5, 512, 768), (512, 40, 32)]:
+        A = torch.randn(M, K, generator=g)
+        B = torch.randn(N, K, generator=g)
+        bias = torch.randn(N, generator=g)
+        o = ops.gemm_nt_f32(A.to(dev()), B.to(dev()), bias.to(dev()), alpha=50.0)
+        out.append((f"gemm_f32_small {M}x{N}x{K}", rel(o, 50.0 * (A @ B.t()) + bias), TOL_F32))
+    return out
+
+
+def check_gemm_tn():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    out = []
+    for (M, N, K, splits) in [(96, 128, 128, 1), (1000, 768, 768, 4), (5000, 256, 384, None), (333, 128, 256, 3)]:
+        P = torch.randn(M, N, generator=g)
+        Q = torch.randn(M, K, generator=g)
+        ref = bf(P).t() @ bf(Q)
+        dW = torch.zeros(N, K, device=dev())
+        db = torch.zeros(N, device=dev())
+        ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, beta=0.0, splits=splits)
+        out.append((f"gemm_tn dW {M}x{N}x{K} s={splits}", rel(dW, ref), 1e-4))
+        out.append((f"gemm_tn dbias {M}x{N}x{K}", rel(db, bf(P).sum(0)), 1e-4))
+        ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, beta=1.0, splits=splits)
+        out.append((f"gemm_tn accumulate {M}x{N}x{K}", rel(dW, 2 * ref), 1e-4))
+    return out
+
+
+def check_layernorm():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    out = []
+    for (M, C, eps) in [(1001, 768, 1e-6), (77, 512, 1e-5), (5000, 768, 1e-6)]:
+        x = torch.randn(M, C, generator=g) * 2 + 0.3
+        gam = torch.randn(C, generator=g)
+        bet = torch.randn(C, generator=g)
+        ref = F.layer_norm(x, (C,), gam, bet, eps)
+        y, mean, rstd = ops.layernorm_fwd(x.to(dev()), gam.to(dev()), bet.to(dev()), eps, out_dtype=torch.float32)
+        out.append((f"ln_fwd f32 {M}x{C}", rel(y, ref), TOL_F32))
+        yb, _, _ = ops.layernorm_fwd(x.to(dev()), gam.to(dev()), bet.to(dev()), eps, out_dtype=BF)
+        out.append((f"ln_fwd bf16 {M}x{C}", rel(yb, ref), TOL_BF16))
+        out.append((f"ln_fwd mean {M}x{C}", rel(mean, x.mean(1)), TOL_F32))
+        dy = torch.randn(M, C, generator=g)
+        dxin = torch.randn(M, C, generator=g)
+        xr = x.clone().requires_grad_(True)
+        gr = gam.clone().requires_grad_(True)
+        br = bet.clone().requires_grad_(True)
+        F.layer_norm(xr, (C,), gr, br, eps).backward(dy)
+        dg = torch.zeros(C, device=dev())
+        db = torch.zeros(C, device=dev())
+        dx = ops.layernorm_bwd(dy.to(dev()), x.to(dev()), mean, rstd, gam.to(dev()), dg, db, dx_in=dxin.to(dev()))
+        out.append((f"ln_bwd dx {M}x{C}", rel(dx, xr.grad + dxin), TOL_F32))
+        out.append((f"ln_bwd dgamma {M}x{C}", rel(dg, gr.grad), 1e-4))
+        out.append((f"ln_bwd dbeta {M}x{C}", rel(db, br.grad), 1e-4))
+        dyb = bf(dy)
+        xr.grad = None
+        F.layer_norm(xr, (C,), gam, bet, eps).backward(dyb)
+        dx = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg, db)
+        out.append((f"ln_bwd dx (bf16 dy) {M}x{C}", rel(dx, xr.grad), TOL_F32))
+    return out
+
+
+def _ref_attn(q, k, v, scale, mask=None):
+    s = (q @ k.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+def check_attn_t8():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    out = []
+    nseq, H = 37, 12
+    qkv = torch.randn(nseq * 8, 3 * H * 64, generator=g)
+    qb = bf(qkv).view(nseq, 8, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    o_ref = _ref_attn(qb[0], qb[1], qb[2], 0.125)  # [nseq,H,8,64]
+    o_ref2 = o_ref.permute(0, 2, 1, 3).reshape(nseq * 8, H * 64)
+    o = ops.attn_t8_fwd(qkv.to(dev(), BF), nseq, H, 0.125)
+    out.append(("attn_t8 fwd", rel(o, o_ref2), TOL_BF16))
+    do = torch.randn(nseq * 8, H * 64, generator=g)
+    dob = bf(do)
+    o_ref2.backward(dob)
+    dref = qb.grad.permute(1, 3, 0, 2, 4).reshape(nseq * 8, 3 * H * 64)
+    dq = ops.attn_t8_bwd(qkv.to(dev(), BF), do.to(dev(), BF), nseq, H, 0.125)
+    HD = H * 64
+    out.append(("attn_t8 bwd dq", rel(dq[:, :HD], dref[:, :HD]), TOL_BF16))
+    out.append(("attn_t8 bwd dk", rel(dq[:, HD:2 * HD], dref[:, HD:2 * HD]), TOL_BF16))
+    out.append(("attn_t8 bwd dv", rel(dq[:, 2 * HD:], dref[:, 2 * HD:]), TOL_BF16))
+    return out
+
+
+def check_attn_mfma_contig():
+    """mode 0: contiguous sequences, with causal / key-padding masks (CLIP text, order transformer)."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    out = []
+    for (nseq, S, H, causal, pad) in [(5, 77, 8, True, False), (6, 9, 8, False, True), (3, 197, 12, False, False),
+                                      (4, 32, 12, False, False), (2, 208, 2, False, False), (3, 16, 2, True, True)]:
+        HD = H * 64
+        qkv = torch.randn(nseq * S, 3 * HD, generator=g)
+        qb = bf(qkv).view(nseq, S, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+        mask = torch.zeros(nseq, 1, S, S, dtype=torch.bool)
+        kpm = None
+        if causal:
+            mask |= torch.triu(torch.ones(S, S, dtype=torch.bool), 1)
+        if pad:
+            kpm = torch.zeros(nseq, S, dtype=torch.bool)
+            for i in range(nseq):
+                start = 1 + int(torch.randint(0, S - 1, (1,), generator=g))
+                kpm[i, start:] = True
+            kpm[0, :] = False
+            mask = mask | kpm[:, None, None, :]
+        o_ref = _ref_attn(qb[0], qb[1], qb[2], 0.125, mask)
+        o_ref2 = o_ref.permute(0, 2, 1, 3).reshape(nseq * S, HD)
+        kd = kpm.to(torch.uint8).to(dev()) if kpm is not None else None
+        qd = qkv.to(dev(), BF)
+        o, _, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=0, causal=causal, kpm=kd)
+        tag = f"attn S={S} H={H} c={int(causal)} p={int(pad)}"
+        out.append((tag + " fwd", rel(o, o_ref2), TOL_BF16))
+        do = torch.randn(nseq * S, HD, generator=g)
+        o_ref2.backward(bf(do))
+        dref = qb.grad.permute(1, 3, 0, 2, 4).reshape(nseq * S, 3 * HD)
+        dq, _ = ops.attn_bwd(qd, o, None, do.to(dev(), BF), None, lse, nseq, S, H, 0.125, mode=0, causal=causal, kpm=kd)
+        out.append((tag + " dq", rel(dq[:, :HD], dref[:, :HD]), 1.5e-2))
+        out.append((tag + " dk", rel(dq[:, HD:2 * HD], dref[:, HD:2 * HD]), 1.5e-2))
+        out.append((tag + " dv", rel(dq[:, 2 * HD:], dref[:, 2 * HD:]), 1.5e-2))
+    return out
+
+
+def check_attn_mfma_spatial():
+    """mode 1: TimeSformer spatial gather (cls + every T-th row) addressed in place."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(7)
+    out = []
+    for (B, T, N, H) in [(2, 4, 16, 2), (2, 8, 196, 12)]:
+        HD = H * 64
+        S = N + 1
+        R = B * N * T
+        nseq = B * T
+        qkv = torch.randn(R + B, 3 * HD, generator=g)
+        qkvb = bf(qkv).clone().requires_grad_(True)
+        # gather to [B*T, S, 3HD] exactly like vit.py:139-143
+        tok = qkvb[:R].view(B, N, T, 3 * HD).permute(0, 2, 1, 3)              # b t n c
+        cls = qkvb[R:].view(B, 1, 1, 3 * HD).expand(B, T, 1, 3 * HD)
+        seqs = torch.cat([cls, tok], 2).reshape(nseq, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+        o_ref = _ref_attn(seqs[0], seqs[1], seqs[2], 0.125).permute(0, 2, 1, 3).reshape(B, T, S, HD)
+        o_tok_ref = o_ref[:, :, 1:].permute(0, 2, 1, 3).reshape(R, HD)
+        o_cls_ref = o_ref[:, :, 0].reshape(nseq, HD)
+        qd = qkv.to(dev(), BF)
+        obuf = torch.zeros(R + nseq, HD, device=dev(), dtype=BF)
+        o, o_cls, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
+        tag = f"attn spatial B={B} T={T} N={N}"
+        out.append((tag + " fwd tok", rel(o, o_tok_ref), TOL_BF16))
+        out.append((tag + " fwd cls", rel(o_cls, o_cls_ref), TOL_BF16))
+        do = torch.randn(R + nseq, HD, generator=g)
+        dob = bf(do)
+        (o_tok_ref * dob[:R]).sum().backward(retain_graph=True)
+        (o_cls_ref * dob[R:]).sum().backward()
+        dref = qkvb.grad
+        dod = do.to(dev(), BF)
+        dbuf = torch.zeros(R + B + nseq, 3 * HD, device=dev(), dtype=BF)
+        dqkv, dcls = ops.attn_bwd(qd, obuf[:R], obuf[R:], dod[:R], dod[R:], lse, nseq, S, H, 0.125, mode=1, T=T,
+                                  cls_base=R, dqkv=dbuf[:R + B], dqkv_cls=dbuf[R + B:])
+        out.append((tag + " bwd tok", rel(dqkv[:R], dref[:R]), 1.5e-2))
+        dcls_sum = dcls.float().view(B, T, 3 * HD).sum(1)
+        out.append((tag + " bwd cls", rel(dcls_sum, dref[R:]), 1.5e-2))
+    return out
+
+
+def check_elementwise():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(8)
+    out = []
+    B, T, HI = 2, 4, 64
+    frames = torch.randn(B, 3, T, HI, HI, generator=g)
+    P = HI // 16
+    # reference im2col in (b, n, t) order with (c, py, px) columns
+    x = frames.permute(0, 2, 1, 3, 4).reshape(B, T, 3, P, 16, P, 16).permute(0, 3, 5, 1, 2, 4, 6)
+    ref = x.reshape(B * P * P * T, 768)
+    o = ops.patchify(frames.to(dev()))
+    out.append(("patchify", rel(o, ref), 5e-3))
+    N, C = 9, 768
+    pos = torch.randn(1 + N, C, generator=g); tim = torch.randn(T, C, generator=g); bias = torch.randn(C, generator=g)
+    E = ops.embed_table(pos.to(dev()), tim.to(dev()), bias.to(dev()), N, T)
+    refE = (pos[1:, None, :] + tim[None, :, :] + bias).reshape(N * T, C)
+    out.append(("embed_table", rel(E, refE), TOL_F32))
+    dx = torch.randn(B * N * T, C, generator=g)
+    G = ops.batch_sum(dx.to(dev()), B, N * T)
+    out.append(("batch_sum", rel(G, dx.view(B, N * T, C).sum(0)), TOL_F32))
+    rs = torch.rand(B * N * T, generator=g)
+    cs = ops.cast_scale(dx.to(dev()), rs.to(dev()))
+    out.append(("cast_scale", rel(cs, dx * rs[:, None]), 5e-3))
+    w = torch.randn(300, 130, generator=g)
+    wt = ops.cast_transpose(w.to(dev()))
+    out.append(("cast_transpose", rel(wt, w.t()), 5e-3))
+    groups, Gs = 5, 8
+    xin = torch.randn(groups * Gs, C, generator=g)
+    sc = torch.rand(groups * Gs, generator=g)
+    resid = torch.randn(groups, C, generator=g)
+    r = ops.group_reduce(xin.to(dev()), groups, Gs, scale=sc.to(dev()), alpha=0.125, resid=resid.to(dev()))
+    refr = resid + 0.125 * (xin * sc[:, None]).view(groups, Gs, C).sum(1)
+    out.append(("group_reduce f32", rel(r, refr), TOL_F32))
+    r = ops.group_reduce(xin.to(dev(), BF), groups, Gs, out_dtype=BF)
+    out.append(("group_reduce bf16", rel(r, bf(xin).view(groups, Gs, C).sum(1)), 5e-3))
+    gin = torch.randn(groups, C, generator=g)
+    bc = ops.group_bcast(gin.to(dev()), groups, Gs, scale=sc.to(dev()), alpha=0.125)
+    out.append(("group_bcast", rel(bc, 0.125 * sc[:, None] * gin.repeat_interleave(Gs, 0)), 5e-3))
+    return out
+
+
+def ref_kl_topk(pred, teacher, topk):
+    """tools/train_net.py:152-160 verbatim semantics."""
+    with torch.no_grad():
+        t = F.softmax(teacher, 1)
+        if topk != 0:
+            t = (t.unsqueeze(1) * (t.unsqueeze(1) == t.topk(k=topk, dim=1)[0].unsqueeze(2)).float()).sum(1)
+            t = t / t.sum(1, keepdim=True)
+    loss = torch.nn.KLDivLoss(reduction="batchmean")(F.log_softmax(pred, dim=1), t)
+    return loss, t
+
+
+def check_loss():
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(9)
+    out = []
+    x = torch.randn(26, 512, generator=g)
+    y, inv = ops.l2norm_fwd(x.to(dev()))
+    xr = x.clone().requires_grad_(True)
+    yr = xr / xr.norm(dim=1, keepdim=True)
+    out.append(("l2norm fwd", rel(y, yr), TOL_F32))
+    dy = torch.randn(26, 512, generator=g)
+    yr.backward(dy)
+    dx = ops.l2norm_bwd(dy.to(dev()), y, inv)
+    out.append(("l2norm bwd", rel(dx, xr.grad), TOL_F32))
+    for (rows, K, topk) in [(26, 9871, 5), (7, 778, 5), (4, 300, 0)]:
+        pred = torch.randn(rows, K, generator=g) * 3
+        teacher = torch.randn(rows, K, generator=g) * 4
+        teacher[0, 5] = teacher[0, 9] = teacher[0].max() + 1.0  # exact tie inside the top-k (double counted by the reference)
+        pr = pred.clone().requires_grad_(True)
+        loss_ref, t_ref = ref_kl_topk(pr, teacher, topk)
+        loss_ref.backward()
+        rl, dp, tg = ops.kl_topk(pred.to(dev()), teacher.to(dev()), topk, grad_scale=1.0 / rows, want_target=True)
+        out.append((f"kl_topk loss rows={rows} K={K} k={topk}", abs(rl.sum().item() / rows - loss_ref.item()) / abs(loss_ref.item()), 1e-4))
+        out.append((f"kl_topk target rows={rows} K={K}", rel(tg, t_ref), 1e-4))
+        out.append((f"kl_topk dpred rows={rows} K={K}", rel(dp, pr.grad), 1e-4))
+    a = torch.randn(8, 512, generator=g); b = torch.randn(8, 512, generator=g)
+    ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    lref = F.mse_loss(ar, br); lref.backward()
+    l, da, db = ops.mse(a.to(dev()), b.to(dev()), grad_scale=1.0)
+    out.append(("mse loss", abs(l.item() - lref.item()) / lref.item(), TOL_F32))
+    out.append(("mse da", rel(da, ar.grad), TOL_F32))
+    out.append(("mse db", rel(db, br.grad), TOL_F32))
+    return out
+
+
+ALL_CHECKS = [check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_layernorm, check_attn_t8,
+              check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
