@@ -1,0 +1,156 @@
+"""Headline benchmark: training clips/s of the TimeSformer ViT-B 8x224^2 step-matching path.
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU over RCCL).  A step is one full
+training iteration over one synthetic batch resident in HBM: TimeSformer encoder forward, projection
+head + step logits + top-5 KL loss, backward, gradient all-reduce (N > 1), fused AdamW step.
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_TRAIN_GFLOP = {8: 3 * 391.66 + 3 * 0.0008 + 3 * 0.0101}   # 3 x (encoder + head + logits) fwd GFLOP/clip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config 2: 32)")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--classes", type=int, default=9871)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.config import get_cfg
+    from procedurevrl_amd.build import build_model
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.distributed import GradReducer
+    from procedurevrl_amd.functional import kl_topk_loss
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "vit_base_patch16_224_develop"
+    cfg.MODEL.ARCH = "vit"
+    cfg.MODEL.NUM_CLASSES = args.classes
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.LOSS_FUNC = "kldiv"
+    cfg.MODEL.DROP_PATH = 0.1
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.DATA.NUM_FRAMES = args.frames
+    cfg.NUM_GPUS = 1
+    cfg.SOLVER.OPTIMIZING_METHOD = "adamw"
+    cfg.SOLVER.BASE_LR = 5e-5
+    cfg.SOLVER.WEIGHT_DECAY = 1e-4
+    torch.manual_seed(cfg.RNG_SEED + rank)
+    cfg.TRAIN.LABEL_EMB = synthetic_label_emb(args.classes, 512, seed=0)   # tensor instead of a path (synthetic)
+    model = build_model(cfg, gpu_id=local_rank)
+    vt = model.model
+    with torch.no_grad():   # randomise the branches that the reference zero-initialises so no kernel is idle
+        for blk in vt.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+        torch.nn.init.trunc_normal_(vt.time_embed, std=0.02)
+    model.train()
+    optimizer = construct_optimizer(model, cfg)
+    set_lr(optimizer, cfg.SOLVER.BASE_LR)
+    optimizer.grad_scale = 1.0 / world
+    reducer = GradReducer(vt)
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frames = torch.randn(B, 3, args.frames, 224, 224, device=dev, generator=g)
+    teacher = torch.randn(B, args.classes, device=dev, generator=g) * 4.0
+
+    def step():
+        optimizer.zero_grad(set_to_none=True)
+        pred = model(frames)
+        loss = kl_topk_loss(pred, teacher, 5)
+        loss.backward()
+        reducer.finish()
+        optimizer.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    if not args.no_kernel_timing:
+        ops.KERNEL_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    timing = ops.collect_kernel_timing() if not args.no_kernel_timing else None
+    ops.KERNEL_TIMING = None
+
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips / dt
+        wtrain = W_TRAIN_GFLOP.get(args.frames, W_TRAIN_GFLOP[8] * args.frames / 8) * 1e9
+        out = {
+            "metric": "training clips/sec (8f x 224^2, ViT-B TimeSformer)", "value": round(value, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"TimeSformer ViT-B {args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
+                                   "top-5 KL loss, fwd+bwd+AdamW (BASELINE configs[1])",
+                       "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "loss": float(loss.item()),
+            "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),
+                           "frac_of_bf16_peak": round(value / world * wtrain / 2.5e15, 4),
+                           "w_train_gflop_per_clip": round(wtrain / 1e9, 2)},
+        }
+        if timing:
+            out["roofline"] = timing["roofline"]
+            out["kernels"] = timing["summary"]
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # noqa
+                out["cpu_baseline"] = {"error": repr(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The CPU restatement of the same training step (oracle/, pinned to the reference by golden vectors),
+    timed on this host's cores on a bounded sample: the checker timed as a baseline, never the product."""
+    import torch
+    from oracle import timesformer_oracle as orc
+    return orc.timed_train_step(clips=2, frames=args.frames, classes=args.classes, threads=os.cpu_count() or 1)
+
+
+if __name__ == "__main__":
+    main()

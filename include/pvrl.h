@@ -116,6 +116,14 @@ int pvrl_kl_topk(const float* pred, int64_t ldp, const float* teacher, int64_t l
 int pvrl_mse(const float* a, const float* b, int64_t n, float grad_scale, float* loss, float* da, float* db,
              void* stream);
 
+/* Fused optimiser steps over flat fp32 buffers (torch.optim.AdamW / Adam / SGD-nesterov as built by
+ * lib/models/optimizer.py:93-118; gscale = 1/num_iters of the accumulation branch, train_net.py:187-189).
+ * decoupled = 1: AdamW, 0: Adam with L2 weight decay.  `step` counts from 1. */
+int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t step, float gscale, int decoupled, void* stream);
+int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float dampening,
+                  float weight_decay, int nesterov, int first_step, float gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

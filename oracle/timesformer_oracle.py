@@ -1,0 +1,398 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain eager fp32 PyTorch restatement of the reference's video-narration pre-training hot path
+(facebookresearch/ProcedureVRL), op for op in the reference's own tensor layout, each function citing
+the reference file:line it follows.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg may import this module; nothing under procedurevrl_amd/ does.
+
+Parity pinning: the reference itself is importable in the build container (package-init bypass + stubs,
+see tests/golden/make_golden.py).  That script runs the UNMODIFIED reference modules
+(lib/models/vit.py, lib/models/tfm_model.py, lib/utils/distributed.py) and commits their inputs/outputs as
+fixtures under tests/golden/; tests/test_oracle_golden.py checks every function here against them.
+Two parts cannot be pinned that way and are restated from the cited lines only:
+  * the CLIP text tower lives in third-party openai/CLIP (un-vendored, unpinned in the reference,
+    `clip.load("ViT-B/16")`, vit.py:258): its published architecture is restated in `clip_encode_text`
+    and pinned against the reference's own CLIP-derived blocks (tfm_model.py:18-67) -- "parity unpinned"
+    w.r.t. openai/CLIP itself;
+  * tools/train_net.py is un-importable as shipped (lib/models/optimizer.py:40-41 is a SyntaxError):
+    the loss block :152-162 is restated in `pretrain_loss` and pinned by a golden vector that executes
+    exactly those source lines.
+
+State dicts use the reference's key names (e.g. `blocks.0.temporal_attn.qkv.weight`).
+"""
+import math
+import time
+
+import torch
+import torch.nn.functional as F
+from einops import rearrange
+
+LN_EPS_VIT = 1e-6   # vit.py:488  partial(nn.LayerNorm, eps=1e-6)
+LN_EPS_TFM = 1e-5   # tfm_model.py:18-24 (nn.LayerNorm default)
+
+
+# ------------------------------------------------------------------------------------------
+# encoder (lib/models/vit.py)
+# ------------------------------------------------------------------------------------------
+def mlp(sd, pre, x):
+    """Mlp.forward, vit.py:54-60 (exact-erf GELU, dropout p=0)."""
+    x = F.linear(x, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"])
+    x = F.gelu(x)
+    return F.linear(x, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
+
+
+def attention(sd, pre, x, num_heads=12):
+    """Attention.forward, vit.py:75-92: scale applied AFTER q @ k^T (:84)."""
+    B, N, C = x.shape
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, num_heads, C // num_heads)
+    qkv = qkv.permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * ((C // num_heads) ** -0.5)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(x, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def drop_path_apply(x, keep_mask_scaled):
+    """drop_path, lib/models/vit_utils.py:140-155.  `keep_mask_scaled` = floor(keep + U) / keep per dim-0 row,
+    or None (eval / rate 0).  The draw itself is an explicit input."""
+    if keep_mask_scaled is None:
+        return x
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    return x * keep_mask_scaled.view(shape)
+
+
+def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
+    """Block.forward (divided_space_time), vit.py:119-158.  dp = (s1 [B*H*W], s2 [B*T], s3 [B]) or None."""
+    num_spatial_tokens = (x.size(1) - 1) // T
+    H = num_spatial_tokens // W
+    s1, s2, s3 = dp if dp is not None else (None, None, None)
+    ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), sd[pre + n + ".weight"], sd[pre + n + ".bias"], LN_EPS_VIT)
+    # temporal (:129-135)
+    xt = x[:, 1:, :]
+    xt = rearrange(xt, "b (h w t) m -> (b h w) t m", b=B, h=H, w=W, t=T)
+    res_temporal = drop_path_apply(attention(sd, pre + "temporal_attn.", ln(xt, "temporal_norm1"), num_heads), s1)
+    res_temporal = rearrange(res_temporal, "(b h w) t m -> b (h w t) m", b=B, h=H, w=W, t=T)
+    res_temporal = F.linear(res_temporal, sd[pre + "temporal_fc.weight"], sd[pre + "temporal_fc.bias"])
+    xt = x[:, 1:, :] + res_temporal
+    # spatial (:137-151)
+    init_cls_token = x[:, 0, :].unsqueeze(1)
+    cls_token = init_cls_token.repeat(1, T, 1)
+    cls_token = rearrange(cls_token, "b t m -> (b t) m", b=B, t=T).unsqueeze(1)
+    xs = rearrange(xt, "b (h w t) m -> (b t) (h w) m", b=B, h=H, w=W, t=T)
+    xs = torch.cat((cls_token, xs), 1)
+    res_spatial = drop_path_apply(attention(sd, pre + "attn.", ln(xs, "norm1"), num_heads), s2)
+    cls_token = res_spatial[:, 0, :]
+    cls_token = rearrange(cls_token, "(b t) m -> b t m", b=B, t=T)
+    cls_token = torch.mean(cls_token, 1, True)
+    res_spatial = res_spatial[:, 1:, :]
+    res_spatial = rearrange(res_spatial, "(b t) (h w) m -> b (h w t) m", b=B, h=H, w=W, t=T)
+    # merge + MLP (:155-157)
+    x = torch.cat((init_cls_token, xt), 1) + torch.cat((cls_token, res_spatial), 1)
+    x = x + drop_path_apply(mlp(sd, pre + "mlp.", ln(x, "norm2")), s3)
+    return x
+
+
+def patch_embed(sd, x):
+    """PatchEmbed.forward, vit.py:174-180."""
+    B, C, T, H, W = x.shape
+    x = rearrange(x, "b c t h w -> (b t) c h w")
+    x = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=16)
+    Wp = x.size(-1)
+    x = x.flatten(2).transpose(1, 2)
+    return x, T, Wp
+
+
+def forward_features(sd, x, depth, num_heads=12, droppath=None):
+    """VisionTransformer.forward_features (cls=True), vit.py:365-423.
+    droppath: list over blocks of (s1, s2, s3) or None."""
+    B = x.shape[0]
+    x, T, W = patch_embed(sd, x)
+    cls_tokens = sd["cls_token"].expand(x.size(0), -1, -1)
+    x = torch.cat((cls_tokens, x), dim=1)
+    pos_embed = sd["pos_embed"]
+    if x.size(1) != pos_embed.size(1):   # :374-386 nearest resize
+        cls_pos = pos_embed[0, 0, :].unsqueeze(0).unsqueeze(1)
+        other = pos_embed[0, 1:, :].unsqueeze(0).transpose(1, 2)
+        P = int(other.size(2) ** 0.5)
+        H = x.size(1) // W
+        other = other.reshape(1, x.size(2), P, P)
+        new = F.interpolate(other, size=(H, W), mode="nearest").flatten(2).transpose(1, 2)
+        x = x + torch.cat((cls_pos, new), 1)
+    else:
+        x = x + pos_embed
+    cls_tokens = x[:B, 0, :].unsqueeze(1)
+    x = x[:, 1:]
+    x = rearrange(x, "(b t) n m -> (b n) t m", b=B, t=T)
+    time_embed = sd["time_embed"]
+    if T != time_embed.size(1):          # :398-402
+        te = F.interpolate(time_embed.transpose(1, 2), size=(T), mode="nearest").transpose(1, 2)
+        x = x + te
+    else:
+        x = x + time_embed
+    x = rearrange(x, "(b n) t m -> b (n t) m", b=B, t=T)
+    x = torch.cat((cls_tokens, x), dim=1)
+    for i in range(depth):
+        x = block(sd, f"blocks.{i}.", x, B, T, W, num_heads, None if droppath is None else droppath[i])
+    x = F.layer_norm(x, (x.shape[-1],), sd["norm.weight"], sd["norm.bias"], LN_EPS_VIT)
+    return x[:, 0]
+
+
+def l2n(x):
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def head_logits(sd, feat, label_emb, temp):
+    """vit.py:298-307: head, L2 norm, `x @ label_emb.t() / temp`.  label_emb must already be row-normalised
+    (check_device_norm, vit.py:435-440, normalises on the first device move)."""
+    x = F.linear(feat, sd["head.weight"], sd["head.bias"])
+    x = l2n(x)
+    return x, x @ label_emb.t() / temp
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP-style residual attention stack (lib/models/tfm_model.py:18-67)
+# ------------------------------------------------------------------------------------------
+def resblock(sd, pre, x, n_head, attn_mask=None, pad_mask=None):
+    """ResidualAttentionBlock.forward, tfm_model.py:43-53; x is sequence-first [t, b, c]."""
+    ln = lambda t, n: F.layer_norm(t.float(), (t.shape[-1],), sd[pre + n + ".weight"], sd[pre + n + ".bias"], LN_EPS_TFM)
+    h = ln(x, "ln_1")
+    a = F.multi_head_attention_forward(
+        h, h, h, h.shape[-1], n_head, sd[pre + "attn.in_proj_weight"], sd[pre + "attn.in_proj_bias"], None, None, False,
+        0.0, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"], training=False,
+        key_padding_mask=pad_mask, need_weights=False, attn_mask=attn_mask)[0]
+    x = x + a
+    h = F.linear(ln(x, "ln_2"), sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"])
+    h = h * torch.sigmoid(1.702 * h)                      # QuickGELU, tfm_model.py:27-29
+    return x + F.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+
+
+def stack(sd, pre, x, layers, n_head, attn_mask=None, pad_mask=None):
+    """TemporalModelling.forward, tfm_model.py:63-67."""
+    for i in range(layers):
+        x = resblock(sd, f"{pre}resblocks.{i}.", x, n_head, attn_mask, pad_mask)
+    return x
+
+
+def clip_encode_text(sd, pre, text, layers, n_head=8):
+    """openai/CLIP `CLIP.encode_text` (third-party; published algorithm): token + positional embedding,
+    causal transformer, ln_final, take the features at the EOT token (argmax id), @ text_projection."""
+    x = sd[pre + "token_embedding.weight"][text] + sd[pre + "positional_embedding"]
+    S = text.shape[1]
+    mask = torch.full((S, S), float("-inf")).triu_(1)      # tfm_model.py:265-270 build_attention_mask
+    x = stack(sd, pre + "transformer.", x.permute(1, 0, 2), layers, n_head, attn_mask=mask).permute(1, 0, 2)
+    x = F.layer_norm(x, (x.shape[-1],), sd[pre + "ln_final.weight"], sd[pre + "ln_final.bias"], LN_EPS_TFM)
+    return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ sd[pre + "text_projection"]
+
+
+def pseudo_labels(sd, text_ids, clip_vis_feat, label_emb, temp, text_layers):
+    """get_pseudo_labels, vit.py:425-433."""
+    text_emb = clip_encode_text(sd, "text_model.", text_ids, text_layers)
+    text_emb = (text_emb + clip_vis_feat) / 2.0
+    text_emb = l2n(text_emb)
+    return text_emb @ label_emb.t() / temp
+
+
+# ------------------------------------------------------------------------------------------
+# order / diffusion transformer (lib/models/tfm_model.py:70-302)
+# ------------------------------------------------------------------------------------------
+def sinusoidal(time, dim):
+    """SinusoidalPositionEmbeddings, lib/models/diffusion_model.py:34-47."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half) * -e)
+    e = time[:, None] * e[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def diffusion_coefs(levels):
+    """configure_diffusion, tfm_model.py:106-127 with linear_beta_schedule (diffusion_model.py:328-331)."""
+    betas = torch.linspace(0.0001, 0.02, levels)
+    ac = torch.cumprod(1.0 - betas, 0)
+    return torch.sqrt(ac), torch.sqrt(1.0 - ac)
+
+
+def order_tfm_pretrain(sd, pre, x, max_len, layers, n_head, mask_inds, pad_start, noises):
+    """DiffusionTransformer.forward(is_pretrain=True): tfm_model.py:129-156 -> pad_sequence :272-289 ->
+    diffusion_signal_training :165-204.  RNG draws (mask_inds :145, pad_start :283, noise :180) are inputs."""
+    hidden = x.shape[1]
+    clip_feats = rearrange(x, "(b t) c -> t b c", t=max_len).clone()
+    bsz = clip_feats.size(1)
+    temp_emb = sd[pre + "temporalEmbedding.weight"][torch.arange(max_len)][:, None, :].expand(-1, bsz, -1)
+    bs_inds = torch.arange(bsz)
+    x0 = clip_feats[mask_inds, bs_inds]
+    pad_mask = torch.zeros(bsz, max_len, dtype=torch.bool)
+    for i in range(bsz):                                          # pad_sequence
+        ps = int(pad_start[i])
+        if ps < max_len:
+            clip_feats[ps:, i] = sd[pre + "pad_embedding.weight"]
+        pad_mask[i, ps:] = True
+    sa, sb = diffusion_coefs(layers)
+    orig = clip_feats
+    inter = []
+    denoised = None
+    for time_i in range(layers):
+        cf = orig.clone()
+        t_index = layers - 1 - time_i
+        t = torch.full((bsz,), t_index, dtype=torch.long)
+        src = x0.clone().detach() if time_i == 0 else denoised.clone().detach()
+        noisy = sa[t_index] * src + sb[t_index] * noises[time_i]            # ennoise, :291-302
+        cf[mask_inds, bs_inds] = noisy
+        type_emb = sd[pre + "type_embedding.weight"][torch.zeros(max_len, bsz, dtype=torch.long)].clone()
+        type_emb[mask_inds, bs_inds] = sd[pre + "type_embedding.weight"][torch.ones(bsz, dtype=torch.long)]
+        h = cf + type_emb + temp_emb
+        tm = sinusoidal(t, hidden // 4)
+        tm = F.linear(tm, sd[pre + "time_mlp.1.weight"], sd[pre + "time_mlp.1.bias"])
+        tm = F.linear(F.gelu(tm), sd[pre + "time_mlp.3.weight"], sd[pre + "time_mlp.3.bias"])
+        h = h + tm[None, :, :]
+        out = stack(sd, pre + "temporalModelling.", h, layers, n_head, pad_mask=pad_mask)
+        denoised = out[mask_inds, bs_inds]
+        inter.append(denoised)
+    x0_rep = x0.unsqueeze(0).expand(layers, -1, -1).reshape(-1, x0.size(-1))
+    inter = torch.cat(inter)
+    return denoised, mask_inds, [x0_rep, inter], inter
+
+
+def vit_forward_train(sd, inputs, meta, label_emb, temp, depth, max_len, order_layers, text_layers, rng,
+                      order_recog_batch=9, droppath=None):
+    """VisionTransformer.forward in pre-training mode, vit.py:283-352 (ORDER_PRETRAIN_ENABLED, MATCH_LANG_EMB,
+    text model present, training)."""
+    batch_size = inputs.shape[0]
+    x = rearrange(inputs, "b m c t h w -> (b m) c t h w", m=max_len)
+    feat = forward_features(sd, x, depth, droppath=droppath)
+    video_emb, logits = head_logits(sd, feat, label_emb, temp)
+    teacher_x = pseudo_labels(sd, meta["clip_text_ids"], meta["clip_vis_feat"], label_emb, temp, text_layers)
+    pred_emb, mask_inds, mse, inter = order_tfm_pretrain(sd, "order_tfm.", video_emb, max_len, order_layers, 8,
+                                                         rng["mask_inds"], rng["pad_start"], rng["noises"])
+    ts = rearrange(teacher_x, "(b m) c -> b m c", m=max_len)
+    masked_teacher = ts[torch.arange(ts.shape[0]), mask_inds, :]
+    inter = l2n(inter)
+    inter_pred = inter @ label_emb.t() / temp
+    inter_teacher = masked_teacher.unsqueeze(0).expand(order_layers, -1, -1).reshape(-1, masked_teacher.size(-1))
+    rand_inds = rng["rand_inds"][:batch_size * order_recog_batch]
+    pred = torch.cat((logits[rand_inds], inter_pred), dim=0)
+    teacher = torch.cat((teacher_x[rand_inds], inter_teacher), dim=0)
+    return pred, teacher, mse
+
+
+# ------------------------------------------------------------------------------------------
+# loss head (tools/train_net.py:152-162) and the contrastive operator API
+# ------------------------------------------------------------------------------------------
+def pretrain_loss(pred, teacher_pred, mse, topk=5):
+    with torch.no_grad():
+        teacher_pred = F.softmax(teacher_pred, 1)
+        if topk != 0:
+            teacher_pred = (teacher_pred.unsqueeze(1) * (teacher_pred.unsqueeze(1) == teacher_pred.topk(k=topk, dim=1)[0].unsqueeze(2)).float()).sum(1)
+            teacher_pred = teacher_pred / teacher_pred.sum(1, keepdim=True)
+    loss1 = torch.nn.KLDivLoss(reduction="batchmean")(F.log_softmax(pred, dim=1), teacher_pred)
+    loss2 = torch.nn.MSELoss(reduction="mean")(mse[0], mse[1]) if mse is not None else torch.zeros(())
+    return loss1 + loss2, loss1, loss2
+
+
+def milnce(video_embd, text_embd):
+    """MILNCELoss.forward, lib/models/losses.py:15-23 (th.eye kept on the input's device instead of .cuda())."""
+    x = torch.matmul(video_embd, text_embd.t())
+    x = x.view(video_embd.shape[0], video_embd.shape[0], -1)
+    nominator = x * torch.eye(x.shape[0])[:, :, None]
+    nominator = nominator.sum(dim=1)
+    nominator = torch.logsumexp(nominator, dim=1)
+    denominator = torch.cat((x, x.permute(1, 0, 2)), dim=1).view(x.shape[0], -1)
+    denominator = torch.logsumexp(denominator, dim=1)
+    return torch.mean(denominator - nominator)
+
+
+def allgather_forward_backward(local_tensors, grad_output):
+    """Semantics of du.AllGather (lib/utils/distributed.py:13-29) simulated for a list of per-rank tensors:
+    forward = concatenation over ranks; backward on rank r = rows [b*r, b*(r+1)) of ITS grad_output, no sum."""
+    out = torch.cat(local_tensors, 0)
+    b = local_tensors[0].shape[0]
+    return out, [g[b * r: b * (r + 1)] for r, g in enumerate(grad_output)]
+
+
+def lr_at_epoch(cfg, cur_epoch):
+    """lib/utils/lr_policy.py:8-87 (steps_with_relative_lrs / cosine + warm-up)."""
+    s = cfg.SOLVER
+    def f(ep):
+        if s.LR_POLICY == "cosine":
+            return s.COSINE_END_LR + (s.BASE_LR - s.COSINE_END_LR) * (math.cos(math.pi * ep / s.MAX_EPOCH) + 1.0) * 0.5
+        steps = list(s.STEPS) + [s.MAX_EPOCH]
+        ind = 0
+        for ind, st in enumerate(steps):
+            if ep < st:
+                break
+        return s.LRS[ind - 1] * s.BASE_LR
+    lr = f(cur_epoch)
+    if cur_epoch < s.WARMUP_EPOCHS:
+        alpha = (f(s.WARMUP_EPOCHS) - s.WARMUP_START_LR) / s.WARMUP_EPOCHS
+        lr = cur_epoch * alpha + s.WARMUP_START_LR
+    return lr
+
+
+# ------------------------------------------------------------------------------------------
+# weights + CPU-baseline timing helpers
+# ------------------------------------------------------------------------------------------
+def encoder_shapes(depth, num_frames=8, num_patches=196, dim=768, head_dim=512):
+    sh = {"cls_token": (1, 1, dim), "pos_embed": (1, num_patches + 1, dim), "time_embed": (1, num_frames, dim),
+          "patch_embed.proj.weight": (dim, 3, 16, 16), "patch_embed.proj.bias": (dim,),
+          "norm.weight": (dim,), "norm.bias": (dim,), "head.weight": (head_dim, dim), "head.bias": (head_dim,)}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        for n in ("norm1", "temporal_norm1", "norm2"):
+            sh[p + n + ".weight"] = (dim,); sh[p + n + ".bias"] = (dim,)
+        for a in ("attn", "temporal_attn"):
+            sh[p + a + ".qkv.weight"] = (3 * dim, dim); sh[p + a + ".qkv.bias"] = (3 * dim,)
+            sh[p + a + ".proj.weight"] = (dim, dim); sh[p + a + ".proj.bias"] = (dim,)
+        sh[p + "temporal_fc.weight"] = (dim, dim); sh[p + "temporal_fc.bias"] = (dim,)
+        sh[p + "mlp.fc1.weight"] = (4 * dim, dim); sh[p + "mlp.fc1.bias"] = (4 * dim,)
+        sh[p + "mlp.fc2.weight"] = (dim, 4 * dim); sh[p + "mlp.fc2.bias"] = (dim,)
+    return sh
+
+
+def seeded_state(shapes, seed):
+    """Deterministic synthetic weights keyed by NAME (sorted), so two implementations with the same keys get
+    identical tensors: LayerNorm gains ~ 1 + 0.1 N, matrices / embeddings ~ 0.02 N (0.05 for biases)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        r = torch.randn(shp, generator=g)
+        if k.endswith("logit_scale"):
+            sd[k] = torch.tensor(math.log(1 / 0.07))
+        elif (".norm" in k or k.startswith("norm") or ".ln_" in k or "ln_final" in k or "temporal_norm1" in k) and k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * r
+        elif k.endswith("bias"):
+            sd[k] = 0.05 * r
+        elif k.endswith("positional_embedding") or "Embedding" in k or "embedding.weight" in k:
+            sd[k] = 0.02 * r
+        elif "text_projection" in k or "in_proj_weight" in k:
+            sd[k] = r * (shp[-1] ** -0.5)
+        else:
+            sd[k] = 0.02 * r
+    return sd
+
+
+def timed_train_step(clips=2, frames=8, classes=9871, threads=8, repeats=1):
+    """One full training step of BASELINE config 2's workload (encoder fwd, head + step logits + top-5 KL,
+    backward, AdamW) on the host CPU in eager fp32, on a bounded sample of `clips` clips."""
+    torch.set_num_threads(threads)
+    sd = seeded_state(encoder_shapes(12, frames), 0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=5e-5, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(clips, 3, frames, 224, 224, generator=g)
+    label = l2n(torch.randn(classes, 512, generator=g) * 0.38)
+    teacher = torch.randn(clips, classes, generator=g) * 4
+    times = []
+    for _ in range(repeats + 1):   # first pass is the warm-up
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        feat = forward_features(params, x, 12)
+        _, logits = head_logits(params, feat, label, 0.02)
+        loss, _, _ = pretrain_loss(logits, teacher, None, 5)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = min(times[1:])
+    return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{clips} clips x {frames}f x 224^2, one full train step (fwd+bwd+AdamW), eager fp32 PyTorch oracle, "
+                      f"best of {repeats} after 1 warm-up, {dt:.2f} s"}

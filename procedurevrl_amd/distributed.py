@@ -1,0 +1,161 @@
+"""Distributed helpers: RCCL (torch.distributed backend "nccl" on ROCm) over xGMI, one process per GPU.
+
+API surface of the reference `lib/utils/distributed.py` (AllGather :13-29, all_gather :31-50,
+all_reduce :53-69, init_process_group :72-110, get_world_size / get_rank / is_master_proc ...), plus the
+data-parallel gradient reduction that replaces DDP (lib/models/build.py:49-53):
+
+  * gradients live in ONE flat fp32 buffer (engine.GradStore); `GradReducer` all-reduces it in
+    per-block chunks (~28 MB each) launched as soon as a block's backward finishes, so the
+    transfers overlap the remaining backward GEMMs; xGMI is point-to-point, so few large
+    messages beat DDP's 25 MB bucket stream with per-bucket copies.
+  * the three per-iteration metric scalars of tools/train_net.py:234 travel as ONE 12-byte
+    all-reduce (`all_reduce_scalars`) instead of three collectives + `.item()` syncs.
+"""
+import functools
+import os
+
+import torch
+import torch.distributed as dist
+
+_LOCAL_PROCESS_GROUP = None
+
+
+class AllGather(torch.autograd.Function):
+    """All-gather with the reference's backward: the LOCAL slice of the incoming gradient, no
+    reduction (distributed.py:24-29)."""
+
+    @staticmethod
+    def forward(ctx, tensor):
+        world = dist.get_world_size()
+        tensor = tensor.contiguous()
+        out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+        dist.all_gather_into_tensor(out, tensor)   # one collective into the final buffer, no list + cat
+        ctx.rank = dist.get_rank()
+        ctx.batch_size = tensor.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None
+
+
+def all_gather(tensors):
+    """distributed.py:31-50: every tensor gathered along dim 0 from all ranks."""
+    world = dist.get_world_size()
+    out = []
+    for t in tensors:
+        t = t.contiguous()
+        buf = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(buf, t)
+        out.append(buf)
+    return out
+
+
+def all_reduce(tensors, average=True):
+    """distributed.py:53-69 (in place, sum then optional 1/world)."""
+    for t in tensors:
+        dist.all_reduce(t, async_op=False)
+    if average:
+        w = dist.get_world_size()
+        for t in tensors:
+            t.mul_(1.0 / w)
+    return tensors
+
+
+def all_reduce_scalars(values, average=True):
+    """Fused form of `du.all_reduce([loss, top1_err, top5_err])`: one collective, no host sync."""
+    v = torch.stack([x.detach().float().reshape(()) if torch.is_tensor(x) else torch.tensor(float(x)) for x in values])
+    if torch.is_tensor(values[0]):
+        v = v.to(values[0].device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(v)
+        if average:
+            v.mul_(1.0 / dist.get_world_size())
+    return v
+
+
+def init_process_group(local_rank, local_world_size, shard_id, num_shards, init_method, dist_backend="nccl"):
+    """distributed.py:72-110"""
+    proc_rank = local_rank + shard_id * local_world_size
+    world_size = local_world_size * num_shards
+    dist.init_process_group(backend=dist_backend, init_method=init_method, world_size=world_size, rank=proc_rank)
+    if dist_backend == "nccl":
+        torch.cuda.set_device(local_rank)
+
+
+def is_master_proc(num_gpus=8):
+    return dist.get_rank() % num_gpus == 0 if dist.is_available() and dist.is_initialized() else True
+
+
+def is_root_proc():
+    return dist.get_rank() == 0 if dist.is_available() and dist.is_initialized() else True
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def synchronize():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def init_distributed_training(cfg):
+    """distributed.py:284-299: one local process group per node."""
+    global _LOCAL_PROCESS_GROUP
+    if cfg.NUM_GPUS <= 1:
+        return
+    n = cfg.NUM_GPUS
+    for i in range(dist.get_world_size() // n):
+        pg = dist.new_group(list(range(i * n, (i + 1) * n)))
+        if i == cfg.SHARD_ID:
+            _LOCAL_PROCESS_GROUP = pg
+
+
+class GradReducer:
+    """Sum the flat gradient buffer over ranks, overlapped with the encoder backward.
+
+    `attach(vt)` installs `engine.grad_hook`; during loss.backward() the hook fires after each block
+    (last block first) and launches an async all-reduce of that block's contiguous slice.
+    `finish()` reduces whatever is left (embeddings, head, order transformer: they sit outside the
+    block ranges) and waits.  Averaging (1/world) is folded into the optimiser's `grad_scale`.
+    """
+
+    def __init__(self, vt, enabled=None):
+        self.vt = vt
+        self.enabled = (get_world_size() > 1) if enabled is None else enabled
+        self.handles = []
+        self.done = []
+        vt.engine.grad_hook = self._hook if self.enabled else None
+
+    def _block_range(self, i):
+        gs = self.vt.grad_store()
+        pre = f"blocks.{i}."
+        idx = [k for k, n in enumerate(gs.names) if n.startswith(pre)]
+        a = gs.offsets[idx[0]]
+        last = idx[-1]
+        b = gs.offsets[last + 1] if last + 1 < len(gs.offsets) else gs.flat.numel()
+        return a, b
+
+    def _hook(self, i):
+        a, b = self._block_range(i)
+        gs = self.vt.grad_store()
+        self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
+        self.done.append((a, b))
+
+    def finish(self):
+        if not self.enabled:
+            return
+        gs = self.vt.adopt_grads()
+        cur = 0
+        for a, b in sorted(self.done) + [(gs.flat.numel(), gs.flat.numel())]:
+            if a > cur:
+                self.handles.append(dist.all_reduce(gs.flat[cur:a], async_op=True))
+            cur = max(cur, b)
+        for h in self.handles:
+            h.wait()
+        self.handles, self.done = [], []

@@ -1,0 +1,331 @@
+"""Kernel sequencing for the TimeSformer divided space-time encoder (forward + backward).
+
+This is the host side of the hot path `VisionTransformer.forward_features`
+(reference lib/models/vit.py:365-423) and its autograd backward, restated as an explicit
+schedule of C-ABI kernel launches (include/pvrl.h) on torch's current HIP stream.
+
+Token layout (one fp32 residual stream buffer x[M, 768], M = B*N*T + B):
+    rows [0, R)   patch tokens ordered (b, n, t), t innermost      R = B*N*T
+    rows [R, M)   the cls token of clip b
+The reference keeps [B, 1 + N*T, C] and re-gathers it with einops for every branch
+(vit.py:130-151); here temporal sequences are 8 consecutive rows, spatial sequences are
+addressed in place by the attention kernel, and the cls rows are a small suffix, so the
+three residual branches of a block are 3 LayerNorms + 7 GEMMs + 2 attention launches and no
+copy kernels.  Activations are bf16 GEMM operands; the residual stream, LayerNorm
+statistics, softmax statistics and all parameter gradients are fp32.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class GradStore:
+    """Flat fp32 gradient buffer; every trainable parameter's .grad is a view into it so the
+    data-parallel all-reduce works on large contiguous chunks (reference: DDP buckets,
+    lib/models/build.py:49-53)."""
+
+    def __init__(self, named_params, device):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [p.numel() for p in self.params]
+        # 64-element alignment keeps every view 256-byte aligned
+        self.offsets = []
+        off = 0
+        for s in sizes:
+            self.offsets.append(off)
+            off += (s + 63) // 64 * 64
+        self.flat = torch.zeros(off, device=device, dtype=F32)
+        self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+
+    def target(self, p):
+        """-> (grad tensor to write into, beta).  beta = 0 overwrites, 1 accumulates."""
+        i = self.index[id(p)]
+        v = self.views[i]
+        if p.grad is None:
+            p.grad = v
+            return v, 0.0
+        if p.grad.data_ptr() == v.data_ptr():
+            return v, 1.0
+        # a foreign .grad tensor (someone else allocated it): accumulate into it
+        return p.grad, 1.0
+
+
+class _W:
+    """bf16 operand copies of one weight matrix: `w` = [N, K] for forward, `t` = [K, N] for the data gradient."""
+    __slots__ = ("w", "t", "ver")
+
+    def __init__(self):
+        self.w = None
+        self.t = None
+        self.ver = -1
+
+
+class EncoderEngine:
+    def __init__(self, model):
+        """`model` is a procedurevrl_amd.vit.VisionTransformer (same parameter names as the reference)."""
+        self.m = model
+        self.C = model.embed_dim
+        self.H = model.num_heads
+        self.scale = (self.C // self.H) ** -0.5
+        self.eps = model.ln_eps
+        self._w = {}
+        self._grads = None
+        self.saved = None
+        self.grad_hook = None
+        assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
+
+    # ------------------------------------------------------------------ weights
+    def _weight(self, p, need_t=True):
+        e = self._w.get(id(p))
+        if e is None:
+            e = _W()
+            self._w[id(p)] = e
+        ver = (p._version, getattr(self.m, "weights_epoch", 0), p.data_ptr())
+        if e.ver != ver or e.w is None or e.w.device != p.device:
+            w2 = p.detach().reshape(p.shape[0], -1)
+            e.w = ops.cast_scale(w2, None, out=e.w if e.w is not None and e.w.device == p.device else None)
+            if need_t:
+                e.t = ops.cast_transpose(w2.contiguous(), out=e.t if e.t is not None and e.t.device == p.device else None)
+            e.ver = ver
+        return e
+
+    def grad_store(self):
+        return self.m.grad_store()
+
+    # ------------------------------------------------------------------ drop path
+    def _droppath(self, i, B, N, T, device, training):
+        rate = self.m.drop_path_rates[i]
+        if not training or rate == 0.0:
+            return None
+        keep = 1.0 - rate
+        # lib/models/vit_utils.py:140-155: floor(keep + U[0,1)) / keep per dim-0 row of each branch
+        s1 = torch.floor(keep + torch.rand(B * N, device=device)) / keep          # temporal: per (b h w)
+        s2 = torch.floor(keep + torch.rand(B * T, device=device)) / keep          # spatial: per (b t)
+        s3 = torch.floor(keep + torch.rand(B, device=device)) / keep              # mlp: per b
+        return self.expand_droppath(s1, s2, s3, B, N, T)
+
+    @staticmethod
+    def expand_droppath(s1, s2, s3, B, N, T):
+        s1_tok = s1.repeat_interleave(T).contiguous()
+        s2_tok = s2.view(B, 1, T).expand(B, N, T).reshape(-1).contiguous()
+        s3_all = torch.cat([s3.repeat_interleave(N * T), s3]).contiguous()
+        return dict(s1_tok=s1_tok, s2_seq=s2.contiguous(), s2_tok=s2_tok, s3_all=s3_all)
+
+    # ------------------------------------------------------------------ embeddings
+    def _pos_time(self, N, T, Wp):
+        """nearest-neighbour resize of pos/time embeddings when the input differs (vit.py:375-386,398-402)."""
+        m = self.m
+        pos = m.pos_embed[0]
+        if pos.shape[0] != N + 1:
+            P = int(math.isqrt(pos.shape[0] - 1))
+            Hn = N // Wp
+            other = pos[1:].t().reshape(1, self.C, P, P)
+            other = torch.nn.functional.interpolate(other, size=(Hn, Wp), mode="nearest").flatten(2)[0].t()
+            pos = torch.cat([pos[:1], other], 0)
+        tim = m.time_embed[0]
+        if tim.shape[0] != T:
+            tim = torch.nn.functional.interpolate(tim.t().unsqueeze(0), size=T, mode="nearest")[0].t()
+        return pos.contiguous(), tim.contiguous()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, frames, training, droppath=None, save=True):
+        """frames fp32 [B, 3, T, H, W] on the GPU -> (feat fp32 [B, C] = norm(x)[:, 0]).
+        `droppath`: optional list (per block) of dicts from expand_droppath, to pin the RNG draws."""
+        L = lib()
+        m = self.m
+        B, _, T, HI, WI = frames.shape
+        Wp = WI // 16
+        N = (HI // 16) * Wp
+        R = B * N * T
+        M = R + B
+        C = self.C
+        dev = frames.device
+        sv = dict(B=B, T=T, N=N, R=R, M=M, Wp=Wp, blocks=[])
+
+        a_pe = ops.patchify(frames.contiguous())
+        pos, tim = self._pos_time(N, T, Wp)
+        E = ops.embed_table(pos, tim, m.patch_embed.proj.bias.detach(), N, T)
+        x = torch.empty((M, C), device=dev, dtype=F32)
+        wpe = self._weight(m.patch_embed.proj.weight, need_t=False)
+        ops.gemm_nt(a_pe, wpe.w, L.PVRL_EPI_RESID_F32, aux=E, aux_rowmod=N * T, out0=x[:R])
+        x[R:] = (m.cls_token.detach()[0, 0] + pos[0]).unsqueeze(0)
+        sv["a_pe"] = a_pe if save else None
+
+        for i, blk in enumerate(m.blocks):
+            dp = droppath[i] if droppath is not None else self._droppath(i, B, N, T, dev, training)
+            x = self._block_fwd(blk, x, sv, dp, save)
+
+        feat, mean, rstd = ops.layernorm_fwd(x[R:], m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
+                                             out_dtype=F32)
+        if save:
+            sv["x_final"] = x
+            sv["norm_stats"] = (mean, rstd)
+            self.saved = sv
+        return feat
+
+    def _block_fwd(self, blk, x0, sv, dp, save):
+        L = lib()
+        B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
+        C, H = self.C, self.H
+        dev = x0.device
+        s1_tok = dp["s1_tok"] if dp else None
+        s2_seq = dp["s2_seq"] if dp else None
+        s2_tok = dp["s2_tok"] if dp else None
+        s3_all = dp["s3_all"] if dp else None
+        P = lambda t: t.detach()
+
+        # ---- temporal branch (vit.py:129-135), rows [0, R) ----
+        h_t, mean_t, rstd_t = ops.layernorm_fwd(x0[:R], P(blk.temporal_norm1.weight), P(blk.temporal_norm1.bias), self.eps)
+        qkv_t = ops.gemm_nt(h_t, self._weight(blk.temporal_attn.qkv.weight).w, L.PVRL_EPI_BF16,
+                            bias=P(blk.temporal_attn.qkv.bias))
+        lse_t = None
+        if T == 8:
+            o_t = ops.attn_t8_fwd(qkv_t, B * N, H, self.scale)
+        else:
+            o_t, _, lse_t = ops.attn_fwd(qkv_t, B * N, T, H, self.scale, mode=0)
+        p_t = ops.gemm_nt(o_t, self._weight(blk.temporal_attn.proj.weight).w, L.PVRL_EPI_BF16,
+                          bias=P(blk.temporal_attn.proj.bias), rowscale=s1_tok)
+        x1 = torch.empty_like(x0)
+        ops.gemm_nt(p_t, self._weight(blk.temporal_fc.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.temporal_fc.bias),
+                    aux=x0[:R], out0=x1[:R])
+        x1[R:] = x0[R:]
+
+        # ---- spatial branch (vit.py:137-151), all rows; cls of clip b is token 0 of its T sequences ----
+        h_s, mean_s, rstd_s = ops.layernorm_fwd(x1, P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
+        qkv_s = ops.gemm_nt(h_s, self._weight(blk.attn.qkv.weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
+        o_s = torch.empty((R + B * T, C), device=dev, dtype=BF16)
+        _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
+        x2 = torch.empty_like(x0)
+        wproj = self._weight(blk.attn.proj.weight).w
+        ops.gemm_nt(o_s[:R], wproj, L.PVRL_EPI_RESID_F32, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1[:R],
+                    out0=x2[:R])
+        pc = ops.gemm_nt(o_s[R:], wproj, L.PVRL_EPI_F32, bias=P(blk.attn.proj.bias))
+        ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1[R:], out=x2[R:])
+
+        # ---- MLP (vit.py:155-157) ----
+        h_m, mean_m, rstd_m = ops.layernorm_fwd(x2, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
+        u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
+        x3 = torch.empty_like(x0)
+        ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
+                    rowscale=s3_all, aux=x2, out0=x3)
+        if save:
+            sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
+                                     lse_t=lse_t, p_t=p_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
+                                     lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp))
+        return x3
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dfeat):
+        """dfeat fp32 [B, C]: gradient of the loss w.r.t. forward()'s output.  Writes every encoder
+        parameter gradient into the GradStore views (p.grad) and returns nothing."""
+        L = lib()
+        m = self.m
+        sv = self.saved
+        assert sv is not None, "backward() without a saved forward()"
+        gs = self.grad_store()
+        B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
+        C = self.C
+        dev = dfeat.device
+
+        dx = torch.zeros((M, C), device=dev, dtype=F32)
+        mean, rstd = sv["norm_stats"]
+        (dg, bg), (db, bb) = gs.target(m.norm.weight), gs.target(m.norm.bias)
+        ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
+                          dx_out=dx[R:], beta_acc=bg)
+
+        for i in range(len(m.blocks) - 1, -1, -1):
+            self._block_bwd(m.blocks[i], sv["blocks"][i], sv, dx, gs)
+            sv["blocks"][i] = None  # free activations as we go
+            if self.grad_hook is not None:
+                self.grad_hook(i)   # block i's parameter gradients are final: the reducer may start its all-reduce
+
+        # ---- embedding prologue + patch embed (vit.py:174-180, 370-407) ----
+        dz = ops.cast_scale(dx[:R], None)
+        w = m.patch_embed.proj.weight
+        (dw, bw), (dbias, _) = gs.target(w), gs.target(m.patch_embed.proj.bias)
+        ops.gemm_tn(dz, sv["a_pe"], dw.view(C, -1), dbias, beta=bw)
+        G = ops.batch_sum(dx[:R], B, N * T).view(N, T, C)
+        dcls_rows = dx[R:].sum(0)
+        self._acc(gs, m.cls_token, dcls_rows.view(1, 1, C))
+        dpos = torch.cat([dcls_rows.unsqueeze(0), G.sum(1)], 0)
+        dtime = G.sum(0)
+        pos_p, tim_p = m.pos_embed, m.time_embed
+        if pos_p.shape[1] != N + 1 or tim_p.shape[1] != T:
+            raise NotImplementedError("training with resized pos/time embeddings is not supported (reference "
+                                      "resizes at inference only, vit.py:374)")
+        self._acc(gs, pos_p, dpos.unsqueeze(0))
+        self._acc(gs, tim_p, dtime.unsqueeze(0))
+        self.saved = None
+
+    @staticmethod
+    def _acc(gs, p, g):
+        tgt, beta = gs.target(p)
+        if beta == 0.0:
+            tgt.copy_(g.view_as(tgt))
+        else:
+            tgt.add_(g.view_as(tgt))
+
+    def _block_bwd(self, blk, s, sv, dx, gs):
+        L = lib()
+        B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
+        C, H = self.C, self.H
+        dev = dx.device
+        dp = s["dp"]
+        s1_tok = dp["s1_tok"] if dp else None
+        s2_seq = dp["s2_seq"] if dp else None
+        s2_tok = dp["s2_tok"] if dp else None
+        s3_all = dp["s3_all"] if dp else None
+        P = lambda t: t.detach()
+
+        def wgrad(dy, xin, lin):
+            (dw, bw), (dbias, _) = gs.target(lin.weight), gs.target(lin.bias)
+            ops.gemm_tn(dy, xin, dw, dbias, beta=bw)
+
+        def lnbwd(dh, x, st, ln, dx_in, dx_out):
+            (dg, bg), (db, _) = gs.target(ln.weight), gs.target(ln.bias)
+            ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg)
+
+        # ---- MLP ----
+        dy = ops.cast_scale(dx, s3_all)
+        wgrad(dy, s["g"], blk.mlp.fc2)
+        du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
+        wgrad(du, s["h_m"], blk.mlp.fc1)
+        dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
+        del du
+        lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx)
+
+        # ---- spatial ----
+        dps = torch.empty((R + B * T, C), device=dev, dtype=BF16)
+        ops.cast_scale(dx[:R], s2_tok, out=dps[:R])
+        ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
+        wgrad(dps, s["o_s"], blk.attn.proj)
+        do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
+        dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=BF16)
+        ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
+                     mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
+        ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
+        wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
+        dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
+        del dqkv, do, dps
+        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx)
+
+        # ---- temporal (rows [0, R); cls rows pass straight through) ----
+        dz = ops.cast_scale(dx[:R], None)
+        wgrad(dz, s["p_t"], blk.temporal_fc)
+        dpt = ops.gemm_nt(dz, self._weight(blk.temporal_fc.weight).t, L.PVRL_EPI_BF16, rowscale=s1_tok)
+        wgrad(dpt, s["o_t"], blk.temporal_attn.proj)
+        dot = ops.gemm_nt(dpt, self._weight(blk.temporal_attn.proj.weight).t, L.PVRL_EPI_BF16)
+        if T == 8:
+            dqkv_t = ops.attn_t8_bwd(s["qkv_t"], dot, B * N, H, self.scale)
+        else:
+            dqkv_t, _ = ops.attn_bwd(s["qkv_t"], s["o_t"], None, dot, None, s["lse_t"], B * N, T, H, self.scale, mode=0)
+        wgrad(dqkv_t, s["h_t"], blk.temporal_attn.qkv)
+        dh = ops.gemm_nt(dqkv_t, self._weight(blk.temporal_attn.qkv.weight).t, L.PVRL_EPI_BF16)
+        lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R])

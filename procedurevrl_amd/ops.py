@@ -13,6 +13,44 @@ from ._lib import lib, PvrlError
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+# When set to a list, gemm launches are bracketed with events on the launch stream (bench.py roofline leg).
+KERNEL_TIMING = None
+_EPI_NAMES = {0: "bf16", 1: "gelu", 2: "qgelu", 3: "resid_f32", 4: "f32", 5: "dgelu", 6: "dqgelu"}
+
+
+def _timed(name, flops, fn):
+    if KERNEL_TIMING is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    KERNEL_TIMING.append((name, flops, e0, e1))
+    return r
+
+
+def collect_kernel_timing():
+    """-> {"roofline": {...dominant kernel...}, "summary": {name: {calls, ms, tflops}}}"""
+    if not KERNEL_TIMING:
+        return None
+    torch.cuda.synchronize()
+    agg = {}
+    for name, flops, e0, e1 in KERNEL_TIMING:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += flops
+    summary = {k: {"calls": v[0], "ms": round(v[1], 3), "avg_us": round(1e3 * v[1] / v[0], 2),
+                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in agg.items()}
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (calls, ms, flops) = dom[0], dom[1]
+    ach = flops / (ms * 1e-3) / 1e12
+    roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(ach / 2500.0, 4), "traffic": None, "calls": calls, "avg_launch_us": round(1e3 * ms / calls, 2),
+            "flops_per_launch_avg": flops / calls}
+    return {"roofline": roof, "summary": summary}
+
 
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -23,7 +61,7 @@ def _stream():
 
 
 def _chk2d(t, dtype=None):
-    if t.dim() != 2 or t.stride(1) != 1:
+    if t.dim() != 2 or (t.stride(1) != 1 and t.shape[1] != 1):
         raise PvrlError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} stride {t.stride()}")
     if not t.is_cuda:
         raise PvrlError("the HIP path needs device tensors (no CPU fallback)")
@@ -52,9 +90,10 @@ def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=No
     two = epi in (L.PVRL_EPI_GELU, L.PVRL_EPI_QGELU)
     if two and out1 is None:
         out1 = torch.empty((M, N), device=A.device, dtype=BF16)
-    L.call("pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
-           _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
-           _ptr(out1), _ld(out1) if out1 is not None else 0, _stream())
+    _timed("gemm_nt_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K, lambda: L.call(
+        "pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
+        _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
+        _ptr(out1), _ld(out1) if out1 is not None else 0, _stream()))
     return (out0, out1) if two else out0
 
 
@@ -99,8 +138,9 @@ def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None):
         splits = tn_splits(M, N, K)
     nbytes = L.call("pvrl_gemm_tn_workspace_bytes", N, K, splits)
     ws = workspace(nbytes, P.device, "tn")
-    L.call("pvrl_gemm_tn_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), _ptr(dbias),
-           _ptr(ws), ws.numel(), _stream())
+    _timed("gemm_tn_kernel+reduce", 2.0 * M * N * K, lambda: L.call(
+        "pvrl_gemm_tn_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), _ptr(dbias),
+        _ptr(ws), ws.numel(), _stream()))
     return dW
 
 

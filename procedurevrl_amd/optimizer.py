@@ -1,0 +1,189 @@
+"""Optimiser construction + fused HIP step.
+
+`construct_optimizer(model, cfg)` reproduces the parameter grouping of the reference
+lib/models/optimizer.py:10-91 (pre-training: [bn (empty for ViT), non-bn + text] with `lr_mult`;
+fine-tuning: encoder group with TRAIN.MULT / BN.WEIGHT_DECAY and head+order group) and its
+hyper-parameters (:93-118).  `get_epoch_lr` / `set_lr` are optimizer.py:121-142.  The step itself is
+one fused kernel per contiguous parameter range of the model's flat buffers (csrc/optim.hip)
+instead of torch.optim's per-tensor foreach loops; numerics follow torch.optim.{SGD, Adam, AdamW}.
+"""
+import ctypes
+
+import torch
+
+from . import lr_policy
+from ._lib import lib
+
+
+def _inner(model):
+    m = model.module if hasattr(model, "module") else model
+    return m.model if hasattr(m, "model") and hasattr(m.model, "grad_store") else m
+
+
+class FusedOptimizer(torch.optim.Optimizer):
+    def __init__(self, params, model, method, lr, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=0.0,
+                 betas=(0.9, 0.999), eps=1e-8):
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, nesterov=nesterov, weight_decay=weight_decay,
+                        betas=betas, eps=eps)
+        super().__init__(params, defaults)
+        assert method in ("sgd", "adam", "adamw")
+        self.method = method
+        self.vt = _inner(model)
+        self.flat_p = None
+        self.buf1 = None   # exp_avg / momentum buffer
+        self.buf2 = None   # exp_avg_sq
+        self.steps = 0
+        self.grad_scale = 1.0
+
+    # -- flat storage -----------------------------------------------------------------------
+    def _ensure_flat(self):
+        gs = self.vt.grad_store()
+        ok = self.flat_p is not None and self.flat_p.device == gs.flat.device and self.flat_p.numel() == gs.flat.numel()
+        if ok:
+            for p, o in zip(gs.params[:4], gs.offsets[:4]):
+                ok &= p.data_ptr() == self.flat_p.data_ptr() + 4 * o
+        if not ok:
+            old1, old2 = self.buf1, self.buf2
+            self.flat_p = torch.zeros_like(gs.flat)
+            for p, o in zip(gs.params, gs.offsets):
+                v = self.flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+            self.buf1 = torch.zeros_like(gs.flat) if old1 is None or old1.numel() != gs.flat.numel() else old1.to(gs.flat.device)
+            self.buf2 = (torch.zeros_like(gs.flat) if old2 is None or old2.numel() != gs.flat.numel()
+                         else old2.to(gs.flat.device)) if self.method != "sgd" else None
+        return gs
+
+    def _runs(self, gs, params, had_grad):
+        idx = sorted(gs.index[id(p)] for p in params if id(p) in gs.index and had_grad[gs.index[id(p)]])
+        runs = []
+        for i in idx:
+            a = gs.offsets[i]
+            b = gs.offsets[i + 1] if i + 1 < len(gs.offsets) else gs.flat.numel()
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L = lib()
+        gs0 = self.vt.grad_store()
+        had_grad = [p.grad is not None for p in gs0.params]
+        self.vt.adopt_grads()
+        gs = self._ensure_flat()
+        self.steps += 1
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        base_p, base_g = self.flat_p.data_ptr(), gs.flat.data_ptr()
+        base_1 = self.buf1.data_ptr()
+        base_2 = self.buf2.data_ptr() if self.buf2 is not None else 0
+        vp = ctypes.c_void_p
+        for g in self.param_groups:
+            for a, b in self._runs(gs, g["params"], had_grad):
+                n, o = b - a, 4 * a
+                if self.method == "sgd":
+                    L.call("pvrl_sgd_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), n, float(g["lr"]),
+                           float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]),
+                           1 if g["nesterov"] else 0, 1 if self.steps == 1 else 0, float(self.grad_scale), stream)
+                else:
+                    L.call("pvrl_adam_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), vp(base_2 + o), n,
+                           float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                           float(g["weight_decay"]), self.steps, float(self.grad_scale),
+                           1 if self.method == "adamw" else 0, stream)
+        self._bump(gs)
+        return None
+
+    def _bump(self, gs):
+        # parameters changed in place through the flat buffer: tell the bf16 operand cache to refresh
+        self.vt.weights_epoch = getattr(self.vt, "weights_epoch", 0) + 1
+
+    # -- torch.optim-compatible state (checkpoint `optimizer_state`, lib/utils/checkpoint.py:126-131) ---------
+    def state_dict(self):
+        sd = {"param_groups": [], "state": {}, "fused": {"steps": self.steps, "method": self.method}}
+        k = 0
+        gs = self.vt.grad_store() if self.flat_p is not None else None
+        for g in self.param_groups:
+            pg = {x: y for x, y in g.items() if x != "params"}
+            pg["params"] = list(range(k, k + len(g["params"])))
+            for j, p in enumerate(g["params"]):
+                if gs is not None and id(p) in gs.index:
+                    i = gs.index[id(p)]
+                    a, n = gs.offsets[i], p.numel()
+                    if self.method == "sgd":
+                        sd["state"][k + j] = {"momentum_buffer": self.buf1[a:a + n].view(p.shape).clone()}
+                    else:
+                        sd["state"][k + j] = {"step": torch.tensor(float(self.steps)),
+                                              "exp_avg": self.buf1[a:a + n].view(p.shape).clone(),
+                                              "exp_avg_sq": self.buf2[a:a + n].view(p.shape).clone()}
+            k += len(g["params"])
+            sd["param_groups"].append(pg)
+        return sd
+
+    def load_state_dict(self, sd):
+        gs = self._ensure_flat()
+        self.steps = int(sd.get("fused", {}).get("steps", 0))
+        k = 0
+        for g, pg in zip(self.param_groups, sd["param_groups"]):
+            for key, val in pg.items():
+                if key != "params":
+                    g[key] = val
+            for j, p in enumerate(g["params"]):
+                st = sd["state"].get(k + j)
+                if st is None or id(p) not in gs.index:
+                    continue
+                i = gs.index[id(p)]
+                a, n = gs.offsets[i], p.numel()
+                if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                    self.buf1[a:a + n].copy_(st["momentum_buffer"].reshape(-1))
+                if "exp_avg" in st:
+                    self.buf1[a:a + n].copy_(st["exp_avg"].reshape(-1))
+                    self.buf2[a:a + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.steps = max(self.steps, int(float(st.get("step", 0))))
+            k += len(g["params"])
+
+
+def construct_optimizer(model, cfg):
+    """Parameter groups per lib/models/optimizer.py:18-91."""
+    text = []
+    if cfg.TRAIN.MULT != 1.0 or cfg.TRAIN.LINEAR:           # fine-tuning
+        enc, rest = [], []
+        for name, p in model.named_parameters():
+            if "head" not in name and "order" not in name:
+                enc.append(p)
+                if cfg.TRAIN.LINEAR:
+                    p.requires_grad = False
+            else:
+                rest.append(p)
+        if cfg.TRAIN.LINEAR:
+            optim_params = [{"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY, "lr": cfg.SOLVER.BASE_LR, "lr_mult": 1.0}]
+        else:
+            optim_params = [{"params": enc, "weight_decay": cfg.BN.WEIGHT_DECAY, "lr_mult": cfg.TRAIN.MULT},
+                            {"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY, "lr_mult": 1.0}]
+    else:                                                    # pre-training
+        bn, non_bn = [], []
+        for name, p in model.named_parameters():
+            if "bn" in name:
+                bn.append(p)
+            elif "text_model" in name or "text_module" in name:
+                text.append(p)
+                if cfg.TRAIN.MULT == 0:
+                    p.requires_grad = False
+            else:
+                non_bn.append(p)
+        optim_params = [{"params": bn, "weight_decay": cfg.BN.WEIGHT_DECAY, "lr_mult": 1.0},
+                        {"params": non_bn + text, "weight_decay": cfg.SOLVER.WEIGHT_DECAY, "lr_mult": 1.0}]
+    s = cfg.SOLVER
+    if s.OPTIMIZING_METHOD not in ("sgd", "adam", "adamw"):
+        raise NotImplementedError("Does not support {} optimizer".format(s.OPTIMIZING_METHOD))
+    return FusedOptimizer(optim_params, model, s.OPTIMIZING_METHOD, lr=s.BASE_LR, momentum=s.MOMENTUM,
+                          dampening=s.DAMPENING, nesterov=s.NESTEROV, weight_decay=s.WEIGHT_DECAY)
+
+
+def get_epoch_lr(cur_epoch, cfg):
+    return lr_policy.get_lr_at_epoch(cfg, cur_epoch)
+
+
+def set_lr(optimizer, new_lr):
+    for g in optimizer.param_groups:
+        g["lr"] = new_lr * g["lr_mult"] if "lr_mult" in g else new_lr

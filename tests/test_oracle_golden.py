@@ -1,0 +1,161 @@
+"""The CPU oracle (oracle/timesformer_oracle.py) against the golden vectors produced by the UNMODIFIED reference
+(tests/golden/make_golden.py).  This is what pins the oracle; fp32 vs fp32, so the bar is 1e-5 relative."""
+import os
+
+import pytest
+import torch
+
+from oracle import timesformer_oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 2e-5
+
+
+def load(name):
+    return torch.load(os.path.join(G, name + ".pt"), weights_only=False)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+@pytest.mark.parametrize("name", ["attn_s8", "attn_s197"])
+def test_attention(name):
+    f = load(name)
+    shapes = {"qkv.weight": (2304, 768), "qkv.bias": (2304,), "proj.weight": (768, 768), "proj.bias": (768,)}
+    sd = orc.seeded_state(shapes, f["seed"])
+    assert abs(checksum(sd) - f["wsum"]) < 1e-6 * f["wsum"]
+    assert rel(orc.attention(sd, "", f["x"]), f["y"]) < TOL
+
+
+def block_state(seed):
+    sh = {k[len("blocks.0."):]: v for k, v in orc.encoder_shapes(1).items() if k.startswith("blocks.0.")}
+    return orc.seeded_state(sh, seed)
+
+
+def test_block_forward_backward():
+    f = load("block")
+    sd = {k: v.requires_grad_(True) for k, v in block_state(f["seed"]).items()}
+    assert abs(checksum(sd) - f["wsum"]) < 1e-6 * f["wsum"]
+    x = f["x"].clone().requires_grad_(True)
+    y = orc.block(sd, "", x, f["B"], f["T"], f["W"])
+    assert rel(y, f["y"]) < TOL
+    y.backward(f["dy"])
+    assert rel(x.grad, f["dx"]) < TOL
+    for k, g in f["grads"].items():
+        assert rel(sd[k].grad, g) < 1e-4, k
+    for k, s in f["grad_sums"].items():
+        assert abs(float(sd[k].grad.double().abs().sum()) - s) < 1e-3 * max(s, 1e-6), k
+
+
+def e2e_state(f):
+    K = f["K"]
+    sh = orc.encoder_shapes(f["depth"], 8, (f["crop"] // 16) ** 2)
+    sh.update(orc_order_shapes())
+    sh.update(orc_text_shapes(f["text_layers"]))
+    sh = {"model." + k: v for k, v in sh.items()}
+    return sh
+
+
+def orc_order_shapes(layers=4, w=512, L=9):
+    sh = {"order_tfm.pad_embedding.weight": (1, w), "order_tfm.type_embedding.weight": (2, w),
+          "order_tfm.temporalEmbedding.weight": (L, w), "order_tfm.time_mlp.1.weight": (w, w // 4),
+          "order_tfm.time_mlp.1.bias": (w,), "order_tfm.time_mlp.3.weight": (w, w), "order_tfm.time_mlp.3.bias": (w,)}
+    sh.update(stack_shapes("order_tfm.temporalModelling.", layers, w))
+    return sh
+
+
+def stack_shapes(pre, layers, w):
+    sh = {}
+    for i in range(layers):
+        p = f"{pre}resblocks.{i}."
+        sh.update({p + "attn.in_proj_weight": (3 * w, w), p + "attn.in_proj_bias": (3 * w,),
+                   p + "attn.out_proj.weight": (w, w), p + "attn.out_proj.bias": (w,),
+                   p + "ln_1.weight": (w,), p + "ln_1.bias": (w,), p + "ln_2.weight": (w,), p + "ln_2.bias": (w,),
+                   p + "mlp.c_fc.weight": (4 * w, w), p + "mlp.c_fc.bias": (4 * w,),
+                   p + "mlp.c_proj.weight": (w, 4 * w), p + "mlp.c_proj.bias": (w,)})
+    return sh
+
+
+def orc_text_shapes(layers, w=512):
+    sh = {"text_model.token_embedding.weight": (49408, w), "text_model.positional_embedding": (77, w),
+          "text_model.ln_final.weight": (w,), "text_model.ln_final.bias": (w,), "text_model.text_projection": (w, w),
+          "text_model.logit_scale": ()}
+    sh.update(stack_shapes("text_model.transformer.", layers, w))
+    return sh
+
+
+def test_e2e_state_dict_keys_match_reference():
+    f = load("e2e")
+    assert sorted(e2e_state(f).keys()) == f["state_keys"]
+
+
+def test_e2e_train_forward_loss_grads():
+    f = load("e2e")
+    full = orc.seeded_state(e2e_state(f), f["seed"])
+    assert abs(checksum(full) - f["wsum"]) < 1e-6 * f["wsum"]
+    sd = {k[len("model."):]: v.requires_grad_(not k.startswith("model.text_model")) for k, v in full.items()}
+    meta = {"clip_text_ids": f["clip_text_ids"], "clip_vis_feat": f["clip_vis_feat"]}
+    pred, teacher, mse = orc.vit_forward_train(sd, f["inputs"], meta, f["label_emb"], 0.02, f["depth"], 9, 4,
+                                               f["text_layers"], f["rng"])
+    assert rel(pred, f["pred"]) < 1e-4
+    assert rel(teacher, f["teacher"]) < 1e-4
+    assert rel(mse[0], f["mse0"]) < 1e-4 and rel(mse[1], f["mse1"]) < 1e-4
+    loss, l1, l2 = orc.pretrain_loss(pred, teacher, mse, 5)
+    assert abs(float(l1) - f["loss1"]) < 1e-4 * abs(f["loss1"])
+    assert abs(float(l2) - f["loss2"]) < 1e-4 * abs(f["loss2"])
+    loss.backward()
+    for k, g in f["grads"].items():
+        assert rel(sd[k[len("model."):]].grad, g) < 2e-3, k
+    for k, s in f["grad_sums"].items():
+        got = float(sd[k[len("model."):]].grad.double().abs().sum())
+        assert abs(got - s) < 5e-3 * max(s, 1e-6), (k, got, s)
+
+
+def test_forward_features_eval():
+    f = load("features")
+    e = load("e2e")
+    full = orc.seeded_state(e2e_state(e), f["seed"])
+    sd = {k[len("model."):]: v for k, v in full.items()}
+    with torch.no_grad():
+        feat = orc.forward_features(sd, f["x"], e["depth"])
+    assert rel(feat, f["feat"]) < TOL
+
+
+def test_milnce():
+    f = load("milnce")
+    assert abs(float(orc.milnce(f["v"], f["t"])) - f["loss"]) < 1e-5 * abs(f["loss"])
+
+
+def test_droppath_formula():
+    f = load("droppath_formula")
+    assert rel(orc.drop_path_apply(f["x"], f["mask"]), f["y"]) < 1e-6
+
+
+def test_allgather_semantics():
+    f = load("allgather")
+    out, grads = orc.allgather_forward_backward([r["x"] for r in f], [r["w"] for r in f])
+    for r, g in zip(f, grads):
+        assert torch.equal(out, r["y"])
+        assert torch.equal(g, r["grad"])
+
+
+def test_lr_table():
+    from procedurevrl_amd.config import get_cfg
+    from procedurevrl_amd import lr_policy
+    tab = load("lr_table")
+    sched = {"procedurevrl_sgd": dict(BASE_LR=0.005, STEPS=[0, 2, 4], MAX_EPOCH=5),
+             "procedurevrl_adamw": dict(BASE_LR=5e-5, STEPS=[0, 15, 23], MAX_EPOCH=25)}
+    for name, t in tab.items():
+        cfg = get_cfg()
+        cfg.SOLVER.LR_POLICY = "steps_with_relative_lrs"
+        cfg.SOLVER.LRS = [1, 0.1, 0.01]
+        for k, v in sched[name].items():
+            cfg.SOLVER[k] = v
+        for ep, lr in zip(t["epochs"], t["lrs"]):
+            assert abs(orc.lr_at_epoch(cfg, ep) - lr) < 1e-12
+            assert abs(lr_policy.get_lr_at_epoch(cfg, ep) - lr) < 1e-12

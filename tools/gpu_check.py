@@ -13,10 +13,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def main():
     import torch
     import kernel_checks as kc
+    import e2e_checks as ec
     names = sys.argv[1:]
     rows = []
     ok = True
-    for chk in kc.ALL_CHECKS:
+    for chk in kc.ALL_CHECKS + ec.ALL_CHECKS:
         if names and not any(n in chk.__name__ for n in names):
             continue
         t0 = time.time()
