@@ -374,7 +374,12 @@ def seeded_state(shapes, seed):
 def timed_train_step(clips=2, frames=8, classes=9871, threads=8, repeats=1):
     """One full training step of BASELINE config 2's workload (encoder fwd, head + step logits + top-5 KL,
     backward, AdamW) on the host CPU in eager fp32, on a bounded sample of `clips` clips."""
-    torch.set_num_threads(threads)
+    try:
+        import os
+        threads = min(int(threads), len(os.sched_getaffinity(0)), 32)   # > 32 eager threads only add contention
+    except Exception:
+        threads = min(int(threads), 32)
+    torch.set_num_threads(max(1, threads))
     sd = seeded_state(encoder_shapes(12, frames), 0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.AdamW(list(params.values()), lr=5e-5, weight_decay=1e-4)

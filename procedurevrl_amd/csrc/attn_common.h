@@ -57,17 +57,50 @@ __device__ __forceinline__ bf16x8 bl_frag(const char* tile, int ks2, int ct, int
   return tr_frag8(tile, o0, o1);
 }
 
-// Cooperative load of one head slice [S rows][64] of a packed activation into LDS.
-// rm / bl may each be null.  Rows >= S (up to zero_rows) are zero-filled.
-__device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int col0, const SeqMap& mp, int seq,
-                                               char* rm, int rm_rows, char* bl, int bl_rows, int tid) {
+// Per-workgroup view of one sequence: row(j) without per-element integer division.
+struct SeqRows {
+  long base0;   // row of token 0
+  long base1;   // row of token 1
+  long stride;  // row distance between tokens j and j+1 (j >= 1)
+};
+__device__ __forceinline__ SeqRows seq_rows(const SeqMap& mp, int seq) {
+  SeqRows r;
+  if (mp.mode == 0) {
+    r.base0 = (long)seq * mp.S; r.base1 = r.base0 + 1; r.stride = 1;
+  } else {
+    const int b = seq / mp.T, t = seq - b * mp.T;
+    r.base0 = mp.cls_base + b; r.base1 = (long)b * (mp.S - 1) * mp.T + t; r.stride = mp.T;
+  }
+  return r;
+}
+__device__ __forceinline__ long row_of(const SeqRows& r, int j) { return j == 0 ? r.base0 : r.base1 + (long)(j - 1) * r.stride; }
+
+// Cooperative load of one head slice [S rows][64] of a packed activation into LDS (256 threads).
+// All global loads of the tile are issued before the first LDS store so their latencies overlap
+// (7 x 16 B in flight per thread for S = 197).  `src0` (optional) overrides the source row of token 0
+// (side buffer of the per-(b,t) cls rows).  rm / bl may each be null.  Rows >= S are zero-filled.
+constexpr int ATT_LOAD_ITERS = (ATT_ROWS_PAD * 8) / 256;   // 7
+__device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int col0, const SeqRows& sr, int S,
+                                               const bf16* src0, char* rm, int rm_rows, char* bl, int bl_rows,
+                                               int tid) {
   const int maxrows = rm_rows > bl_rows ? rm_rows : bl_rows;
-  for (int idx = tid; idx < maxrows * 8; idx += 256) {
+  u32x4 v[ATT_LOAD_ITERS];
+#pragma unroll
+  for (int it = 0; it < ATT_LOAD_ITERS; ++it) {
+    const int idx = tid + 256 * it;
     const int row = idx >> 3, c = idx & 7;
-    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-    if (row < mp.S) v = *reinterpret_cast<const u32x4*>(base + seq_row(mp, seq, row) * ld + col0 + c * 8);
-    if (rm && row < rm_rows) *reinterpret_cast<u32x4*>(rm + rm_off(row, c)) = v;
-    if (bl && row < bl_rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = v;
+    v[it] = (u32x4){0u, 0u, 0u, 0u};
+    if (row < S && row < maxrows) {
+      const bf16* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
+      v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ATT_LOAD_ITERS; ++it) {
+    const int idx = tid + 256 * it;
+    const int row = idx >> 3, c = idx & 7;
+    if (rm && row < rm_rows) *reinterpret_cast<u32x4*>(rm + rm_off(row, c)) = v[it];
+    if (bl && row < bl_rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = v[it];
   }
 }
 

@@ -44,9 +44,9 @@ __device__ __forceinline__ bool key_masked(const AttnArgs& p, int seq, int query
 
 // row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
 template <typename T>
-__device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, int seq, int j) {
+__device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, const SeqRows& sr, int seq, int j) {
   if (mp.mode == 1 && j == 0) return cls + (long)seq * ld;
-  return tok + seq_row(mp, seq, j) * ld;
+  return tok + row_of(sr, j) * ld;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -64,15 +64,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
 
-  load_head_tile(p.qkv, p.ld, HD + h * 64, p.mp, seq, Kr, nkt * 16, nullptr, 0, tid);
-  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, p.mp, seq, nullptr, 0, Vb, nks2 * 32, tid);
+  const SeqRows sr = seq_rows(p.mp, seq);
+  load_head_tile(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, nkt * 16, nullptr, 0, tid);
+  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, nks2 * 32, tid);
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
   for (int qt = wave; qt < nkt; qt += 4) {
     const int query = qt * 16 + i;
     const int qrow = query < S ? query : S - 1;
-    const bf16* qp = p.qkv + seq_row(p.mp, seq, qrow) * p.ld + h * 64 + q4 * 8;
+    const bf16* qp = p.qkv + row_of(sr, qrow) * p.ld + h * 64 + q4 * 8;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       }
     }
     if (query < S) {
-      bf16* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, seq, query) + h * 64 + 4 * q4;
+      bf16* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, sr, seq, query) + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
@@ -167,21 +168,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
   const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
 
-  load_head_tile(p.qkv, p.ld, HD + h * 64, p.mp, seq, Kr, nkt * 16, Kb, nks2 * 32, tid);
-  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, p.mp, seq, Vr, nkt * 16, nullptr, 0, tid);
+  const SeqRows sr = seq_rows(p.mp, seq);
+  load_head_tile(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, nkt * 16, Kb, nks2 * 32, tid);
+  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, Vr, nkt * 16, nullptr, 0, tid);
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
   for (int qt = wave; qt < nkt; qt += 4) {
     const int query = qt * 16 + i;
     const int qj = query < S ? query : S - 1;
-    const bf16* qp = p.qkv + seq_row(p.mp, seq, qj) * p.ld + h * 64 + q4 * 8;
+    const bf16* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
-    const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, seq, qj) + h * 64 + q4 * 8;
+    const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
     const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop);
     const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32);
-    const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, seq, qj) + h * 64 + q4 * 8;
+    const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
     const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(ofp);
     const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(ofp + 32);
     float dsum = 0.f;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
       }
     }
     if (query < S) {
-      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, seq, query) + h * 64 + 4 * q4;
+      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, query) + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
@@ -271,15 +273,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
   const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
 
-  load_head_tile(p.qkv, p.ld, h * 64, p.mp, seq, Qr, nks2 * 32, Qb, nks2 * 32, tid);
+  const SeqRows sr = seq_rows(p.mp, seq);
+  load_head_tile(p.qkv, p.ld, h * 64, sr, S, nullptr, Qr, nks2 * 32, Qb, nks2 * 32, tid);
   {  // dO tile: token 0 may live in the side buffer (mode 1)
-    for (int idx = tid; idx < nks2 * 32 * 8; idx += 256) {
-      const int row = idx >> 3, c = idx & 7;
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (row < S) v = *reinterpret_cast<const u32x4*>(tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, seq, row) + h * 64 + c * 8);
-      *reinterpret_cast<u32x4*>(Dr + rm_off(row, c)) = v;
-      *reinterpret_cast<u32x4*>(Db + bl_off(row, c * 8)) = v;
-    }
+    const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;
+    load_head_tile(p.d_o, p.ldo, h * 64, sr, S, src0, Dr, nks2 * 32, Db, nks2 * 32, tid);
     for (int idx = tid; idx < ATT_ROWS_PAD; idx += 256) {
       const long stat = ((long)seq * p.H + h) * S + idx;
       lse_s[idx] = idx < S ? p.lse[stat] : 0.f;
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
   for (int kt = wave; kt < nkt; kt += 4) {
     const int key = kt * 16 + i;
     const int kj = key < S ? key : S - 1;
-    const bf16* kp = p.qkv + seq_row(p.mp, seq, kj) * p.ld + HD + h * 64 + q4 * 8;
+    const bf16* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
     const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp);
     const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
     const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(kp + HD);
@@ -340,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
       }
     }
     if (key < S) {
-      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, seq, key) + HD + h * 64 + 4 * q4;
+      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, key) + HD + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ok, ov;

@@ -101,20 +101,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
     const char* bx = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* bw = bx + TILE_BYTES;
+    // all 16 fragment reads of the K-step are issued up front; the MFMAs of the first half overlap the
+    // LDS latency of the second half (the compiler otherwise serialises read -> wait(0) -> 8 MFMAs)
+    bf16x8 xf0[4], wf0[4], xf1[4], wf1[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 xf[4], wf[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xf[t] = *reinterpret_cast<const bf16x8*>(bx + (xoff[t] ^ (ks << 6)));
-        wf[t] = *reinterpret_cast<const bf16x8*>(bw + (woff[t] ^ (ks << 6)));
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      wf0[t] = *reinterpret_cast<const bf16x8*>(bw + woff[t]);
+      xf0[t] = *reinterpret_cast<const bf16x8*>(bx + xoff[t]);
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wf1[t] = *reinterpret_cast<const bf16x8*>(bw + (woff[t] ^ 64));
+      xf1[t] = *reinterpret_cast<const bf16x8*>(bx + (xoff[t] ^ 64));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+    // schedule: 8 reads, then one read per two MFMAs while the first half computes, then the rest of the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   }
 
   // ---- epilogue: lane owns row m, 16 consecutive columns nb..nb+15 (e = 4*nt + reg) ----

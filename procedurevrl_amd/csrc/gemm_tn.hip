@@ -27,8 +27,8 @@ struct GemmTN {
   float* cpart;  // [splits][N] or null
 };
 
-constexpr int TM = 32;
-constexpr int OP_BYTES = TM * 128 * 2;  // 8 KiB per operand tile
+constexpr int TM = 64;                  // reduction rows per pipeline stage (two K=32 MFMA steps)
+constexpr int OP_BYTES = TM * 128 * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0, int off1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
@@ -52,20 +52,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   const int mend = min(p.M, mbeg + p.Ms);
   const int nsteps = (mend - mbeg + TM - 1) / TM;
 
-  // staging map: 2 chunks of 16 B per operand per thread
-  int srow[2], sc8[2], soff[2];
+  // staging map: 4 chunks of 16 B per operand per thread
+  constexpr int NCH = TM * 16 / 256;
+  int srow[NCH], sc8[NCH], soff[NCH];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NCH; ++j) {
     const int idx = tid + 256 * j;
     srow[j] = idx >> 4;
     sc8[j] = idx & 15;
     const int rb = srow[j] >> 2, cb = sc8[j] >> 1;
     soff[j] = (rb * 8 + (cb ^ ((rb >> 1) & 1))) * 128 + (srow[j] & 3) * 32 + (sc8[j] & 1) * 16;
   }
-  u32x4 rp[2], rq[2];
+  u32x4 rp[NCH], rq[NCH];
   auto gload = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int m = mbeg + st * TM + srow[j];
       if (m < mend) {
         rp[j] = *reinterpret_cast<const u32x4*>(p.P + (long)m * p.ldp + n0 + sc8[j] * 8);
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
     char* bp = smem + buf * 2 * OP_BYTES;
     char* bq = bp + OP_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       *reinterpret_cast<u32x4*>(bp + soff[j]) = rp[j];
       *reinterpret_cast<u32x4*>(bq + soff[j]) = rq[j];
     }
@@ -115,22 +116,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
     if (st + 1 < nsteps) gload(st + 1);
     const char* bp = smem + (st & 1) * 2 * OP_BYTES;
     const char* bq = bp + OP_BYTES;
-    bf16x8 pf[4], qf[4];
+    bf16x8 pf0[4], qf0[4], pf1[4], qf1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      pf[t] = tr_frag(bp, poff[t][0], poff[t][1]);
-      qf[t] = tr_frag(bq, qoff[t][0], qoff[t][1]);
+      qf0[t] = tr_frag(bq, qoff[t][0], qoff[t][1]);
+      pf0[t] = tr_frag(bp, poff[t][0], poff[t][1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {   // second K=32 step: row blocks +8 (1024 B per row block)
+      qf1[t] = tr_frag(bq + 8 * 1024, qoff[t][0], qoff[t][1]);
+      pf1[t] = tr_frag(bp + 8 * 1024, poff[t][0], poff[t][1]);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
-        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kt], pf[nt], acc[nt][kt], 0, 0, 0);
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0[kt], pf0[nt], acc[nt][kt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1[kt], pf1[nt], acc[nt][kt], 0, 0, 0);
+    // 16 transposing reads, then one read per MFMA while the first K=32 step computes, then the second step
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     if (do_csum) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csum[t] += (float)pf[t][e];
+        for (int e = 0; e < 8; ++e) csum[t] += (float)pf0[t][e] + (float)pf1[t][e];
     }
     if (st + 1 < nsteps) lwrite((st + 1) & 1);
     __syncthreads();

@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/pvrl.h declares (no compute calls)."""
+import ctypes
+import os
+
+from procedurevrl_amd import _lib
+
+
+def test_header_parses_and_lists_entry_points():
+    protos = _lib.parse_header()
+    assert len(protos) >= 24
+    for must in ("pvrl_gemm_nt_bf16", "pvrl_gemm_tn_bf16", "pvrl_layernorm_fwd", "pvrl_layernorm_bwd", "pvrl_attn_fwd",
+                 "pvrl_attn_bwd", "pvrl_attn_t8_fwd", "pvrl_attn_t8_bwd", "pvrl_patchify", "pvrl_kl_topk", "pvrl_mse",
+                 "pvrl_adam_step", "pvrl_sgd_step"):
+        assert must in protos
+    for name, (ret, args) in protos.items():
+        assert ret in ("int", "int64_t")
+        for ty, _ in args:
+            assert ty in _lib._CTYPES, (name, ty)   # plain pointers and sizes only: no torch types at the boundary
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from procedurevrl_amd.csrc import build_ext
+        build_ext.build(verbose=False)
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _lib.parse_header():
+        assert hasattr(cdll, name), f"{name} declared in include/pvrl.h but not exported"
+    L = _lib.lib()
+    assert L.PVRL_EPI_RESID_F32 == 3 and L.PVRL_EPI_DQGELU == 6
+
+
+def test_pure_size_queries_run_without_a_gpu():
+    L = _lib.lib()
+    assert L.call("pvrl_gemm_tn_workspace_bytes", 768, 768, 4) == 4 * (768 * 768 + 768) * 4
+    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 25 * 2 * 768 * 4
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import pytest
+    import torch
+    from procedurevrl_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.PvrlError):
+        ops.layernorm_fwd(torch.zeros(4, 768), torch.ones(768), torch.zeros(768), 1e-6)

@@ -1,0 +1,125 @@
+"""Host-side logic that needs no GPU: config surface, registry, state_dict keys, LR schedule, drop-path expansion,
+optimizer grouping, gradient-store layout."""
+import glob
+import os
+
+import pytest
+import torch
+
+from procedurevrl_amd.config import CfgNode, get_cfg
+
+REF_CFG = "/root/reference/configs"
+
+
+def test_cfg_defaults_and_overrides():
+    cfg = get_cfg()
+    assert cfg.DEV.TEMP == 0.02 and cfg.TIMESFORMER.DEPTH == 12 and cfg.TRAIN.TOPK == 5
+    cfg.merge_from_list(["SOLVER.BASE_LR", "1e-4", "NUM_GPUS", "0", "MVIT.PATCH_KERNEL", "(3, 7, 7)"])
+    assert cfg.SOLVER.BASE_LR == 1e-4 and cfg.NUM_GPUS == 0 and cfg.MVIT.PATCH_KERNEL == [3, 7, 7]
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["NO.SUCH_KEY", "1"])
+    with pytest.raises(ValueError):
+        cfg.merge_from_list(["NUM_GPUS", "'eight'"])
+    again = CfgNode.load_cfg(cfg.dump())
+    assert again.SOLVER.BASE_LR == 1e-4 and again.DEV.ORDER_PRETRAIN_MAX_LEN == 9
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.NUM_GPUS = 3
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference configs not present")
+def test_reference_yaml_files_load_unchanged():
+    files = sorted(glob.glob(os.path.join(REF_CFG, "*", "*.yaml")))
+    assert len(files) == 8
+    for f in files:
+        cfg = get_cfg()
+        cfg.merge_from_file(f)
+        assert cfg.TIMESFORMER.ATTENTION_TYPE == "divided_space_time"
+        assert isinstance(cfg.SOLVER.BASE_LR, float) and isinstance(cfg.SOLVER.WEIGHT_DECAY, float)
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF_CFG, "HowTo100M", "procedurevrl_mvitv2_adamw.yaml"))
+    assert cfg.MVIT.PATCH_KERNEL == [3, 7, 7] and cfg.MVIT.PATCH_STRIDE == [2, 4, 4]   # "(3, 7, 7)" strings literal_eval'ed
+
+
+def _small_model(text=True):
+    from procedurevrl_amd.build import MODEL_REGISTRY
+    from procedurevrl_amd import vit  # noqa: F401
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "vit_base_patch16_224_develop"
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NUM_CLASSES = 64
+    cfg.MODEL.TEXT_MODEL = "clip_vit_b_16" if text else ""
+    cfg.TIMESFORMER.DEPTH = 2
+    cfg.DATA.TRAIN_CROP_SIZE = 32
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.DEV.ORDER_PRETRAIN_ENABLED = True
+    cfg.SYNTHETIC.TEXT_LAYERS = 2
+    cfg.NUM_GPUS = 0
+    cfg.TRAIN.LABEL_EMB = torch.randn(64, 512)
+    return cfg, MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+
+
+def test_state_dict_keys_equal_the_reference_model():
+    f = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e.pt"), weights_only=False)
+    _, model = _small_model()
+    assert sorted(model.state_dict().keys()) == f["state_keys"]
+    # constructor facts of the reference: temporal_fc of every block and time_embed start at zero
+    for blk in model.model.blocks:
+        assert float(blk.temporal_fc.weight.abs().sum()) == 0.0
+    assert float(model.model.time_embed.abs().sum()) == 0.0
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    _, model = _small_model(text=False)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 9, 3, 8, 32, 32))
+
+
+def test_grad_store_layout_and_optimizer_groups():
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+    cfg, model = _small_model()
+    vt = model.model
+    gs = vt.grad_store()
+    assert gs.flat.numel() >= sum(p.numel() for p in vt.parameters() if p.requires_grad)
+    assert all(o % 64 == 0 for o in gs.offsets)
+    assert not any(n.startswith("text_model") for n in gs.names)           # frozen teacher is not in the flat buffer
+    tgt, beta = gs.target(vt.norm.weight)
+    assert beta == 0.0 and vt.norm.weight.grad.data_ptr() == tgt.data_ptr()
+    assert gs.target(vt.norm.weight)[1] == 1.0                               # second touch accumulates
+    cfg.SOLVER.OPTIMIZING_METHOD = "adamw"
+    opt = construct_optimizer(model, cfg)
+    assert len(opt.param_groups) == 2 and len(opt.param_groups[0]["params"]) == 0       # [bn (empty), non-bn + text]
+    n_all = len(list(model.parameters()))
+    assert len(opt.param_groups[1]["params"]) == n_all
+    set_lr(opt, 0.25)
+    assert all(g["lr"] == 0.25 * g["lr_mult"] for g in opt.param_groups)
+
+
+def test_droppath_expansion_matches_reference_granularity():
+    from procedurevrl_amd.engine import EncoderEngine
+    B, N, T = 2, 3, 4
+    s1 = torch.arange(B * N, dtype=torch.float32)
+    s2 = torch.arange(B * T, dtype=torch.float32) + 100
+    s3 = torch.arange(B, dtype=torch.float32) + 1000
+    d = EncoderEngine.expand_droppath(s1, s2, s3, B, N, T)
+    for b in range(B):
+        for n in range(N):
+            for t in range(T):
+                r = (b * N + n) * T + t
+                assert d["s1_tok"][r] == s1[b * N + n]          # temporal branch: per (b h w) row  (vit.py:132)
+                assert d["s2_tok"][r] == s2[b * T + t]          # spatial branch: per (b t) row     (vit.py:144)
+                assert d["s3_all"][r] == s3[b]                  # mlp: per b                        (vit.py:157)
+        assert d["s3_all"][B * N * T + b] == s3[b]
+
+
+def test_order_transformer_draws_follow_reference_ranges():
+    _, model = _small_model()
+    ot = model.model.order_tfm
+    torch.manual_seed(0)
+    for _ in range(50):
+        d = ot.draw(16, "cpu")
+        m, p = d["mask_inds"], d["pad_start"]
+        assert int(m.min()) >= 0 and int(m.max()) <= 8
+        last = m + 1 == 9
+        assert torch.all(p[last] == 9)                           # mask at the last position: nothing padded
+        assert torch.all((p[~last] > m[~last]) & (p[~last] <= 8))  # randint(mask + 1, max_len)
