@@ -42,6 +42,9 @@ int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, in
                       int epilogue, const float* bias, const float* rowscale, const void* aux, int64_t aux_ld,
                       int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, void* stream);
 
+/* Benchmark knob: force the GEMM tile (0 heuristic, 1 128x128, 2 256x128, 3 256x256). Not used by the model. */
+int pvrl_debug_set_gemm_tile(int tile);
+
 /* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits
  * `x @ label_emb.t() / temp` vit.py:307,334,340,432). */
 int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float alpha,
@@ -49,7 +52,8 @@ int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t 
 
 /* Weight gradient dW[N,K] = beta*dW + P[M,N]^T . Q[M,K]; dbias[N] = beta*dbias + colsum(P) (optional).
  * Backward of nn.Linear / the patch-embed conv (loss.backward(), tools/train_net.py:176-181).
- * N % 128 == 0, K % 128 == 0.  workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
+ * N % 128 == 0, K % 128 == 0, splits a positive multiple of 8 (one slice of M per XCD).
+ * workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
 int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
 int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,

@@ -6,14 +6,16 @@
 // and nn.MultiheadAttention inside ResidualAttentionBlock (lib/models/tfm_model.py:32-53; key padding
 // mask) / the CLIP text tower (causal mask).  Backward = autograd of the same expression.
 //
-// One workgroup (4 waves) per (sequence, head).  The whole K and V head slices of a sequence
-// fit in LDS (197 x 64 bf16 = 25 KiB each), so softmax is exact single-pass (no online rescale)
-// and the S x S score matrix never exists in memory (the reference materialises 477 MB of it).
+// One workgroup per (sequence, head).  The whole K and V head slices of a sequence fit in LDS
+// (197 x 64 bf16 = 25 KiB each), so softmax is exact single-pass (no online rescale) and the S x S
+// score matrix never exists in memory (the reference materialises 477 MB of it).
 // MFMA operands are arranged "swapped" (a = keys, b = queries) so that a lane owns ONE query and
 // 4 keys per 16-key tile: the softmax row reduction is register-local plus two cross-lane
 // steps, and P feeds the second MFMA straight from registers as its b-operand.  V (and, in the
 // backward, K / Q / dO) is read through ds_read_b64_tr_b16 from a [4][16]-blocked LDS image, so
 // no transposed copies are ever built.
+// The number of 16-key tiles NKT is a template parameter (1, 2, 3, 5, 13): every loop over keys is
+// straight-line code the compiler can software-pipeline (a run-time tile count cost 5x in branches).
 #include "attn_common.h"
 #include "../../include/pvrl.h"
 
@@ -35,13 +37,6 @@ struct AttnArgs {
   bf16* dqkv; bf16* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
 };
 
-__device__ __forceinline__ bool key_masked(const AttnArgs& p, int seq, int query, int key) {
-  if (key >= p.mp.S) return true;
-  if (p.causal && key > query) return true;
-  if (p.kpm && p.kpm[(long)seq * p.mp.S + key]) return true;
-  return false;
-}
-
 // row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
 template <typename T>
 __device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, const SeqRows& sr, int seq, int j) {
@@ -49,70 +44,113 @@ __device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp,
   return tok + row_of(sr, j) * ld;
 }
 
+// key-padding bits of the 4*NKT keys a lane owns in the "lane = query" layout (key = 16 kt + 4 q4 + r)
+template <int NKT, bool GEN>
+__device__ __forceinline__ unsigned long long pad_bits_q(const AttnArgs& p, int seq, int q4) {
+  unsigned long long bits = 0ull;
+  if constexpr (GEN) {
+    if (p.kpm) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * q4 + r;
+          if (key < p.mp.S && p.kpm[(long)seq * p.mp.S + key]) bits |= 1ull << (kt * 4 + r);
+        }
+    }
+  }
+  return bits;
+}
+
+template <int NT>
+__device__ __forceinline__ void load_tile(const bf16* base, long ld, int col0, const SeqRows& sr, int S, const bf16* src0,
+                                          char* rm, int rm_rows, char* bl, int bl_rows, int tid) {
+  constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
+  const int maxrows = rm_rows > bl_rows ? rm_rows : bl_rows;
+  u32x4 v[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + NT * it;
+    const int row = idx >> 3, c = idx & 7;
+    v[it] = (u32x4){0u, 0u, 0u, 0u};
+    if (row < S && row < maxrows) {
+      const bf16* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
+      v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + NT * it;
+    const int row = idx >> 3, c = idx & 7;
+    if (rm && row < rm_rows) *reinterpret_cast<u32x4*>(rm + rm_off(row, c)) = v[it];
+    if (bl && row < bl_rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = v[it];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[ATT_RM_BYTES + ATT_BL_BYTES];
+template <int NKT, bool GEN, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int NKS2 = (NKT + 1) / 2;
+  constexpr int RM = NKT * 16 * 128, BL = NKS2 * 32 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[RM + BL];
   char* Kr = smem;
-  char* Vb = smem + ATT_RM_BYTES;
+  char* Vb = smem + RM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
   const int S = p.mp.S;
-  const int nkt = (S + 15) >> 4;
-  const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
-
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_head_tile(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, nkt * 16, nullptr, 0, tid);
-  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, nks2 * 32, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, NKT * 16, nullptr, 0, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, NKS2 * 32, tid);
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
-  for (int qt = wave; qt < nkt; qt += 4) {
+  const unsigned long long pbits = pad_bits_q<NKT, GEN>(p, seq, q4);
+  const int nqt = (S + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int query = qt * 16 + i;
     const int qrow = query < S ? query : S - 1;
     const bf16* qp = p.qkv + row_of(sr, qrow) * p.ld + h * 64 + q4 * 8;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
 
-    f32x4 sc[ATT_MAX_TILES];
+    f32x4 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int krow = kt * 16 + i;
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nkt) {
-        const int krow = kt * 16 + i;
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * q4 + r;
-          const float v = key_masked(p, seq, query, key) ? -INFINITY : a[r] * p.scale;
-          a[r] = v;
-          mx = fmaxf(mx, v);
-        }
-        sc[kt] = a;
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * q4 + r;
+        bool msk = key >= S;
+        if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
+        const float v = msk ? -INFINITY : sc[kt][r] * p.scale;
+        sc[kt][r] = v;
+        mx = fmaxf(mx, v);
       }
-    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mref = (mx == -INFINITY) ? 0.f : mx;
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nkt) {
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(sc[kt][r] - mref);
-          sc[kt][r] = e;
-          sum += e;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sc[kt][r] - mref);
+        sc[kt][r] = e;
+        sum += e;
       }
-    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
@@ -121,20 +159,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks2 = 0; ks2 < (ATT_MAX_TILES + 1) / 2; ++ks2) {
-      if (ks2 < nks2) {
-        bf16x8 pf;
+    for (int ks2 = 0; ks2 < NKS2; ++ks2) {
+      bf16x8 pf;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pf[r] = (bf16)(sc[2 * ks2][r] * inv);
-          pf[4 + r] = (2 * ks2 + 1 < ATT_MAX_TILES && 2 * ks2 + 1 < nkt) ? (bf16)(sc[(2 * ks2 + 1) % ATT_MAX_TILES][r] * inv)
-                                                                        : (bf16)0.f;
-        }
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (bf16)(sc[2 * ks2][r] * inv);
+        if (2 * ks2 + 1 < NKT) pf[4 + r] = (bf16)(sc[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r] * inv);
+        else pf[4 + r] = (bf16)0.f;
+      }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 vf = bl_frag(Vb, ks2, dt, lane);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = bl_frag(Vb, ks2, dt, lane);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
       }
     }
     if (query < S) {
@@ -152,29 +188,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, pass 1: dQ (and D = rowsum(dO * O)), one workgroup per (sequence, head),
-// waves own query tiles exactly as in the forward.
+// backward, pass 1: dQ (and D = rowsum(dO * O)); waves own query tiles exactly as in the forward.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_RM_BYTES + ATT_BL_BYTES];
+template <int NKT, bool GEN, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
+  constexpr int NKS2 = (NKT + 1) / 2;
+  constexpr int RM = NKT * 16 * 128, BL = NKS2 * 32 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * RM + BL];
   char* Kr = smem;
-  char* Vr = smem + ATT_RM_BYTES;
-  char* Kb = smem + 2 * ATT_RM_BYTES;
+  char* Vr = smem + RM;
+  char* Kb = smem + 2 * RM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
   const int S = p.mp.S;
-  const int nkt = (S + 15) >> 4;
-  const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
-
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_head_tile(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, nkt * 16, Kb, nks2 * 32, tid);
-  load_head_tile(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, Vr, nkt * 16, nullptr, 0, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, NKT * 16, Kb, NKS2 * 32, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, Vr, NKT * 16, nullptr, 0, tid);
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
-  for (int qt = wave; qt < nkt; qt += 4) {
+  const unsigned long long pbits = pad_bits_q<NKT, GEN>(p, seq, q4);
+  const int nqt = (S + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int query = qt * 16 + i;
     const int qj = query < S ? query : S - 1;
     const bf16* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
@@ -195,49 +232,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
     const float lse = p.lse[stat];
     if (q4 == 0 && query < S) p.dvec[stat] = dsum;
 
-    f32x4 ds[ATT_MAX_TILES];
+    f32x4 ds[NKT];
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nkt) {
-        const int krow = kt * 16 + i;
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
-        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, q4));
-        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, 4 + q4));
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
-        f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int krow = kt * 16 + i;
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, q4));
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, 4 + q4));
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
+      f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * q4 + r;
-          const bool msk = key_masked(p, seq, query, key) || query >= S;
-          const float pr = msk ? 0.f : __expf(s[r] * p.scale - lse);
-          s[r] = pr * (dp[r] - dsum) * p.scale;
-        }
-        ds[kt] = s;
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * q4 + r;
+        bool msk = key >= S || query >= S;
+        if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
+        const float pr = msk ? 0.f : __expf(s[r] * p.scale - lse);
+        s[r] = pr * (dp[r] - dsum) * p.scale;
       }
+      ds[kt] = s;
     }
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks2 = 0; ks2 < (ATT_MAX_TILES + 1) / 2; ++ks2) {
-      if (ks2 < nks2) {
-        bf16x8 sf;
+    for (int ks2 = 0; ks2 < NKS2; ++ks2) {
+      bf16x8 sf;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sf[r] = (bf16)ds[2 * ks2][r];
-          sf[4 + r] = (2 * ks2 + 1 < ATT_MAX_TILES && 2 * ks2 + 1 < nkt) ? (bf16)ds[(2 * ks2 + 1) % ATT_MAX_TILES][r]
-                                                                        : (bf16)0.f;
-        }
+      for (int r = 0; r < 4; ++r) {
+        sf[r] = (bf16)ds[2 * ks2][r];
+        if (2 * ks2 + 1 < NKT) sf[4 + r] = (bf16)ds[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r];
+        else sf[4 + r] = (bf16)0.f;
+      }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 kf = bl_frag(Kb, ks2, dt, lane);
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, dq[dt], 0, 0, 0);
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 kf = bl_frag(Kb, ks2, dt, lane);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, dq[dt], 0, 0, 0);
       }
     }
     if (query < S) {
@@ -257,28 +291,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
 // backward, pass 2: dK and dV.  Waves own KEY tiles; the query dimension is the MFMA reduction.
 // Needs lse and dvec from the forward / pass 1.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_RM_BYTES + 2 * ATT_BL_BYTES + 2 * ATT_ROWS_PAD * 4];
+template <int NKT, bool GEN, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
+  constexpr int NKS2 = (NKT + 1) / 2;
+  constexpr int ROWS = NKS2 * 32;
+  constexpr int T = ROWS * 128;
+  __shared__ __attribute__((aligned(16))) char smem[4 * T + 2 * ROWS * 4];
   char* Qr = smem;
-  char* Dr = smem + ATT_RM_BYTES;
-  char* Qb = smem + 2 * ATT_RM_BYTES;
-  char* Db = Qb + ATT_BL_BYTES;
-  float* lse_s = reinterpret_cast<float*>(Db + ATT_BL_BYTES);
-  float* dv_s = lse_s + ATT_ROWS_PAD;
+  char* Dr = smem + T;
+  char* Qb = smem + 2 * T;
+  char* Db = smem + 3 * T;
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * T);
+  float* dv_s = lse_s + ROWS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
   const int S = p.mp.S;
-  const int nkt = (S + 15) >> 4;
-  const int nks2 = (nkt + 1) >> 1;
   const int HD = p.H * 64;
-
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_head_tile(p.qkv, p.ld, h * 64, sr, S, nullptr, Qr, nks2 * 32, Qb, nks2 * 32, tid);
-  {  // dO tile: token 0 may live in the side buffer (mode 1)
-    const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;
-    load_head_tile(p.d_o, p.ldo, h * 64, sr, S, src0, Dr, nks2 * 32, Db, nks2 * 32, tid);
-    for (int idx = tid; idx < ATT_ROWS_PAD; idx += 256) {
+  load_tile<64 * NW>(p.qkv, p.ld, h * 64, sr, S, nullptr, Qr, ROWS, Qb, ROWS, tid);
+  {
+    const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
+    load_tile<64 * NW>(p.d_o, p.ldo, h * 64, sr, S, src0, Dr, ROWS, Db, ROWS, tid);
+    for (int idx = tid; idx < ROWS; idx += 64 * NW) {
       const long stat = ((long)seq * p.H + h) * S + idx;
       lse_s[idx] = idx < S ? p.lse[stat] : 0.f;
       dv_s[idx] = idx < S ? p.dvec[stat] : 0.f;
@@ -287,7 +322,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
-  for (int kt = wave; kt < nkt; kt += 4) {
+  const int nkt_rt = (S + 15) >> 4;
+  for (int kt = wave; kt < nkt_rt; kt += NW) {
     const int key = kt * 16 + i;
     const int kj = key < S ? key : S - 1;
     const bf16* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
@@ -295,13 +331,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
     const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
     const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(kp + HD);
     const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(kp + HD + 32);
-    const bool kpad = p.kpm ? (p.kpm[(long)seq * S + kj] != 0) : false;
+    bool kbad = key >= S;
+    if constexpr (GEN) kbad = kbad || (p.kpm ? (p.kpm[(long)seq * S + kj] != 0) : false);
 
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    for (int u = 0; u < nks2; ++u) {
+#pragma unroll 1
+    for (int u = 0; u < NKS2; ++u) {
       bf16x8 pf, sf;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -323,7 +361,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int query = qb + r;
-          const bool msk = query >= S || key >= S || kpad || (p.causal && key > query);
+          bool msk = query >= S || kbad;
+          if constexpr (GEN) msk = msk || (p.causal && key > query);
           const float pr = msk ? 0.f : __expf(s[r] * p.scale - l4[r]);
           pf[half * 4 + r] = (bf16)pr;
           sf[half * 4 + r] = (bf16)(pr * (dp[r] - d4[r]) * p.scale);
@@ -358,6 +397,31 @@ int check_common(const AttnArgs& p) {
   return PVRL_OK;
 }
 
+template <int NKT, int NW>
+int launch_fwd(const AttnArgs& p, hipStream_t s) {
+  const dim3 grid((unsigned)(p.nseq * p.H)), blk(64 * NW);
+  if (p.causal || p.kpm) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true, NW>), grid, blk, 0, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, NW>), grid, blk, 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+template <int NKT, int NW>
+int launch_bwd(const AttnArgs& p, hipStream_t s) {
+  const dim3 grid((unsigned)(p.nseq * p.H)), blk(64 * NW);
+  if (p.causal || p.kpm) {
+    hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, true, NW>), grid, blk, 0, s, p);
+    PVRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<NKT, true, NW>), grid, blk, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, false, NW>), grid, blk, 0, s, p);
+    PVRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<NKT, false, NW>), grid, blk, 0, s, p);
+  }
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
 }  // namespace
 
 extern "C" int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
@@ -371,9 +435,12 @@ extern "C" int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (nseq == 0) return PVRL_OK;
   if (int e = check_common(p)) return e;
   if (!o || (ldo % 4) || (mode == 1 && !o_cls)) return PVRL_EINVAL;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, (hipStream_t)stream, p);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 16) return launch_fwd<1, 4>(p, s);
+  if (S <= 32) return launch_fwd<2, 4>(p, s);
+  if (S <= 48) return launch_fwd<3, 4>(p, s);
+  if (S <= 80) return launch_fwd<5, 4>(p, s);
+  return launch_fwd<13, 8>(p, s);
 }
 
 extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
@@ -392,9 +459,9 @@ extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (!o || !d_o || !lse || !dvec || !dqkv || (ldo % 8) || (ldd % 4)) return PVRL_EINVAL;
   if (mode == 1 && (!o_cls || !d_o_cls || !dqkv_cls)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, s, p);
-  PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)(nseq * H)), dim3(256), 0, s, p);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
+  if (S <= 16) return launch_bwd<1, 4>(p, s);
+  if (S <= 32) return launch_bwd<2, 4>(p, s);
+  if (S <= 48) return launch_bwd<3, 4>(p, s);
+  if (S <= 80) return launch_bwd<5, 4>(p, s);
+  return launch_bwd<13, 8>(p, s);
 }

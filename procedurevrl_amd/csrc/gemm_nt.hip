@@ -32,47 +32,82 @@ struct GemmNT {
   long aux_ld; int aux_rowmod;
   void* out0; long ld0;
   void* out1; long ld1;
-  int tiles_n, nwg;
+  int tiles_m, tiles_n, nwg;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
 
 __device__ __forceinline__ int swz_x(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+// W rows are read in a permuted order so that the lanes of one epilogue store instruction write contiguous bytes:
+//   fp32 outputs: natural order, lane (i = 4q + r) of tile nt holds column 16 nt + i -> the 4 lanes q of a row write
+//                 16 consecutive floats (64 B) per instruction;
+//   bf16 outputs: tile nt = 2c + h holds column 32c + 8q + 4h + r -> a lane packs 8 consecutive bf16 (tiles 2c, 2c+1)
+//                 and the 4 lanes q of a row write 32 consecutive bf16 (64 B) per instruction.
+// Each order has its own chunk swizzle making ds_read_b128 conflict-free (rows that a lane group reads together
+// must land on distinct 16-byte slots of the 256-byte bank row).
+template <bool F32OUT> __device__ __forceinline__ int w_row(int nt, int i) {
+  return F32OUT ? 16 * nt + i : 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3);
+}
+template <bool F32OUT> __device__ __forceinline__ int swz_w(int row) {
+  return F32OUT ? (row >> 1) & 7 : ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+}
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+// WM x WN waves per workgroup, each owning a 64x64 output block: tile = (64*WM) x (64*WN).
+//   <2,2>: 128x128, 4 waves, 64 KiB LDS, 2 workgroups / CU   (small M: order transformer, CLIP text)
+//   <4,4>: 256x256, 16 waves, 128 KiB LDS, 1 workgroup / CU  (the encoder's 50k-row GEMMs: half the L2->LDS
+//          bytes per FLOP of the 128x128 tile, which is what bounds the small tile at ~0.7-0.9 PFLOP/s)
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int NINST = (BM + BN) / 8;          // 1 KiB LDS-DMA instructions per stage
+  constexpr int PER = NINST / NW;               // per wave
+  static_assert(NINST % NW == 0, "stage instructions must divide evenly over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int wg = xcd_remap(blockIdx.x, p.nwg);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int wm = wave / WN, wn = wave % WN;
+  // L2-aware rasterisation.  Hardware places block b on XCD b % 8 (private 4 MiB L2 each).  Every XCD owns a
+  // contiguous range of M-panels and walks it in groups of GM panels x all N-tiles, panel index fastest, so the
+  // ~64 tiles resident on an XCD share GM activation panels and a few weight tiles instead of sweeping the whole
+  // weight matrix per panel.
+  constexpr int GM = 8;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);                 // panels owned by this XCD
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging addresses (per lane: 4 X chunks + 4 W chunks per K-step) ----
-  const bf16* gx[4];
-  const bf16* gw[4];
+  // ---- staging: instruction `it` of a stage copies 8 tile rows (X rows first, then W rows) ----
+  const bf16* gsrc[PER];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int it = wave * 4 + j;
-    const int row = it * 8 + (lane >> 3);
+  for (int j = 0; j < PER; ++j) {
+    const int it = wave * PER + j;
     const int pc = lane & 7;
-    int grow = m0 + row;
-    grow = grow < p.M ? grow : p.M - 1;
-    gx[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
-    gw[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w(row)) << 3);
+    if (it < BM / 8) {
+      const int row = it * 8 + (lane >> 3);
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+    } else {
+      const int row = (it - BM / 8) * 8 + (lane >> 3);
+      gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
+    }
   }
   auto stage = [&](int buf, int k0) {
-    char* bx = smem + buf * 2 * TILE_BYTES;
-    char* bw = bx + TILE_BYTES;
+    char* b = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int it = wave * 4 + j;
-      glds16(gx[j] + k0, bx + it * 1024);
-      glds16(gw[j] + k0, bw + it * 1024);
-    }
+    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);   // W tile follows the X tile
   };
 
   // ---- fragment read offsets (bytes inside an operand tile), ks = 0; ks = 1 is ^64 ----
@@ -83,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     for (int t = 0; t < 4; ++t) {
       const int rx = wm * 64 + t * 16 + i;
       xoff[t] = rx * 128 + ((q ^ swz_x(rx)) << 4);
-      const int rw = wn * 64 + 16 * (i >> 2) + 4 * t + (i & 3);
-      woff[t] = rw * 128 + ((q ^ swz_w(rw)) << 4);
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = rw * 128 + ((q ^ swz_w<F32OUT>(rw)) << 4);
     }
   }
 
@@ -99,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
     if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    const char* bx = smem + (kt & 1) * 2 * TILE_BYTES;
-    const char* bw = bx + TILE_BYTES;
+    const char* bx = smem + (kt & 1) * STAGE;
+    const char* bw = bx + XBYTES;
     // all 16 fragment reads of the K-step are issued up front; the MFMAs of the first half overlap the
     // LDS latency of the second half (the compiler otherwise serialises read -> wait(0) -> 8 MFMAs)
     bf16x8 xf0[4], wf0[4], xf1[4], wf1[4];
@@ -134,80 +169,81 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   }
 
-  // ---- epilogue: lane owns row m, 16 consecutive columns nb..nb+15 (e = 4*nt + reg) ----
+  // ---- epilogue ----
   const int q = lane >> 4, i = lane & 15;
-  const int nb = n0 + wn * 64 + 16 * q;
-  float bv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[nb + e] : 0.f;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + i;
-    if (m >= p.M) continue;
-    const float rs = p.rowscale ? p.rowscale[m] : 1.f;
-    float v[16];
+  const int nw0 = n0 + wn * 64;
+  if constexpr (F32OUT) {
+    // lane holds, for tile nt, columns nw0 + 16 nt + 4q + (0..3)
+    f32x4 bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
+      bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 16 * nt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
-
-    if constexpr (EPI == PVRL_EPI_BF16) {
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { o0[e] = (bf16)(rs * v[e]); o1[e] = (bf16)(rs * v[8 + e]); }
-      bf16* o = (bf16*)p.out0 + (long)m * p.ld0 + nb;
-      *reinterpret_cast<bf16x8*>(o) = o0;
-      *reinterpret_cast<bf16x8*>(o + 8) = o1;
-    } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
-      bf16x8 u0, u1, g0, g1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float a = v[e], b = v[8 + e];
-        u0[e] = (bf16)a; u1[e] = (bf16)b;
-        g0[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(a) : quick_gelu(a));
-        g1[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(b) : quick_gelu(b));
-      }
-      bf16* ou = (bf16*)p.out0 + (long)m * p.ld0 + nb;
-      bf16* og = (bf16*)p.out1 + (long)m * p.ld1 + nb;
-      *reinterpret_cast<bf16x8*>(ou) = u0; *reinterpret_cast<bf16x8*>(ou + 8) = u1;
-      *reinterpret_cast<bf16x8*>(og) = g0; *reinterpret_cast<bf16x8*>(og + 8) = g1;
-    } else if constexpr (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32) {
-      float* o = (float*)p.out0 + (long)m * p.ld0 + nb;
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + i;
+      if (m >= p.M) continue;
+      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 4 * q;
+      const float* r = nullptr;
       if constexpr (EPI == PVRL_EPI_RESID_F32) {
         const int mr = p.aux_rowmod ? (m % p.aux_rowmod) : m;
-        const float* r = (const float*)p.aux + (long)mr * p.aux_ld + nb;
+        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 4 * q;
+      }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          f32x4 rv = *reinterpret_cast<const f32x4*>(r + 4 * c);
-          f32x4 ov;
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 ov;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = rv[e] + rs * v[4 * c + e];
-          *reinterpret_cast<f32x4*>(o + 4 * c) = ov;
+        for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
+        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 16 * nt);
+        *reinterpret_cast<f32x4*>(o + 16 * nt) = ov;
+      }
+    }
+  } else {
+    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
+    float bv[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[c][e] = p.bias ? p.bias[nw0 + 32 * c + 8 * q + e] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + i;
+      if (m >= p.M) continue;
+      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mt][2 * c][e] + bv[c][e];
+          v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
         }
-      } else {
+        const long col = nw0 + 32 * c + 8 * q;
+        if constexpr (EPI == PVRL_EPI_BF16) {
+          bf16x8 o0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          f32x4 ov;
+          for (int e = 0; e < 8; ++e) o0[e] = (bf16)(rs * v[e]);
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
+        } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
+          bf16x8 u0, g0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = rs * v[4 * c + e];
-          *reinterpret_cast<f32x4*>(o + 4 * c) = ov;
+          for (int e = 0; e < 8; ++e) {
+            u0[e] = (bf16)v[e];
+            g0[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
+          }
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = u0;
+          *reinterpret_cast<bf16x8*>((bf16*)p.out1 + (long)m * p.ld1 + col) = g0;
+        } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
+          const bf16x8 ua = *reinterpret_cast<const bf16x8*>((const bf16*)p.aux + (long)m * p.aux_ld + col);
+          bf16x8 o0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
+            o0[e] = (bf16)(rs * v[e] * d);
+          }
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
         }
       }
-    } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
-      const bf16* u = (const bf16*)p.aux + (long)m * p.aux_ld + nb;
-      const bf16x8 ua = *reinterpret_cast<const bf16x8*>(u);
-      const bf16x8 ub = *reinterpret_cast<const bf16x8*>(u + 8);
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float da = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
-        const float db = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ub[e]) : quick_gelu_grad((float)ub[e]);
-        o0[e] = (bf16)(rs * v[e] * da);
-        o1[e] = (bf16)(rs * v[8 + e] * db);
-      }
-      bf16* o = (bf16*)p.out0 + (long)m * p.ld0 + nb;
-      *reinterpret_cast<bf16x8*>(o) = o0;
-      *reinterpret_cast<bf16x8*>(o + 8) = o1;
     }
   }
 }
@@ -261,11 +297,26 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
   }
 }
 
-template <int EPI>
-int launch_nt(const GemmNT& p, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(p.nwg), dim3(256), 0, s, p);
+template <int EPI, int WM, int WN>
+int launch_tile(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / (64 * WN);
+  p.tiles_m = cdiv(p.M, 64 * WM);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;   // per-XCD tile lists padded to equal length (surplus blocks exit)
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
+}
+
+int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x128, 3 = 256x256 (debug / benchmarking knob)
+
+template <int EPI>
+int launch_nt(const GemmNT& p, hipStream_t s) {
+  int t = g_force_tile;
+  if (t == 0) t = (p.M >= 4096 && p.N % 256 == 0) ? 3 : (p.M >= 2048 ? 2 : 1);
+  if (t == 3 && p.N % 256) t = 2;
+  if (t == 3) return launch_tile<EPI, 4, 4>(p, s);
+  if (t == 2) return launch_tile<EPI, 4, 2>(p, s);
+  return launch_tile<EPI, 2, 2>(p, s);
 }
 
 }  // namespace
@@ -275,7 +326,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
                                  const void* aux, int64_t aux_ld, int64_t aux_rowmod, void* out0, int64_t ld0,
                                  void* out1, int64_t ld1, void* stream) {
   if (M <= 0) return PVRL_OK;
-  if (!A || !W || !out0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return PVRL_EINVAL;
+  if (!A || !W || !out0 || N <= 0 || K <= 0 || (N % 128) || (K % BK)) return PVRL_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ld0 % 8)) return PVRL_EINVAL;
   if ((epilogue == PVRL_EPI_GELU || epilogue == PVRL_EPI_QGELU) && (!out1 || (ld1 % 8))) return PVRL_EINVAL;
   if ((epilogue == PVRL_EPI_RESID_F32 || epilogue == PVRL_EPI_DGELU || epilogue == PVRL_EPI_DQGELU) &&
@@ -286,8 +337,6 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
   p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1;
-  p.tiles_n = (int)(N / BN);
-  p.nwg = cdiv(M, BM) * p.tiles_n;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s);
@@ -299,6 +348,11 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     case PVRL_EPI_DQGELU: return launch_nt<PVRL_EPI_DQGELU>(p, s);
     default: return PVRL_EINVAL;
   }
+}
+
+extern "C" int pvrl_debug_set_gemm_tile(int tile) {
+  g_force_tile = tile;
+  return PVRL_OK;
 }
 
 extern "C" int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,

@@ -43,23 +43,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;  // wm: k half, wn: n half
-  const int wg = blockIdx.x;
-  const int s = wg / p.tiles_nk;
-  const int rem = wg - s * p.tiles_nk;
+  // every slice of M lives on ONE XCD (hardware: block b -> XCD b % 8): its rows of P and Q are pulled into that
+  // XCD's L2 once and shared by all (n, k) tiles of the slice instead of being re-fetched by all 8 L2s.
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = (j / p.tiles_nk) * 8 + xcd;
+  const int rem = j % p.tiles_nk;
   const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   const int mbeg = s * p.Ms;
   const int mend = min(p.M, mbeg + p.Ms);
   const int nsteps = (mend - mbeg + TM - 1) / TM;
 
-  // staging map: 4 chunks of 16 B per operand per thread
+  // staging map: 4 chunks of 16 B per operand per thread.  A wave copies 4 tile rows x 256 B per instruction; lanes
+  // are assigned (column block, row in block, half) so that 8 consecutive lanes write one whole 128-byte [4][16]
+  // block: the 8-lane groups of ds_write_b128 then cover 32 distinct banks (row-major lane order was 4-way
+  // conflicted), while every global row is still read as full 256-byte lines.
   constexpr int NCH = TM * 16 / 256;
   int srow[NCH], sc8[NCH], soff[NCH];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    const int idx = tid + 256 * j;
-    srow[j] = idx >> 4;
-    sc8[j] = idx & 15;
+    const int w4 = (tid >> 6) + 4 * j;                       // 4-row group handled by this wave-instruction
+    srow[j] = w4 * 4 + ((lane >> 1) & 3);
+    sc8[j] = (lane >> 3) * 2 + (lane & 1);
     const int rb = srow[j] >> 2, cb = sc8[j] >> 1;
     soff[j] = (rb * 8 + (cb ^ ((rb >> 1) & 1))) * 128 + (srow[j] & 3) * 32 + (sc8[j] & 1) * 16;
   }
@@ -209,7 +214,7 @@ extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t sp
 extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
                                  int64_t K, int64_t splits, float beta, float* dW, float* dbias, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
+  if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 8 || (splits % 8) || M < 0)
     return PVRL_EINVAL;
   if ((ldp % 8) || (ldq % 8)) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_gemm_tn_workspace_bytes(N, K, splits)) return PVRL_EINVAL;

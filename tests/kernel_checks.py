@@ -102,7 +102,7 @@ def check_gemm_tn():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(3)
     out = []
-    for (M, N, K, splits) in [(96, 128, 128, 1), (1000, 768, 768, 4), (5000, 256, 384, None), (333, 128, 256, 3)]:
+    for (M, N, K, splits) in [(96, 128, 128, 8), (1000, 768, 768, 16), (5000, 256, 384, None), (333, 128, 256, 24)]:
         P = torch.randn(M, N, generator=g)
         Q = torch.randn(M, K, generator=g)
         ref = bf(P).t() @ bf(Q)

@@ -50,7 +50,19 @@ def main():
         us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    gemm_case("nt qkv      bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
+    for tile in (1, 2, 3):
+        L.call("pvrl_debug_set_gemm_tile", tile)
+        tg = {1: "128x128", 2: "256x128", 3: "256x256"}[tile]
+        gemm_case(f"nt[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
+        gemm_case(f"nt[{tg}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
+        gemm_case(f"nt[{tg}] fc    resid M x768x768", R, 768, 768, L.PVRL_EPI_RESID_F32)
+        gemm_case(f"nt[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
+        gemm_case(f"nt[{tg}] fc2   resid M x768x3072", M, 768, 3072, L.PVRL_EPI_RESID_F32)
+        gemm_case(f"nt[{tg}] dfc2  dgelu M x3072x768", M, 3072, 768, L.PVRL_EPI_DGELU)
+        gemm_case(f"nt[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
+        gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
+    L.call("pvrl_debug_set_gemm_tile", 0)
+    gemm_case("nt-auto qkv      bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
     gemm_case("nt proj     bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
     gemm_case("nt fc/projs resid M x768x768", R, 768, 768, L.PVRL_EPI_RESID_F32)
     gemm_case("nt fc1      gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
