@@ -27,8 +27,7 @@ struct GemmTN {
   float* cpart;  // [splits][N] or null
 };
 
-constexpr int TM = 64;                  // reduction rows per pipeline stage (two K=32 MFMA steps)
-constexpr int OP_BYTES = TM * 128 * 2;  // 16 KiB per operand tile
+constexpr int TM = 64;   // reduction rows per pipeline stage (two K=32 MFMA steps)
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0, int off1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
@@ -38,58 +37,66 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0, int off1) 
   return u.v;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * OP_BYTES];
+// WN x WK waves per workgroup, each owning a 64(n) x 64(k) block of dW: tile = (64 WN) x (64 WK).
+//   <2,2>: 128x128, 4 waves, 64 KiB LDS, 2 workgroups / CU;   <4,4>: 256x256, 16 waves, 128 KiB LDS, 1 / CU
+//   (half the L2->LDS bytes per FLOP; every operand row block is shared by 4 waves instead of 2).
+template <int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void gemm_tn_kernel(GemmTN p) {
+  constexpr int NW = WN * WK, NT = 64 * NW;
+  constexpr int PB = 4 * WN, QB = 4 * WK;                 // 16-column blocks per row block of the P / Q tile
+  constexpr int PBYTES = TM * 64 * WN * 2, QBYTES = TM * 64 * WK * 2, STAGE = PBYTES + QBYTES;
+  constexpr int PINST = 16 * WN / 2, QINST = 16 * WK / 2;  // wave-instructions (4 rows x 256 B) per stage
+  constexpr int PER = (PINST + QINST) / NW;
+  static_assert((PINST + QINST) % NW == 0, "staging must divide evenly over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // wm: k half, wn: n half
+  const int wk = wave / WN, wn = wave % WN;
   // every slice of M lives on ONE XCD (hardware: block b -> XCD b % 8): its rows of P and Q are pulled into that
   // XCD's L2 once and shared by all (n, k) tiles of the slice instead of being re-fetched by all 8 L2s.
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int s = (j / p.tiles_nk) * 8 + xcd;
   const int rem = j % p.tiles_nk;
   const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
-  const int n0 = tn * 128, k0 = tk * 128;
+  const int n0 = tn * 64 * WN, k0 = tk * 64 * WK;
   const int mbeg = s * p.Ms;
   const int mend = min(p.M, mbeg + p.Ms);
   const int nsteps = (mend - mbeg + TM - 1) / TM;
 
-  // staging map: 4 chunks of 16 B per operand per thread.  A wave copies 4 tile rows x 256 B per instruction; lanes
-  // are assigned (column block, row in block, half) so that 8 consecutive lanes write one whole 128-byte [4][16]
-  // block: the 8-lane groups of ds_write_b128 then cover 32 distinct banks (row-major lane order was 4-way
-  // conflicted), while every global row is still read as full 256-byte lines.
-  constexpr int NCH = TM * 16 / 256;
-  int srow[NCH], sc8[NCH], soff[NCH];
+  // staging: wave-instruction `it` copies 4 tile rows x 256 B of P (it < PINST) or Q.  Lanes are assigned
+  // (column block, row in block, half) so that 8 consecutive lanes write one whole 128-byte [4][16] block: the 8-lane
+  // groups of ds_write_b128 cover 32 distinct banks, and every global row is still read as full 256-byte lines.
+  int srow[PER], scol[PER], soff[PER];
+  bool isq[PER];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    const int w4 = (tid >> 6) + 4 * j;                       // 4-row group handled by this wave-instruction
-    srow[j] = w4 * 4 + ((lane >> 1) & 3);
-    sc8[j] = (lane >> 3) * 2 + (lane & 1);
-    const int rb = srow[j] >> 2, cb = sc8[j] >> 1;
-    soff[j] = (rb * 8 + (cb ^ ((rb >> 1) & 1))) * 128 + (srow[j] & 3) * 32 + (sc8[j] & 1) * 16;
+  for (int e = 0; e < PER; ++e) {
+    int it = wave * PER + e;
+    isq[e] = it >= PINST;
+    if (isq[e]) it -= PINST;
+    const int segs = isq[e] ? WK / 2 : WN / 2;             // 256-byte segments per tile row
+    const int rg = it / segs, seg = it - rg * segs;
+    srow[e] = rg * 4 + ((lane >> 1) & 3);
+    const int c8 = seg * 16 + (lane >> 3) * 2 + (lane & 1);  // 16-byte chunk within the tile row
+    scol[e] = c8 * 8;
+    const int rb = srow[e] >> 2, cb = c8 >> 1;
+    const int nb = isq[e] ? QB : PB;
+    soff[e] = (isq[e] ? PBYTES : 0) + (rb * nb + (cb ^ ((rb >> 1) & 1))) * 128 + (srow[e] & 3) * 32 + (c8 & 1) * 16;
   }
-  u32x4 rp[NCH], rq[NCH];
+  u32x4 rg_[PER];
   auto gload = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int m = mbeg + st * TM + srow[j];
-      if (m < mend) {
-        rp[j] = *reinterpret_cast<const u32x4*>(p.P + (long)m * p.ldp + n0 + sc8[j] * 8);
-        rq[j] = *reinterpret_cast<const u32x4*>(p.Q + (long)m * p.ldq + k0 + sc8[j] * 8);
-      } else {
-        rp[j] = (u32x4){0u, 0u, 0u, 0u};
-        rq[j] = (u32x4){0u, 0u, 0u, 0u};
-      }
+    for (int e = 0; e < PER; ++e) {
+      const int m = mbeg + st * TM + srow[e];
+      rg_[e] = (u32x4){0u, 0u, 0u, 0u};
+      if (m < mend)
+        rg_[e] = isq[e] ? *reinterpret_cast<const u32x4*>(p.Q + (long)m * p.ldq + k0 + scol[e])
+                        : *reinterpret_cast<const u32x4*>(p.P + (long)m * p.ldp + n0 + scol[e]);
     }
   };
   auto lwrite = [&](int buf) {
-    char* bp = smem + buf * 2 * OP_BYTES;
-    char* bq = bp + OP_BYTES;
+    char* b = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      *reinterpret_cast<u32x4*>(bp + soff[j]) = rp[j];
-      *reinterpret_cast<u32x4*>(bq + soff[j]) = rq[j];
-    }
+    for (int e = 0; e < PER; ++e) *reinterpret_cast<u32x4*>(b + soff[e]) = rg_[e];
   };
 
   // fragment offsets: lane (i, q); rows 8q..8q+3 (h=0) and 8q+4..8q+7 (h=1) of column tile cb
@@ -100,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int rb = 2 * q + h;
-      poff[t][h] = (rb * 8 + ((wn * 4 + t) ^ (q & 1))) * 128 + i * 8;
-      qoff[t][h] = (rb * 8 + ((wm * 4 + t) ^ (q & 1))) * 128 + i * 8;
+      poff[t][h] = (rb * PB + ((wn * 4 + t) ^ (q & 1))) * 128 + i * 8;
+      qoff[t][h] = PBYTES + (rb * QB + ((wk * 4 + t) ^ (q & 1))) * 128 + i * 8;
     }
 
   f32x4 acc[4][4];
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wm == 0);
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
 
   if (nsteps > 0) {
     gload(0);
@@ -119,55 +126,78 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
     if (st + 1 < nsteps) gload(st + 1);
-    const char* bp = smem + (st & 1) * 2 * OP_BYTES;
-    const char* bq = bp + OP_BYTES;
-    bf16x8 pf0[4], qf0[4], pf1[4], qf1[4];
+    const char* b = smem + (st & 1) * STAGE;
+    if constexpr (NW <= 4) {
+      // 2 waves / SIMD: all 32 transposing reads of the stage are scheduled explicitly -- 16 up front, then one read
+      // per MFMA while the first K=32 step computes, then the second step.
+      bf16x8 pf0[4], qf0[4], pf1[4], qf1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      qf0[t] = tr_frag(bq, qoff[t][0], qoff[t][1]);
-      pf0[t] = tr_frag(bp, poff[t][0], poff[t][1]);
-    }
+      for (int t = 0; t < 4; ++t) {
+        qf0[t] = tr_frag(b, qoff[t][0], qoff[t][1]);
+        pf0[t] = tr_frag(b, poff[t][0], poff[t][1]);
+      }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {   // second K=32 step: row blocks +8 (1024 B per row block)
-      qf1[t] = tr_frag(bq + 8 * 1024, qoff[t][0], qoff[t][1]);
-      pf1[t] = tr_frag(bp + 8 * 1024, poff[t][0], poff[t][1]);
-    }
+      for (int t = 0; t < 4; ++t) {
+        qf1[t] = tr_frag(b + 8 * QB * 128, qoff[t][0], qoff[t][1]);
+        pf1[t] = tr_frag(b + 8 * PB * 128, poff[t][0], poff[t][1]);
+      }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0[kt], pf0[nt], acc[nt][kt], 0, 0, 0);
+        for (int kt = 0; kt < 4; ++kt)
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0[kt], pf0[nt], acc[nt][kt], 0, 0, 0);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1[kt], pf1[nt], acc[nt][kt], 0, 0, 0);
-    // 16 transposing reads, then one read per MFMA while the first K=32 step computes, then the second step
-    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+        for (int kt = 0; kt < 4; ++kt)
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1[kt], pf1[nt], acc[nt][kt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    if (do_csum) {
+      for (int r = 0; r < 16; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      if (do_csum) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csum[t] += (float)pf0[t][e] + (float)pf1[t][e];
+          for (int e = 0; e < 8; ++e) csum[t] += (float)pf0[t][e] + (float)pf1[t][e];
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {   // K = 32 MFMA step: row blocks 8 ks .. 8 ks + 7
+        bf16x8 pf[4], qf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          qf[t] = tr_frag(b + ks * 8 * QB * 128, qoff[t][0], qoff[t][1]);
+          pf[t] = tr_frag(b + ks * 8 * PB * 128, poff[t][0], poff[t][1]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kt], pf[nt], acc[nt][kt], 0, 0, 0);
+        if (do_csum) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[t] += (float)pf[t][e];
+        }
+      }
     }
     if (st + 1 < nsteps) lwrite((st + 1) & 1);
     __syncthreads();
   }
 
-  // lane holds n = n0 + wn*64 + nt*16 + i, k = k0 + wm*64 + kt*16 + 4q + reg
+  // lane holds n = n0 + wn*64 + nt*16 + i, k = k0 + wk*64 + kt*16 + 4q + reg
   float* part = p.part + (long)s * p.N * p.K;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int n = n0 + wn * 64 + nt * 16 + i;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const int k = k0 + wm * 64 + kt * 16 + 4 * q;
+      const int k = k0 + wk * 64 + kt * 16 + 4 * q;
       *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
     }
   }
@@ -205,7 +235,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
+int g_tn_tile = 0;   // 0 heuristic, 1 = 128x128, 3 = 256x256 (benchmark knob)
+
 }  // namespace
+
+extern "C" int pvrl_debug_set_gemm_tn_tile(int tile) { g_tn_tile = tile; return PVRL_OK; }
 
 extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits) {
   return splits * (N * K + N) * (int64_t)sizeof(float);
@@ -223,12 +257,20 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   int ms = cdiv(M > 0 ? M : 1, splits);
   p.Ms = cdiv(ms, TM) * TM;
-  p.tiles_k = (int)(K / 128);
-  p.tiles_nk = (int)(N / 128) * p.tiles_k;
   p.part = (float*)workspace;
   p.cpart = dbias ? p.part + splits * N * K : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+  const bool big = (g_tn_tile == 0) ? ((N % 256 == 0) && (K % 256 == 0) && (N / 256) * (K / 256) * splits >= 192)
+                                    : (g_tn_tile == 3 && (N % 256 == 0) && (K % 256 == 0));
+  if (big) {
+    p.tiles_k = (int)(K / 256);
+    p.tiles_nk = (int)(N / 256) * p.tiles_k;
+    hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), dim3((unsigned)(splits * p.tiles_nk)), dim3(1024), 0, s, p);
+  } else {
+    p.tiles_k = (int)(K / 128);
+    p.tiles_nk = (int)(N / 128) * p.tiles_k;
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+  }
   PVRL_LAUNCH_CHECK();
   const long NK = N * K;
   const long nthreads = (NK >> 2) + (dbias ? N : 0);

@@ -71,18 +71,26 @@ def main():
     gemm_case("nt dfc1     bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
     gemm_case("nt dqkv     bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
 
-    def tn_case(name, M_, N_, K_):
+    def tn_case(name, M_, N_, K_, splits=None):
         if not want(name):
             return
         P = rnd(M_, N_).to(BF); Q = rnd(M_, K_).to(BF)
         dW = torch.zeros(N_, K_, device=DEV); db = torch.zeros(N_, device=DEV)
-        us = timeit(lambda: ops.gemm_tn(P, Q, dW, db))
+        if "256x256" in name and splits is None:
+            tiles = (N_ // 256) * (K_ // 256)
+            splits = 8 * max(1, -(-32 // tiles))
+        us = timeit(lambda: ops.gemm_tn(P, Q, dW, db, splits=splits))
+        name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    tn_case("tn wqkv  2304x768", M, 2304, 768)
-    tn_case("tn wproj 768x768", R, 768, 768)
-    tn_case("tn wfc1  3072x768", M, 3072, 768)
-    tn_case("tn wfc2  768x3072", M, 768, 3072)
+    for tile in (1, 3):
+        L.call("pvrl_debug_set_gemm_tn_tile", tile)
+        tg = {1: "128x128", 3: "256x256"}[tile]
+        tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
+        tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
+        tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
+        tn_case(f"tn[{tg}] wfc2  768x3072", M, 768, 3072)
+    L.call("pvrl_debug_set_gemm_tn_tile", 0)
 
     if want("attn"):
         H = 12
