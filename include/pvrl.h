@@ -120,6 +120,10 @@ int pvrl_kl_topk(const float* pred, int64_t ldp, const float* teacher, int64_t l
                  int64_t ldto, void* stream);
 int pvrl_mse(const float* a, const float* b, int64_t n, float grad_scale, float* loss, float* da, float* db,
              void* stream);
+/* MIL-NCE over x[n][n][C] = video . text^T (lib/models/losses.py:15-23): nom[i] / den[i] log-sum-exps (loss =
+ * mean(den - nom)) and dx = grad_scale * d(sum_i (den_i - nom_i)) / dx. */
+int pvrl_milnce(const float* x, int64_t n, int64_t C, float grad_scale, float* nom, float* den, float* dx,
+                void* stream);
 
 /* Fused optimiser steps over flat fp32 buffers (torch.optim.AdamW / Adam / SGD-nesterov as built by
  * lib/models/optimizer.py:93-118; gscale = 1/num_iters of the accumulation branch, train_net.py:187-189).

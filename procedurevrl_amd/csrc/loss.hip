@@ -184,7 +184,69 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
   if (threadIdx.x == 0 && loss) loss[0] = s / (float)n;
 }
 
+// MIL-NCE (lib/models/losses.py:15-23) on x[n][n][C] = video . text^T:
+//   nom_i = logsumexp_c x[i][i][c];   den_i = logsumexp over row i and column i (all j, c);   loss = mean(den - nom)
+// one workgroup per i computes (nom_i, den_i); the gradient kernel is elementwise over x.
+__global__ __launch_bounds__(256) void milnce_stats_kernel(const float* __restrict__ x, int n, int C,
+                                                           float* __restrict__ nom, float* __restrict__ den) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const long row = (long)n * C;
+  float mx = -INFINITY;
+  for (int e = tid; e < n * C; e += 256) {
+    const int j = e / C, c = e - j * C;
+    mx = fmaxf(mx, fmaxf(x[i * row + e], x[j * row + (long)i * C + c]));
+  }
+  mx = block_reduce(mx, red, true);
+  float se = 0.f;
+  for (int e = tid; e < n * C; e += 256) {
+    const int j = e / C, c = e - j * C;
+    se += expf(x[i * row + e] - mx) + expf(x[j * row + (long)i * C + c] - mx);
+  }
+  se = block_reduce(se, red, false);
+  float nm = -INFINITY;
+  for (int c = tid; c < C; c += 256) nm = fmaxf(nm, x[i * row + (long)i * C + c]);
+  nm = block_reduce(nm, red, true);
+  float ns = 0.f;
+  for (int c = tid; c < C; c += 256) ns += expf(x[i * row + (long)i * C + c] - nm);
+  ns = block_reduce(ns, red, false);
+  if (tid == 0) {
+    den[i] = mx + logf(se);
+    nom[i] = nm + logf(ns);
+  }
+}
+
+__global__ __launch_bounds__(256) void milnce_grad_kernel(const float* __restrict__ x, const float* __restrict__ nom,
+                                                          const float* __restrict__ den, int n, int C, float gscale,
+                                                          float* __restrict__ dx) {
+  const long total = (long)n * n * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int a = (int)(idx / ((long)n * C));
+    const int b = (int)((idx / C) % n);
+    const float v = x[idx];
+    float g = expf(v - den[a]) + expf(v - den[b]);
+    if (a == b) g -= expf(v - nom[a]);
+    dx[idx] = gscale * g;
+  }
+}
+
 }  // namespace
+
+extern "C" int pvrl_milnce(const float* x, int64_t n, int64_t C, float grad_scale, float* nom, float* den, float* dx,
+                           void* stream) {
+  if (n <= 0 || C <= 0 || !x || !nom || !den) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(milnce_stats_kernel, dim3((unsigned)n), dim3(256), 0, s, x, (int)n, (int)C, nom, den);
+  PVRL_LAUNCH_CHECK();
+  if (dx) {
+    long blocks = (n * n * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(milnce_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, nom, den, (int)n, (int)C,
+                       grad_scale, dx);
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
 
 extern "C" int pvrl_l2norm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, float* inv_norm, int64_t M, int64_t D,
                                void* stream) {

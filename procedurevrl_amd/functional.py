@@ -150,3 +150,41 @@ class MSELossFn(torch.autograd.Function):
 
 def mse_loss(a, b):
     return MSELossFn.apply(a, b)
+
+
+class MatmulNTFn(torch.autograd.Function):
+    """a @ b.t() in fp32 with gradients to both operands (similarity matrix of the contrastive loss)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.gemm_nt_f32(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = ops.gemm_nt_f32(dy, b.t().contiguous()) if ctx.needs_input_grad[0] else None
+        db = ops.gemm_nt_f32(dy.t().contiguous(), a.t().contiguous()) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+class MILNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n, C):
+        nom, den, dx = ops.milnce(x.contiguous(), n, C, grad_scale=1.0 / n)
+        ctx.save_for_backward(dx)
+        return (den - nom).sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None
+
+
+def milnce_loss(video_embd, text_embd):
+    """MILNCELoss.forward (lib/models/losses.py:15-23): video [n, D], text [n*C, D]."""
+    n = video_embd.shape[0]
+    C = text_embd.shape[0] // n
+    x = MatmulNTFn.apply(video_embd, text_embd)
+    return MILNCEFn.apply(x, n, C)

@@ -359,3 +359,15 @@ def mse(a, b, grad_scale=None):
     L.call("pvrl_mse", _ptr(a), _ptr(b), a.numel(), float(grad_scale if grad_scale is not None else 0.0), _ptr(loss),
            _ptr(da), _ptr(db), _stream())
     return loss, da, db
+
+
+def milnce(x, n, C, grad_scale=None):
+    """x fp32 [n, n*C] -> (nom[n], den[n], dx or None)"""
+    L = lib()
+    assert x.dtype == F32 and x.is_contiguous() and x.numel() == n * n * C
+    nom = torch.empty(n, device=x.device, dtype=F32)
+    den = torch.empty(n, device=x.device, dtype=F32)
+    dx = torch.empty_like(x) if grad_scale is not None else None
+    L.call("pvrl_milnce", _ptr(x), n, C, float(grad_scale if grad_scale is not None else 0.0), _ptr(nom), _ptr(den),
+           _ptr(dx), _stream())
+    return nom, den, dx

@@ -334,6 +334,18 @@ def check_loss():
         out.append((f"kl_topk loss rows={rows} K={K} k={topk}", abs(rl.sum().item() / rows - loss_ref.item()) / abs(loss_ref.item()), 1e-4))
         out.append((f"kl_topk target rows={rows} K={K}", rel(tg, t_ref), 1e-4))
         out.append((f"kl_topk dpred rows={rows} K={K}", rel(dp, pr.grad), 1e-4))
+    from oracle import timesformer_oracle as orc
+    from procedurevrl_amd.functional import milnce_loss
+    for (n, C, D) in [(4, 3, 16), (32, 1, 512), (24, 5, 64)]:
+        v = torch.randn(n, D, generator=g) * 0.3
+        t = torch.randn(n * C, D, generator=g) * 0.3
+        vr = v.clone().requires_grad_(True); tr = t.clone().requires_grad_(True)
+        lref = orc.milnce(vr, tr); lref.backward()
+        vd = v.to(dev()).requires_grad_(True); td = t.to(dev()).requires_grad_(True)
+        l = milnce_loss(vd, td); l.backward()
+        out.append((f"milnce loss n={n} C={C}", abs(l.item() - lref.item()) / abs(lref.item()), 1e-5))
+        out.append((f"milnce dV n={n} C={C}", rel(vd.grad, vr.grad), 1e-4))
+        out.append((f"milnce dT n={n} C={C}", rel(td.grad, tr.grad), 1e-4))
     a = torch.randn(8, 512, generator=g); b = torch.randn(8, 512, generator=g)
     ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     lref = F.mse_loss(ar, br); lref.backward()
