@@ -3,7 +3,8 @@
     python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL).  A step is one full
 training iteration over one synthetic batch resident in HBM: TimeSformer encoder forward, projection
-head + step logits + top-5 KL loss, backward, gradient all-reduce (N > 1), fused AdamW step.
+head + step logits + top-5 KL loss + global InfoNCE over the all-gathered clip / text embeddings,
+backward, gradient all-reduce (N > 1), fused AdamW step.
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
@@ -35,11 +36,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("PVRL_DIST_BACKEND", "nccl")          # "gloo" = functional test of the N > 1 path on one GPU
+    if os.environ.get("PVRL_SINGLE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -47,8 +54,9 @@ def main():
     from procedurevrl_amd.config import get_cfg
     from procedurevrl_amd.build import build_model
     from procedurevrl_amd.datasets import synthetic_label_emb
-    from procedurevrl_amd.distributed import GradReducer
-    from procedurevrl_amd.functional import kl_topk_loss
+    from procedurevrl_amd.distributed import AllGather, GradReducer
+    from procedurevrl_amd.functional import kl_topk_loss, l2norm
+    from procedurevrl_amd.losses import MILNCELoss
     from procedurevrl_amd.optimizer import construct_optimizer, set_lr
 
     cfg = get_cfg()
@@ -82,11 +90,16 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     frames = torch.randn(B, 3, args.frames, 224, 224, device=dev, generator=g)
     teacher = torch.randn(B, args.classes, device=dev, generator=g) * 4.0
+    text_emb = l2norm(torch.randn(B, 512, device=dev, generator=g))        # stand-in for the frozen CLIP-text embeddings
+    nce = MILNCELoss()
 
     def step():
         optimizer.zero_grad(set_to_none=True)
         pred = model(frames)
-        loss = kl_topk_loss(pred, teacher, 5)
+        loss = kl_topk_loss(pred, teacher, 5)                                # step matching (tools/train_net.py:152-160)
+        v = vt.last_video_emb                                                # unit-norm clip embeddings [B, 512]
+        v_all, t_all = (AllGather.apply(v), AllGather.apply(text_emb)) if world > 1 else (v, text_emb)
+        loss = loss + nce(v_all * (1.0 / 0.07 ** 0.5), t_all * (1.0 / 0.07 ** 0.5))   # global InfoNCE over all ranks' clips
         loss.backward()
         reducer.finish()
         optimizer.step()
@@ -123,7 +136,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"TimeSformer ViT-B {args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
-                                   "top-5 KL loss, fwd+bwd+AdamW (BASELINE configs[1])",
+                                   "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": float(loss.item()),
             "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),

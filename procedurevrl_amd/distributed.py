@@ -20,6 +20,14 @@ import torch.distributed as dist
 _LOCAL_PROCESS_GROUP = None
 
 
+def _gather_into(out, tensor, world):
+    """all_gather straight into `out` (RCCL); the gloo test backend lacks the flat form, so it gets views of `out`."""
+    if dist.get_backend() == "gloo":
+        dist.all_gather(list(out.chunk(world, 0)), tensor)
+    else:
+        dist.all_gather_into_tensor(out, tensor)
+
+
 class AllGather(torch.autograd.Function):
     """All-gather with the reference's backward: the LOCAL slice of the incoming gradient, no
     reduction (distributed.py:24-29)."""
@@ -29,7 +37,7 @@ class AllGather(torch.autograd.Function):
         world = dist.get_world_size()
         tensor = tensor.contiguous()
         out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
-        dist.all_gather_into_tensor(out, tensor)   # one collective into the final buffer, no list + cat
+        _gather_into(out, tensor, world)           # one collective into the final buffer, no list + cat
         ctx.rank = dist.get_rank()
         ctx.batch_size = tensor.shape[0]
         return out
@@ -46,7 +54,7 @@ def all_gather(tensors):
     for t in tensors:
         t = t.contiguous()
         buf = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        dist.all_gather_into_tensor(buf, t)
+        _gather_into(buf, t, world)
         out.append(buf)
     return out
 

@@ -262,6 +262,7 @@ class VisionTransformer(nn.Module):
             x = linear_f32(x, self.head.weight, self.head.bias)
             x = l2norm(x)
             video_emb = x
+            self.last_video_emb = video_emb        # exposed for the all-gather contrastive loss (MILNCELoss)
             if hasattr(self, "num_seg") and self.num_seg > 0:
                 x = self.order_tfm(video_emb)
                 x = l2norm(x.contiguous())
