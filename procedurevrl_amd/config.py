@@ -73,6 +73,9 @@ class CfgNode(dict):
                 return [plain(x) for x in v]
             if isinstance(v, list):
                 return [plain(x) for x in v]
+            if not isinstance(v, _VALID):       # e.g. an in-memory synthetic label-embedding tensor
+                shape = tuple(getattr(v, "shape", ()))
+                return f"<{type(v).__name__} {shape}>"
             return v
         return yaml.safe_dump(plain(self), **kwargs)
 
