@@ -145,6 +145,7 @@ def main():
         }
         if timing:
             out["roofline"] = timing["roofline"]
+            out["roofline"]["traffic"] = pmc_traffic(timing["roofline"]["kernel"])
             out["kernels"] = timing["summary"]
         if not args.no_cpu_baseline:
             try:
@@ -155,6 +156,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1_b_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r1_b_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
+    if kernel.startswith("gemm_tn"):
+        keys = [k for k in t if k.startswith("gemm_tn_kernel") or k.startswith("tn_reduce_kernel")]
+    else:
+        e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
+        keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]
+    if not keys:
+        return None
+    main = max(keys, key=lambda k: t[k]["avg_us"])
+    return round(sum(t[k]["hbm_bytes_per_launch"] for k in keys if k == main or k.startswith("tn_reduce")), 0)
 
 
 def cpu_baseline(args):
