@@ -75,6 +75,22 @@ def check_gemm_nt():
         ur = ub.clone().requires_grad_(True)
         (ur * torch.sigmoid(1.702 * ur)).sum().backward()
         out.append((f"gemm_nt dqgelu {M}x{N}x{K}", rel(o, ref * ur.grad), TOL_BF16))
+    # large-M path: 256x256 tiles, ragged last M-tile (50208 = 196 * 256 + 32), row-modulo residual table
+    M, N, K = 50208, 768, 128
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g); rs = torch.rand(M, generator=g) + 0.5
+    E = torch.randn(1568, N, generator=g)
+    ref = bf(A) @ bf(W).t()
+    Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
+    o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bias.to(dev()), rowscale=rs.to(dev()), aux=E.to(dev()), aux_rowmod=1568)
+    out.append(("gemm_nt large-M resid-mod 50208x768", rel(o, E[torch.arange(M) % 1568] + rs[:, None] * (ref + bias)), 1e-4))
+    u, gl = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_GELU, bias=bias.to(dev()))
+    out.append(("gemm_nt large-M gelu 50208x768", rel(gl, F.gelu(ref + bias)), TOL_BF16))
+    upre = torch.randn(M, N, generator=g)
+    o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_DGELU, rowscale=rs.to(dev()), aux=upre.to(dev(), BF))
+    ur = bf(upre).clone().requires_grad_(True)
+    F.gelu(ur).sum().backward()
+    out.append(("gemm_nt large-M dgelu 50208x768", rel(o, rs[:, None] * ref * ur.grad), TOL_BF16))
     # strided A (a column slice of a wider buffer) and row-sliced output
     M, N, K = 200, 128, 128
     big = torch.randn(M, 3 * K, generator=g)
