@@ -152,7 +152,15 @@ class GradReducer:
     def _hook(self, i):
         a, b = self._block_range(i)
         gs = self.vt.grad_store()
-        self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
+        side = self.vt.engine._side if self.vt.engine.overlap_wgrad else None
+        if side is not None and gs.flat.is_cuda:
+            # block i's weight gradients were produced on the side stream, its LayerNorm gradients on the main one:
+            # order the collective after both
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
         self.done.append((a, b))
 
     def finish(self):

@@ -79,6 +79,8 @@ class EncoderEngine:
         self._grads = None
         self.saved = None
         self.grad_hook = None
+        self.overlap_wgrad = True     # weight-gradient GEMMs on a side stream, concurrent with the dgrad chain
+        self._side = None
         assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
 
     # ------------------------------------------------------------------ weights
@@ -98,6 +100,35 @@ class EncoderEngine:
 
     def grad_store(self):
         return self.m.grad_store()
+
+    # ------------------------------------------------------------------ side stream for weight gradients
+    def side_stream(self, device):
+        """Nothing in backward depends on a weight gradient until the optimiser step, while the data-gradient chain
+        (dgrad GEMM -> LayerNorm bwd -> attention bwd ...) is strictly serial.  Weight-gradient GEMMs are therefore
+        issued on a second HIP stream: they fill CUs left idle by the ragged last wave of the big-tile dgrad GEMMs
+        and overlap the HBM-bound LayerNorm / cast kernels."""
+        if not self.overlap_wgrad:
+            return None
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _wgrad(self, dy, xin, dw, dbias, beta):
+        side = self.side_stream(dy.device)
+        if side is None:
+            ops.gemm_tn(dy, xin, dw, dbias, beta=beta)
+            return
+        main = torch.cuda.current_stream()
+        ev = main.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            ops.gemm_tn(dy, xin, dw, dbias, beta=beta, ws_tag="tn_side")
+        dy.record_stream(side)
+        xin.record_stream(side)
+
+    def join_side_stream(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     # ------------------------------------------------------------------ drop path
     def _droppath(self, i, B, N, T, device, training):
@@ -250,7 +281,7 @@ class EncoderEngine:
         dz = ops.cast_scale(dx[:R], None)
         w = m.patch_embed.proj.weight
         (dw, bw), (dbias, _) = gs.target(w), gs.target(m.patch_embed.proj.bias)
-        ops.gemm_tn(dz, sv["a_pe"], dw.view(C, -1), dbias, beta=bw)
+        self._wgrad(dz, sv["a_pe"], dw.view(C, -1), dbias, bw)
         G = ops.batch_sum(dx[:R], B, N * T).view(N, T, C)
         dcls_rows = dx[R:].sum(0)
         self._acc(gs, m.cls_token, dcls_rows.view(1, 1, C))
@@ -262,6 +293,7 @@ class EncoderEngine:
                                       "resizes at inference only, vit.py:374)")
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
+        self.join_side_stream()
         self.saved = None
 
     @staticmethod
@@ -286,7 +318,7 @@ class EncoderEngine:
 
         def wgrad(dy, xin, lin):
             (dw, bw), (dbias, _) = gs.target(lin.weight), gs.target(lin.bias)
-            ops.gemm_tn(dy, xin, dw, dbias, beta=bw)
+            self._wgrad(dy, xin, dw, dbias, bw)
 
         def lnbwd(dh, x, st, ln, dx_in, dx_out):
             (dg, bg), (db, _) = gs.target(ln.weight), gs.target(ln.bias)

@@ -132,7 +132,7 @@ def tn_splits(M, N, K):
     return s
 
 
-def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None):
+def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
     """dW[N,K] = beta*dW + P[M,N]^T @ Q[M,K]; dbias = beta*dbias + colsum(P)."""
     L = lib()
     _chk2d(P, BF16); _chk2d(Q, BF16)
@@ -142,7 +142,7 @@ def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None):
     if splits is None:
         splits = tn_splits(M, N, K)
     nbytes = L.call("pvrl_gemm_tn_workspace_bytes", N, K, splits)
-    ws = workspace(nbytes, P.device, "tn")
+    ws = workspace(nbytes, P.device, ws_tag)
     _timed("gemm_tn_kernel+reduce", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_tn_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), _ptr(dbias),
         _ptr(ws), ws.numel(), _stream()))
