@@ -25,6 +25,7 @@ struct GemmTN {
   int M, N, K, Ms, tiles_k, tiles_nk;
   float* part;   // [splits][N][K]
   float* cpart;  // [splits][N] or null
+  const bf16* zero_page;  // 256 zero bytes (source of out-of-range rows for the LDS-DMA path)
 };
 
 constexpr int TM = 64;   // reduction rows per pipeline stage (two K=32 MFMA steps)
@@ -212,6 +213,134 @@ __global__ __launch_bounds__(64 * WN * WK) void gemm_tn_kernel(GemmTN p) {
   }
 }
 
+// LDS-DMA variant of the 128x128 tile: the blocked [4][16] LDS image is written directly by global_load_lds (16 B per
+// lane, lane-linear destination = exactly one 128-byte block per 8 lanes; the column-block swizzle moves to the source
+// address).  Removes the 8 ds_write_b128 + 32 staging VGPRs per thread and stage of the register-staged kernel, whose
+// LDS write cycles (~13 clk per wave-instruction) exceeded the MFMA time of a stage.
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
+  constexpr int PB = 8, QB = 8;
+  constexpr int PBYTES = TM * 128 * 2, STAGE = 2 * PBYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = (j / p.tiles_nk) * 8 + xcd;
+  const int rem = j % p.tiles_nk;
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int nsteps = (mend - mbeg + TM - 1) / TM;
+
+  // 8 LDS-DMA instructions per wave and stage: instruction it = wave*8 + e copies 4 tile rows x 256 B of P (it < 16) or Q
+  const bf16* src[8];
+  long sstep[8];
+  int srow[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int it = wave * 8 + e;
+    const bool isq = it >= 16;
+    const int rg = isq ? it - 16 : it;                 // row block (4 rows)
+    const int r = (lane >> 1) & 3, h = lane & 1;
+    const int cb = (lane >> 3) ^ ((rg >> 1) & 1);      // source-side swizzle of the 16-column block
+    srow[e] = rg * 4 + r;
+    const long ld = isq ? p.ldq : p.ldp;
+    src[e] = (isq ? p.Q + k0 : p.P + n0) + (long)(mbeg + srow[e]) * ld + cb * 16 + h * 8;
+    sstep[e] = (long)TM * ld;
+  }
+  auto stage = [&](int buf, int st) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int it = wave * 8 + e;
+      const bool ok = mbeg + st * TM + srow[e] < mend;
+      const bf16* g = ok ? src[e] + (long)st * sstep[e] : p.zero_page + (lane & 7) * 8;
+      glds16(g, b + (it >= 16 ? PBYTES : 0) + (it & 15) * 1024);
+    }
+  };
+
+  const int q = lane >> 4, i = lane & 15;
+  int poff[4][2], qoff[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rb = 2 * q + h;
+      poff[t][h] = (rb * PB + ((wn * 4 + t) ^ (q & 1))) * 128 + i * 8;
+      qoff[t][h] = PBYTES + (rb * QB + ((wk * 4 + t) ^ (q & 1))) * 128 + i * 8;
+    }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+
+  if (nsteps > 0) stage(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();   // this wave's LDS-DMA has landed (vmcnt(0)); everyone finished reading the other buffer
+    if (st + 1 < nsteps) stage((st + 1) & 1, st + 1);
+    const char* b = smem + (st & 1) * STAGE;
+    bf16x8 pf0[4], qf0[4], pf1[4], qf1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      qf0[t] = tr_frag(b, qoff[t][0], qoff[t][1]);
+      pf0[t] = tr_frag(b, poff[t][0], poff[t][1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      qf1[t] = tr_frag(b + 8 * QB * 128, qoff[t][0], qoff[t][1]);
+      pf1[t] = tr_frag(b + 8 * PB * 128, poff[t][0], poff[t][1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0[kt], pf0[nt], acc[nt][kt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1[kt], pf1[nt], acc[nt][kt], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    if (do_csum) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[t] += (float)pf0[t][e] + (float)pf1[t][e];
+    }
+  }
+
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + wn * 64 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
+    }
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = csum[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) p.cpart[(long)s * p.N + n0 + wn * 64 + t * 16 + i] = v;
+    }
+  }
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -235,14 +364,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
-int g_tn_tile = 0;   // 0 heuristic, 1 = 128x128, 3 = 256x256 (benchmark knob)
+int g_tn_tile = 0;   // 0/1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 (benchmark knob)
 
 }  // namespace
 
 extern "C" int pvrl_debug_set_gemm_tn_tile(int tile) { g_tn_tile = tile; return PVRL_OK; }
 
 extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits) {
-  return splits * (N * K + N) * (int64_t)sizeof(float);
+  return splits * (N * K + N) * (int64_t)sizeof(float) + 256;   // + a zero page for out-of-range rows
 }
 
 extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
@@ -250,7 +379,7 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
                                  int64_t workspace_bytes, void* stream) {
   if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 8 || (splits % 8) || M < 0)
     return PVRL_EINVAL;
-  if ((ldp % 8) || (ldq % 8)) return PVRL_EINVAL;
+  if ((ldp % 8) || (ldq % 8) || ((uintptr_t)P % 16) || ((uintptr_t)Q % 16)) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_gemm_tn_workspace_bytes(N, K, splits)) return PVRL_EINVAL;
   GemmTN p;
   p.P = (const bf16*)P; p.ldp = ldp; p.Q = (const bf16*)Q; p.ldq = ldq;
@@ -260,6 +389,9 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   p.part = (float*)workspace;
   p.cpart = dbias ? p.part + splits * N * K : nullptr;
   hipStream_t s = (hipStream_t)stream;
+  char* zp = (char*)workspace + splits * (N * K + N) * (int64_t)sizeof(float);
+  p.zero_page = (const bf16*)zp;
+  if (hipMemsetAsync(zp, 0, 256, s) != hipSuccess) return PVRL_EHIP;
   // the 256x256 / 16-wave instantiation is register-starved at 128 VGPRs (spills; 2-3x slower on MI355X) and is
   // only reachable through the benchmark knob
   const bool big = g_tn_tile == 3 && (N % 256 == 0) && (K % 256 == 0);
@@ -270,7 +402,13 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   } else {
     p.tiles_k = (int)(K / 128);
     p.tiles_nk = (int)(N / 128) * p.tiles_k;
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+    // measured on MI355X (tools/bench_kernels.py, same process A/B): register staging 505-585 TFLOP/s, LDS-DMA
+    // staging 485-550: the kernel is bound by the half-rate ds_read_b64_tr_b16 stream (32 per wave and stage),
+    // not by the staging path, so the register-staged form stays the default; knob 2 selects the LDS-DMA form.
+    if (g_tn_tile == 2)
+      hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
   }
   PVRL_LAUNCH_CHECK();
   const long NK = N * K;

@@ -132,6 +132,28 @@ def check_gemm_tn():
     return out
 
 
+def check_gemm_tn_variants():
+    """the alternative weight-gradient kernels behind the benchmark knob (LDS-DMA staging, 256x256 tile)"""
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(31)
+    out = []
+    M, N, K = 1111, 512, 256
+    P = torch.randn(M, N, generator=g); Q = torch.randn(M, K, generator=g)
+    ref = bf(P).t() @ bf(Q)
+    try:
+        for knob, name in ((2, "lds-dma"), (3, "256x256")):
+            L.call("pvrl_debug_set_gemm_tn_tile", knob)
+            dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
+            ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, splits=16)
+            out.append((f"gemm_tn[{name}] dW", rel(dW, ref), 1e-4))
+            out.append((f"gemm_tn[{name}] dbias", rel(db, bf(P).sum(0)), 1e-4))
+    finally:
+        L.call("pvrl_debug_set_gemm_tn_tile", 0)
+    return out
+
+
 def check_layernorm():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(4)
@@ -372,5 +394,5 @@ def check_loss():
     return out
 
 
-ALL_CHECKS = [check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]

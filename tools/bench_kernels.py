@@ -91,9 +91,9 @@ def main():
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    for tile in (1, 3):
+    for tile in (1, 0, 1, 0):
         L.call("pvrl_debug_set_gemm_tn_tile", tile)
-        tg = {1: "128x128", 3: "256x256"}[tile]
+        tg = {1: "128 regs", 0: "128 glds"}[tile]
         tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
         tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
         tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
