@@ -53,6 +53,88 @@ template <bool F32OUT> __device__ __forceinline__ int swz_w(int row) {
   return F32OUT ? (row >> 1) & 7 : ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
 }
 
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  // ---- epilogue ----
+  const int q = lane >> 4, i = lane & 15;
+  const int nw0 = n0 + wn * 64;
+  if constexpr (F32OUT) {
+    // lane holds, for tile nt, columns nw0 + 16 nt + 4q + (0..3)
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 16 * nt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + i;
+      if (m >= p.M) continue;
+      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 4 * q;
+      const float* r = nullptr;
+      if constexpr (EPI == PVRL_EPI_RESID_F32) {
+        const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
+        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 4 * q;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
+        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 16 * nt);
+        *reinterpret_cast<f32x4*>(o + 16 * nt) = ov;
+      }
+    }
+  } else {
+    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
+    float bv[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[c][e] = p.bias ? p.bias[nw0 + 32 * c + 8 * q + e] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + i;
+      if (m >= p.M) continue;
+      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mt][2 * c][e] + bv[c][e];
+          v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
+        }
+        const long col = nw0 + 32 * c + 8 * q;
+        if constexpr (EPI == PVRL_EPI_BF16) {
+          bf16x8 o0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o0[e] = (bf16)(rs * v[e]);
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
+        } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
+          bf16x8 u0, g0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            u0[e] = (bf16)v[e];
+            g0[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
+          }
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = u0;
+          *reinterpret_cast<bf16x8*>((bf16*)p.out1 + (long)m * p.ld1 + col) = g0;
+        } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
+          const bf16x8 ua = *reinterpret_cast<const bf16x8*>((const bf16*)p.aux + (long)m * p.aux_ld + col);
+          bf16x8 o0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
+            o0[e] = (bf16)(rs * v[e] * d);
+          }
+          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
+        }
+      }
+    }
+  }
+}
+
 // WM x WN waves per workgroup, each owning a 64x64 output block: tile = (64*WM) x (64*WN).
 //   <2,2>: 128x128, 4 waves, 64 KiB LDS, 2 workgroups / CU   (small M: order transformer, CLIP text)
 //   <4,4>: 256x256, 16 waves, 128 KiB LDS, 1 workgroup / CU  (the encoder's 50k-row GEMMs: half the L2->LDS
@@ -170,83 +252,109 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   }
 
-  // ---- epilogue ----
-  const int q = lane >> 4, i = lane & 15;
-  const int nw0 = n0 + wn * 64;
-  if constexpr (F32OUT) {
-    // lane holds, for tile nt, columns nw0 + 16 nt + 4q + (0..3)
-    f32x4 bv[4];
+  nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Deep-pipelined variant for the 256x256 tile: BK = 32 stages (32 KiB each) in a 4-deep LDS ring, LDS-DMA issued
+// THREE stages ahead, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so that loads stay in flight across barriers.
+// (`__syncthreads()` drains vmcnt(0) whenever an LDS-DMA is pending.)  MEASURED on MI355X (tools/bench_kernels.py, same-
+// process A/B, 50k-row shapes): 0-12 % SLOWER than the 2-stage BK = 64 kernel above (e.g. 892 vs 1028 TFLOP/s at
+// N=768,K=2304) -- twice the barriers per MFMA cost more than the hidden latency buys at 4 waves/SIMD.  Kept behind
+// the benchmark knob (tile 4) as a tested reference point; the heuristic never selects it.
+// LDS tiles are [256 rows][32 bf16] = 64-byte rows; 16-byte chunk c of row r lives at chunk c ^ g(a(r)), g(a) = (4-a)&3,
+// a(r) = (r>>2)&3 for naturally ordered rows and (r>>3)&3 for the bf16-output W row order: every ds_read_b128 lane
+// group then touches 16 distinct 16-byte slots.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int g64(int a) { return (4 - a) & 3; }
+template <bool F32OUT> __device__ __forceinline__ int swz_w64(int row) { return g64(F32OUT ? (row >> 2) & 3 : (row >> 3) & 3); }
+__device__ __forceinline__ int swz_x64(int row) { return g64((row >> 2) & 3); }
+
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_nt_pipe_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, NW = 16, BKS = 32, NS = 4;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BKS * 2, STAGE = 2 * XBYTES;   // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int GM = 8;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: 32 LDS-DMA instructions per stage (16 rows x 64 B each); wave w issues X instruction w and W instruction w
+  const bf16* gx;
+  const bf16* gw;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    const int pc = lane & 3;
+    int grow = m0 + row;
+    grow = grow < p.M ? grow : p.M - 1;
+    gx = p.A + (long)grow * p.lda + ((pc ^ swz_x64(row)) << 3);
+    gw = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w64<F32OUT>(row)) << 3);
+  }
+  auto stage = [&](int kt) {
+    char* b = smem + (kt & (NS - 1)) * STAGE;
+    glds16(gx + kt * BKS, b + wave * 1024);
+    glds16(gw + kt * BKS, b + XBYTES + wave * 1024);
+  };
+
+  int xoff[4], woff[4];
+  {
+    const int q = lane >> 4, i = lane & 15;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-      bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 16 * nt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + i;
-      if (m >= p.M) continue;
-      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
-      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 4 * q;
-      const float* r = nullptr;
-      if constexpr (EPI == PVRL_EPI_RESID_F32) {
-        const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
-        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 4 * q;
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        f32x4 ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
-        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 16 * nt);
-        *reinterpret_cast<f32x4*>(o + 16 * nt) = ov;
-      }
-    }
-  } else {
-    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
-    float bv[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[c][e] = p.bias ? p.bias[nw0 + 32 * c + 8 * q + e] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + i;
-      if (m >= p.M) continue;
-      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[mt][2 * c][e] + bv[c][e];
-          v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
-        }
-        const long col = nw0 + 32 * c + 8 * q;
-        if constexpr (EPI == PVRL_EPI_BF16) {
-          bf16x8 o0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o0[e] = (bf16)(rs * v[e]);
-          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
-        } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
-          bf16x8 u0, g0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            u0[e] = (bf16)v[e];
-            g0[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
-          }
-          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = u0;
-          *reinterpret_cast<bf16x8*>((bf16*)p.out1 + (long)m * p.ld1 + col) = g0;
-        } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
-          const bf16x8 ua = *reinterpret_cast<const bf16x8*>((const bf16*)p.aux + (long)m * p.aux_ld + col);
-          bf16x8 o0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
-            o0[e] = (bf16)(rs * v[e] * d);
-          }
-          *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + col) = o0;
-        }
-      }
+    for (int t = 0; t < 4; ++t) {
+      const int rx = wm * 64 + t * 16 + i;
+      xoff[t] = rx * 64 + ((q ^ swz_x64(rx)) << 4);
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = XBYTES + rw * 64 + ((q ^ swz_w64<F32OUT>(rw)) << 4);
     }
   }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BKS;
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt must have landed: this wave has issued 2 loads per stage for stages .. min(kt+2, nk-1)
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave's part of stage kt is in LDS; buffer (kt-1)%4 is free
+    if (kt + 3 < nk) stage(kt + 3);
+    const char* b = smem + (kt & (NS - 1)) * STAGE;
+    bf16x8 xf[4], wf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wf[t] = *reinterpret_cast<const bf16x8*>(b + woff[t]);
+      xf[t] = *reinterpret_cast<const bf16x8*>(b + xoff[t]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+  }
+  nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -308,11 +416,22 @@ int launch_tile(GemmNT p, hipStream_t s) {
   return PVRL_OK;
 }
 
-int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x128, 3 = 256x256 (debug / benchmarking knob)
+int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 deep pipeline (knob)
+
+template <int EPI>
+int launch_pipe(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / 256;
+  p.tiles_m = cdiv(p.M, 256);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_pipe_kernel<EPI>), dim3(p.nwg), dim3(1024), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
 
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   int t = g_force_tile;
+  if (t == 4 && p.N % 256 == 0) return launch_pipe<EPI>(p, s);
   if (t == 0) t = (p.M >= 4096 && p.N % 256 == 0) ? 3 : (p.M >= 2048 ? 2 : 1);
   if (t == 3 && p.N % 256) t = 2;
   // (cutting the ragged last wave of 256x256 tiles off into a 128x128-tile launch was measured 12 % SLOWER:

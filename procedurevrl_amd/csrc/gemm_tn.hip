@@ -341,6 +341,119 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
   }
 }
 
+// 256(n) x 256(k) tile, 8 waves (2 along n x 4 along k), each wave a 128 x 64 block (8 x 4 MFMA tiles, 128 accumulator
+// VGPRs): 24 transposing reads per 32 MFMAs instead of 32 per 32 for the 64x64 wave block, and half the L2->LDS bytes per
+// FLOP of the 128x128 tile.  LDS-DMA staging (no staging VGPRs), 2 x 64 KiB stages, one workgroup per CU.
+__global__ __launch_bounds__(512, 2) void gemm_tn_w128_kernel(GemmTN p) {
+  constexpr int NB = 16;                                   // 16-column blocks per row block (256 columns)
+  constexpr int PBYTES = TM * 256 * 2, STAGE = 2 * PBYTES; // 32 KiB + 32 KiB
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = (j / p.tiles_nk) * 8 + xcd;
+  const int rem = j % p.tiles_nk;
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int nsteps = (mend - mbeg + TM - 1) / TM;
+
+  const bf16* src[8];
+  long sstep[8];
+  int srow[8], sdst[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int it = wave * 8 + e;                       // 0..63
+    const bool isq = it >= 32;
+    const int l = it & 31;
+    const int rg = l >> 1, seg = l & 1;                // 4-row group, 256-byte segment of the 512-byte tile row
+    const int r = (lane >> 1) & 3, h = lane & 1;
+    const int cb = (seg * 8 + (lane >> 3)) ^ ((rg >> 1) & 1);
+    srow[e] = rg * 4 + r;
+    const long ld = isq ? p.ldq : p.ldp;
+    src[e] = (isq ? p.Q + k0 : p.P + n0) + (long)(mbeg + srow[e]) * ld + cb * 16 + h * 8;
+    sstep[e] = (long)TM * ld;
+    sdst[e] = (isq ? PBYTES : 0) + rg * (NB * 128) + seg * 1024;
+  }
+  auto stage = [&](int buf, int st) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = mbeg + st * TM + srow[e] < mend;
+      const bf16* g = ok ? src[e] + (long)st * sstep[e] : p.zero_page + (lane & 7) * 8;
+      glds16(g, b + sdst[e]);
+    }
+  };
+
+  const int q = lane >> 4, i = lane & 15;
+  int poff[8][2], qoff[4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rb = 2 * q + h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) poff[t][h] = (rb * NB + ((wn * 8 + t) ^ (q & 1))) * 128 + i * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qoff[t][h] = PBYTES + (rb * NB + ((wk * 4 + t) ^ (q & 1))) * 128 + i * 8;
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+
+  if (nsteps > 0) stage(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();
+    if (st + 1 < nsteps) stage((st + 1) & 1, st + 1);
+    const char* b = smem + (st & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* bk = b + ks * 8 * NB * 128;
+      bf16x8 pf[8], qf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) qf[t] = tr_frag(bk, qoff[t][0], qoff[t][1]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pf[t] = tr_frag(bk, poff[t][0], poff[t][1]);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kt], pf[nt], acc[nt][kt], 0, 0, 0);
+      if (do_csum) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[t] += (float)pf[t][e];
+      }
+    }
+  }
+
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int n = n0 + wn * 128 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
+    }
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v = csum[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = v;
+    }
+  }
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -395,7 +508,11 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   // the 256x256 / 16-wave instantiation is register-starved at 128 VGPRs (spills; 2-3x slower on MI355X) and is
   // only reachable through the benchmark knob
   const bool big = g_tn_tile == 3 && (N % 256 == 0) && (K % 256 == 0);
-  if (big) {
+  if (g_tn_tile == 4 && (N % 256 == 0) && (K % 256 == 0)) {
+    p.tiles_k = (int)(K / 256);
+    p.tiles_nk = (int)(N / 256) * p.tiles_k;
+    hipLaunchKernelGGL(gemm_tn_w128_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(512), 0, s, p);
+  } else if (big) {
     p.tiles_k = (int)(K / 256);
     p.tiles_nk = (int)(N / 256) * p.tiles_k;
     hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), dim3((unsigned)(splits * p.tiles_nk)), dim3(1024), 0, s, p);

@@ -101,6 +101,33 @@ def check_gemm_nt():
     return out
 
 
+def check_gemm_nt_tiles():
+    """every NT tile / pipeline variant behind the benchmark knob against the same reference (K = 768, 192 and 64:
+    pipeline prologue / tail paths), three epilogue families"""
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(41)
+    out = []
+    try:
+        for (M, N, K) in [(700, 512, 768), (300, 256, 192), (260, 256, 64)]:
+            A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05
+            bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
+            ref = bf(A) @ bf(W).t()
+            Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
+            for knob in (1, 2, 3, 4):
+                L.call("pvrl_debug_set_gemm_tile", knob)
+                o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_BF16, bias=bias.to(dev()))
+                out.append((f"gemm_nt tile{knob} bf16 {M}x{N}x{K}", rel(o, ref + bias), TOL_BF16))
+                o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bias.to(dev()), aux=resid.to(dev()))
+                out.append((f"gemm_nt tile{knob} resid {M}x{N}x{K}", rel(o, resid + ref + bias), 1e-4))
+                u, gl = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_GELU, bias=bias.to(dev()))
+                out.append((f"gemm_nt tile{knob} gelu {M}x{N}x{K}", rel(gl, F.gelu(ref + bias)), TOL_BF16))
+    finally:
+        L.call("pvrl_debug_set_gemm_tile", 0)
+    return out
+
+
 def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -143,7 +170,7 @@ def check_gemm_tn_variants():
     P = torch.randn(M, N, generator=g); Q = torch.randn(M, K, generator=g)
     ref = bf(P).t() @ bf(Q)
     try:
-        for knob, name in ((2, "lds-dma"), (3, "256x256")):
+        for knob, name in ((2, "lds-dma"), (3, "256x256"), (4, "256x256 w128")):
             L.call("pvrl_debug_set_gemm_tn_tile", knob)
             dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
             ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, splits=16)
@@ -394,5 +421,5 @@ def check_loss():
     return out
 
 
-ALL_CHECKS = [check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]

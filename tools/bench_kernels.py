@@ -62,8 +62,10 @@ def main():
         gemm_case(f"nt[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
         gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
     for rep in range(2):
-        for tile, tg in ((3, "256 nosplit"), (0, "auto/split ")):
+        for tile, tg in ((3, "256 2-stage"), (4, "256 4-stage")):
             L.call("pvrl_debug_set_gemm_tile", tile)
+            gemm_case(f"ab[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
+            gemm_case(f"ab[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
             gemm_case(f"ab[{tg}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] fc    resid M x768x768", R, 768, 768, L.PVRL_EPI_RESID_F32)
             gemm_case(f"ab[{tg}] fc2   resid M x768x3072", M, 768, 3072, L.PVRL_EPI_RESID_F32)
@@ -86,14 +88,14 @@ def main():
         dW = torch.zeros(N_, K_, device=DEV); db = torch.zeros(N_, device=DEV)
         if "256x256" in name and splits is None:
             tiles = (N_ // 256) * (K_ // 256)
-            splits = 8 * max(1, -(-32 // tiles))
+            splits = 8 * max(1, -(-48 // tiles))
         us = timeit(lambda: ops.gemm_tn(P, Q, dW, db, splits=splits))
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    for tile in (1, 0, 1, 0):
+    for tile in (1, 4, 1, 4):
         L.call("pvrl_debug_set_gemm_tn_tile", tile)
-        tg = {1: "128 regs", 0: "128 glds"}[tile]
+        tg = {1: "128 regs", 4: "256x256 w128"}[tile]
         tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
         tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
         tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
