@@ -253,6 +253,47 @@ def order_tfm_pretrain(sd, pre, x, max_len, layers, n_head, mask_inds, pad_start
     return denoised, mask_inds, [x0_rep, inter], inter
 
 
+def order_tfm_forecast(sd, pre, x, num_seg, max_len, layers, n_head):
+    """DiffusionTransformer.diffusion_signal_forecast, tfm_model.py:206-249 (the appended 'noise' token is all-zero)."""
+    hidden = x.shape[1]
+    clip_feats = rearrange(x, "(b t) c -> t b c", t=num_seg)
+    bsz = clip_feats.size(1)
+    temp_emb = sd[pre + "temporalEmbedding.weight"][torch.arange(max_len)][:, None, :].expand(-1, bsz, -1)
+    bs_inds = torch.arange(bsz)
+    mask_inds = torch.full((bsz,), max_len - 1, dtype=torch.long)
+    noise = torch.zeros((1, bsz, hidden))
+    orig = torch.cat((clip_feats, noise), dim=0)
+    cf = orig.clone()
+    sa, sb = diffusion_coefs(layers)
+    denoised = None
+    for time_i in range(layers):
+        t_index = layers - 1 - time_i
+        t = torch.full((bsz,), t_index, dtype=torch.long)
+        if time_i != 0:
+            cf[mask_inds, bs_inds] = sa[t_index] * denoised.clone().detach() + sb[t_index] * noise[0]
+        type_emb = sd[pre + "type_embedding.weight"][torch.zeros(max_len, bsz, dtype=torch.long)].clone()
+        type_emb[mask_inds, bs_inds] = sd[pre + "type_embedding.weight"][torch.ones(bsz, dtype=torch.long)]
+        h = cf + type_emb + temp_emb
+        tm = sinusoidal(t, hidden // 4)
+        tm = F.linear(tm, sd[pre + "time_mlp.1.weight"], sd[pre + "time_mlp.1.bias"])
+        tm = F.linear(F.gelu(tm), sd[pre + "time_mlp.3.weight"], sd[pre + "time_mlp.3.bias"])
+        h = h + tm[None, :, :]
+        out = stack(sd, pre + "temporalModelling.", h, layers, n_head)
+        denoised = out[mask_inds, bs_inds]
+        cf = orig.clone()
+        cf[mask_inds, bs_inds] = denoised
+    return cf[mask_inds, bs_inds]
+
+
+def vit_forward_forecast_eval(sd, x, label_emb, temp, depth, num_seg, max_len=9, order_layers=4):
+    """VisionTransformer.forward in eval mode with MODEL.NUM_SEG > 0 and MATCH_LANG_EMB (vit.py:292-307, 355-356)."""
+    x = rearrange(x, "b c (m t) h w -> (b m) c t h w", m=num_seg, t=x.shape[2] // num_seg)
+    feat = forward_features(sd, x, depth)
+    emb = l2n(F.linear(feat, sd["head.weight"], sd["head.bias"]))
+    z = l2n(order_tfm_forecast(sd, "order_tfm.", emb, num_seg, max_len, order_layers, 8))
+    return torch.softmax(z @ label_emb.t() / temp, dim=1)
+
+
 def vit_forward_train(sd, inputs, meta, label_emb, temp, depth, max_len, order_layers, text_layers, rng,
                       order_recog_batch=9, droppath=None):
     """VisionTransformer.forward in pre-training mode, vit.py:283-352 (ORDER_PRETRAIN_ENABLED, MATCH_LANG_EMB,

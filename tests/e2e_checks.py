@@ -230,6 +230,34 @@ def check_train_step_t4():
     return _hip_vs_oracle(1, 32, 64, 2, frames=4, seed=7, tag="T=4: ")
 
 
+def check_train_step_t32():
+    """T = 32 frames (BASELINE config 4 shape in time): temporal attention over 32-token sequences on the MFMA path."""
+    return _hip_vs_oracle(1, 32, 64, 1, frames=32, seed=9, tag="T=32: ")
+
+
+def check_forecast_eval_golden():
+    """Eval-mode zero-shot step forecasting (NUM_SEG = 8, order transformer's diffusion_signal_forecast) against the
+    reference's output probabilities (tests/golden/forecast.pt)."""
+    import test_oracle_golden as tg
+    f = load("forecast")
+    cfg = make_cfg(f["depth"], f["crop"], f["K"])
+    cfg.MODEL.NUM_SEG = 8
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "emb.pth")
+        torch.save(f["label_emb"], path)
+        cfg.DEV.TEST_LANG_EMB = path
+        cfg.TRAIN.LABEL_EMB = ""
+        from procedurevrl_amd.build import build_model
+        model = build_model(cfg, gpu_id=0)
+    model.load_state_dict(orc.seeded_state(tg.forecast_state(f), f["seed"]), strict=True)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        probs = model(f["x"].to(DEV))
+    return [("forecast eval probabilities vs reference", rel(probs, f["probs"]), 3e-2),
+            ("forecast eval argmax agreement (fraction differing)", float((probs.argmax(1).cpu() != f["probs"].argmax(1)).float().mean()), 0.0)]
+
+
 def check_full_size():
     """BASELINE config-2 shapes (224^2, 12 blocks, K = 9871).  The oracle handles 2 clips in seconds; the 32-clip
     batch is covered by a size-independent property: every clip's logits are independent of its batch-mates."""
@@ -254,4 +282,4 @@ def check_full_size():
 
 
 ALL_CHECKS = [check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
-              check_train_step_t4, check_full_size]
+              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_full_size]

@@ -247,6 +247,38 @@ def make_e2e(defaults, vit, tfm, out, tmpdir):
     out["features"] = dict(seed=31, x=inputs[0, :2].clone(), feat=feat)
 
 
+def make_forecast(defaults, vit, tfm, out, tmpdir):
+    """Zero-shot step forecasting in eval mode (vit.py:292-293, 302-307, 355-356 -> tfm_model.py:206-249): NUM_SEG = 8
+    observed clips per video, the 9th is denoised by the order transformer; output = softmax probabilities."""
+    depth, crop, K = 1, 32, 48
+    cfg = defaults.get_cfg()
+    cfg.MODEL.MODEL_NAME = "vit_base_patch16_224_develop"
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NUM_CLASSES = K
+    cfg.MODEL.DROP_PATH = 0.0
+    cfg.MODEL.NUM_SEG = 8
+    cfg.TIMESFORMER.DEPTH = depth
+    cfg.DATA.TRAIN_CROP_SIZE = crop
+    cfg.DATA.NUM_FRAMES = 8
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.NUM_GPUS = 0
+    g = torch.Generator().manual_seed(78)
+    label = torch.randn(K, 512, generator=g) * 0.38
+    label = label / label.norm(dim=1, keepdim=True)
+    path = os.path.join(tmpdir, "test_emb.pth")
+    torch.save(label, path)
+    cfg.DEV.TEST_LANG_EMB = path
+    model = vit.vit_base_patch16_224_develop(cfg)
+    sd = load_seeded(model, 51)
+    model.eval()
+    b = 2
+    x = torch.randn(b, 3, 8 * 8, crop, crop, generator=g)
+    with torch.no_grad():
+        probs = model(x)
+    out["forecast"] = dict(seed=51, depth=depth, crop=crop, K=K, x=x, label_emb=label, probs=probs, wsum=checksum(sd),
+                           state_keys=sorted(model.state_dict().keys()))
+
+
 def make_small_ops(vit, losses, out):
     g = torch.Generator().manual_seed(3)
     v = torch.randn(4, 16, generator=g); t = torch.randn(4 * 3, 16, generator=g)
@@ -299,6 +331,7 @@ def main():
         make_attention(vit, out)
         make_block(vit, out)
         make_e2e(defaults, vit, tfm, out, tmp)
+        make_forecast(defaults, vit, tfm, out, tmp)
     make_small_ops(vit, losses, out)
     make_lr_table(defaults, out)
     make_allgather(dist_mod, out)

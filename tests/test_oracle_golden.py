@@ -159,3 +159,21 @@ def test_lr_table():
         for ep, lr in zip(t["epochs"], t["lrs"]):
             assert abs(orc.lr_at_epoch(cfg, ep) - lr) < 1e-12
             assert abs(lr_policy.get_lr_at_epoch(cfg, ep) - lr) < 1e-12
+
+
+def forecast_state(f):
+    sh = orc.encoder_shapes(f["depth"], 8, (f["crop"] // 16) ** 2)
+    sh.update(orc_order_shapes())
+    return {"model." + k: v for k, v in sh.items()}
+
+
+def test_forecast_eval():
+    f = load("forecast")
+    shapes = forecast_state(f)
+    assert sorted(shapes.keys()) == f["state_keys"]
+    full = orc.seeded_state(shapes, f["seed"])
+    assert abs(checksum(full) - f["wsum"]) < 1e-6 * f["wsum"]
+    sd = {k[len("model."):]: v for k, v in full.items()}
+    with torch.no_grad():
+        probs = orc.vit_forward_forecast_eval(sd, f["x"], f["label_emb"], 0.02, f["depth"], 8)
+    assert rel(probs, f["probs"]) < 1e-4
