@@ -123,3 +123,30 @@ def test_order_transformer_draws_follow_reference_ranges():
         last = m + 1 == 9
         assert torch.all(p[last] == 9)                           # mask at the last position: nothing padded
         assert torch.all((p[~last] > m[~last]) & (p[~last] <= 8))  # randint(mask + 1, max_len)
+
+
+def test_test_meter_multi_view_ensemble():
+    """TestMeter semantics of the reference (lib/utils/meters.py:90-128,164-203): clip predictions of a video are summed
+    (or max-ed), labels recorded per video, top-k accuracy on the video level."""
+    from procedurevrl_amd.test_net import TestMeter
+    g = torch.Generator().manual_seed(0)
+    num_videos, num_clips, K = 6, 4, 10
+    preds = torch.rand(num_videos * num_clips, K, generator=g)
+    labels_v = torch.randint(0, K, (num_videos,), generator=g)
+    clip_ids = torch.randperm(num_videos * num_clips, generator=g)
+    labels = labels_v[clip_ids // num_clips]
+    for method in ("sum", "max"):
+        m = TestMeter(num_videos, num_clips, K, ensemble_method=method)
+        for lo in range(0, len(clip_ids), 5):                      # ragged batches
+            sl = slice(lo, lo + 5)
+            m.update_stats(preds[clip_ids][sl], labels[sl], clip_ids[sl])
+        ref = torch.zeros(num_videos, K)
+        for ind in range(len(clip_ids)):                           # the reference's per-clip loop
+            v = int(clip_ids[ind]) // num_clips
+            p = preds[clip_ids][ind]
+            ref[v] = ref[v] + p if method == "sum" else torch.max(ref[v], p)
+        assert torch.allclose(m.video_preds, ref, atol=1e-6)
+        assert torch.equal(m.video_labels, labels_v) and torch.all(m.clip_count == num_clips)
+        stats = m.finalize_metrics(ks=(1, 5))
+        top1 = (ref.argmax(1) == labels_v).float().mean().item() * 100
+        assert stats["top1_acc"] == "{:.2f}".format(top1)
