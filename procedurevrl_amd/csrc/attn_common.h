@@ -39,6 +39,13 @@ __device__ __forceinline__ int bl_off(int row, int col) {
   return (rb * 4 + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
 }
 
+// 8 consecutive columns (16-byte chunk `chunk` of 8) of one row, from the SAME blocked image: with the (cb ^ (rb & 1))
+// block swizzle the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots, so one LDS copy of a tile
+// serves both the row-wise (a-operand) and the transposed (ds_read_b64_tr_b16) fragment reads.
+__device__ __forceinline__ bf16x8 bl_row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + bl_off(row, chunk * 8));
+}
+
 __device__ __forceinline__ bf16x8 tr_frag8(const char* tile, int off0, int off1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off1));

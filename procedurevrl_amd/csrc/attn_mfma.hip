@@ -6,7 +6,8 @@
 // and nn.MultiheadAttention inside ResidualAttentionBlock (lib/models/tfm_model.py:32-53; key padding
 // mask) / the CLIP text tower (causal mask).  Backward = autograd of the same expression.
 //
-// One workgroup per (sequence, head).  The whole K and V head slices of a sequence fit in LDS
+// One workgroup (4 waves) per (sequence, head); every kernel keeps <= 57 KiB of LDS so two workgroups share a CU and
+// one's tile loads overlap the other's MFMA work.  The whole K and V head slices of a sequence fit in LDS
 // (197 x 64 bf16 = 25 KiB each), so softmax is exact single-pass (no online rescale) and the S x S
 // score matrix never exists in memory (the reference materialises 477 MB of it).
 // MFMA operands are arranged "swapped" (a = keys, b = queries) so that a lane owns ONE query and
@@ -93,17 +94,17 @@ __device__ __forceinline__ void load_tile(const bf16* base, long ld, int col0, c
 template <int NKT, bool GEN, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
-  constexpr int RM = NKT * 16 * 128, BL = NKS2 * 32 * 128;
-  __shared__ __attribute__((aligned(16))) char smem[RM + BL];
-  char* Kr = smem;
-  char* Vb = smem + RM;
+  constexpr int BL = NKS2 * 32 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BL];
+  char* Kb = smem;
+  char* Vb = smem + BL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, NKT * 16, nullptr, 0, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, nullptr, 0, Kb, NKS2 * 32, tid);
   load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, NKS2 * 32, tid);
   __syncthreads();
 
@@ -121,33 +122,39 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int krow = kt * 16 + i;
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
+      const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
+      const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
       sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
     }
+    // softmax over the lane's 4*NKT keys.  exp(scale*s - max) is evaluated as exp2(fma(s, c, -max*c)) with
+    // c = scale*log2(e) (one FMA + one v_exp per element); P stays un-normalised (<= 1) and the 16 output values are
+    // scaled by 1/sum instead of the 4*NKT probabilities.  Only tiles that can hold masked keys pay for the select.
+    const float c = p.scale * 1.4426950408889634f;
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * q4 + r;
-        bool msk = key >= S;
-        if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
-        const float v = msk ? -INFINITY : sc[kt][r] * p.scale;
-        sc[kt][r] = v;
-        mx = fmaxf(mx, v);
+        if (GEN || kt * 16 + 15 >= S) {
+          bool msk = key >= S;
+          if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
+          if (msk) sc[kt][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, sc[kt][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mref = (mx == -INFINITY) ? 0.f : mx;
+    const float mref = (mx == -INFINITY) ? 0.f : mx;      // raw-score maximum (scale > 0)
+    const float mc = mref * c;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(sc[kt][r] - mref);
+        const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c, -mc));
         sc[kt][r] = e;
         sum += e;
       }
@@ -163,8 +170,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
       bf16x8 pf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pf[r] = (bf16)(sc[2 * ks2][r] * inv);
-        if (2 * ks2 + 1 < NKT) pf[4 + r] = (bf16)(sc[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r] * inv);
+        pf[r] = (bf16)sc[2 * ks2][r];
+        if (2 * ks2 + 1 < NKT) pf[4 + r] = (bf16)sc[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r];
         else pf[4 + r] = (bf16)0.f;
       }
 #pragma unroll
@@ -179,10 +186,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16)oacc[dt][r];
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16)(oacc[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
       }
-      if (q4 == 0 && p.lse) p.lse[((long)seq * p.H + h) * S + query] = mref + __logf(sum);
+      if (q4 == 0 && p.lse) p.lse[((long)seq * p.H + h) * S + query] = mref * p.scale + __logf(sum);
     }
   }
 }
@@ -193,19 +200,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 template <int NKT, bool GEN, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
-  constexpr int RM = NKT * 16 * 128, BL = NKS2 * 32 * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * RM + BL];
-  char* Kr = smem;
-  char* Vr = smem + RM;
-  char* Kb = smem + 2 * RM;
+  constexpr int BL = NKS2 * 32 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BL];
+  char* Kb = smem;
+  char* Vb = smem + BL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, Kr, NKT * 16, Kb, NKS2 * 32, tid);
-  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, Vr, NKT * 16, nullptr, 0, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, nullptr, 0, Kb, NKS2 * 32, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, NKS2 * 32, tid);
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
@@ -229,17 +235,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
     const long stat = ((long)seq * p.H + h) * S + qj;
-    const float lse = p.lse[stat];
+    const float c = p.scale * 1.4426950408889634f;
+    const float lse2 = p.lse[stat] * 1.4426950408889634f;
+    const float dss = dsum * p.scale;
     if (q4 == 0 && query < S) p.dvec[stat] = dsum;
 
     f32x4 ds[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int krow = kt * 16 + i;
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, q4));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kr + rm_off(krow, 4 + q4));
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, q4));
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vr + rm_off(krow, 4 + q4));
+      const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
+      const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
+      const bf16x8 v0 = bl_row_frag(Vb, krow, q4);
+      const bf16x8 v1 = bl_row_frag(Vb, krow, 4 + q4);
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
       s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
@@ -249,10 +257,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * q4 + r;
-        bool msk = key >= S || query >= S;
-        if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
-        const float pr = msk ? 0.f : __expf(s[r] * p.scale - lse);
-        s[r] = pr * (dp[r] - dsum) * p.scale;
+        float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+        if (GEN || kt * 16 + 15 >= S || qt * 16 + 15 >= S) {
+          bool msk = key >= S || query >= S;
+          if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
+          if (msk) pr = 0.f;
+        }
+        s[r] = pr * fmaf(dp[r], p.scale, -dss);
       }
       ds[kt] = s;
     }
@@ -296,12 +307,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int ROWS = NKS2 * 32;
   constexpr int T = ROWS * 128;
-  __shared__ __attribute__((aligned(16))) char smem[4 * T + 2 * ROWS * 4];
-  char* Qr = smem;
-  char* Dr = smem + T;
-  char* Qb = smem + 2 * T;
-  char* Db = smem + 3 * T;
-  float* lse_s = reinterpret_cast<float*>(smem + 4 * T);
+  __shared__ __attribute__((aligned(16))) char smem[2 * T + 2 * ROWS * 4];
+  char* Qb = smem;
+  char* Db = smem + T;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * T);
   float* dv_s = lse_s + ROWS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,19 +318,20 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, h * 64, sr, S, nullptr, Qr, ROWS, Qb, ROWS, tid);
+  load_tile<64 * NW>(p.qkv, p.ld, h * 64, sr, S, nullptr, nullptr, 0, Qb, ROWS, tid);
   {
     const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
-    load_tile<64 * NW>(p.d_o, p.ldo, h * 64, sr, S, src0, Dr, ROWS, Db, ROWS, tid);
+    load_tile<64 * NW>(p.d_o, p.ldo, h * 64, sr, S, src0, nullptr, 0, Db, ROWS, tid);
     for (int idx = tid; idx < ROWS; idx += 64 * NW) {
       const long stat = ((long)seq * p.H + h) * S + idx;
-      lse_s[idx] = idx < S ? p.lse[stat] : 0.f;
-      dv_s[idx] = idx < S ? p.dvec[stat] : 0.f;
+      lse_s[idx] = idx < S ? p.lse[stat] * 1.4426950408889634f : 0.f;
+      dv_s[idx] = idx < S ? p.dvec[stat] * p.scale : 0.f;
     }
   }
   __syncthreads();
 
   const int q4 = lane >> 4, i = lane & 15;
+  const float c = p.scale * 1.4426950408889634f;
   const int nkt_rt = (S + 15) >> 4;
   for (int kt = wave; kt < nkt_rt; kt += NW) {
     const int key = kt * 16 + i;
@@ -344,10 +354,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qrow = (2 * u + half) * 16 + i;   // a-operand row: query
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Qr + rm_off(qrow, q4));
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Qr + rm_off(qrow, 4 + q4));
-        const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(Dr + rm_off(qrow, q4));
-        const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(Dr + rm_off(qrow, 4 + q4));
+        const bf16x8 a0 = bl_row_frag(Qb, qrow, q4);
+        const bf16x8 a1 = bl_row_frag(Qb, qrow, 4 + q4);
+        const bf16x8 d0 = bl_row_frag(Db, qrow, q4);
+        const bf16x8 d1 = bl_row_frag(Db, qrow, 4 + q4);
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf0, s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf1, s, 0, 0, 0);
@@ -356,16 +366,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf1, dp, 0, 0, 0);
         // s[r] = S[query = (2u+half)*16 + 4*q4 + r][key]
         const int qb = (2 * u + half) * 16 + 4 * q4;
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dv_s + qb);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);   // lse * log2(e)
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dv_s + qb);    // D * scale
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int query = qb + r;
           bool msk = query >= S || kbad;
           if constexpr (GEN) msk = msk || (p.causal && key > query);
-          const float pr = msk ? 0.f : __expf(s[r] * p.scale - l4[r]);
+          const float pr = msk ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[r]));
           pf[half * 4 + r] = (bf16)pr;
-          sf[half * 4 + r] = (bf16)(pr * (dp[r] - d4[r]) * p.scale);
+          sf[half * 4 + r] = (bf16)(pr * fmaf(dp[r], p.scale, -d4[r]));
         }
       }
 #pragma unroll

@@ -135,28 +135,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 }
 
 // out[j] = beta*out[j] + sum_b part[b][j]   (j over 2*C: dgamma then dbeta)
-// 32 columns per block, 8 row groups per column, LDS tree at the end.
+// 16 columns x 16 row groups per block (64-byte row segments), LDS tree at the end: 96 blocks for C = 768.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta,
                                                              float* __restrict__ out0, float* __restrict__ out1,
                                                              int half) {
-  __shared__ float red[8][33];
-  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + c;
-  float a = 0.f;
-  if (j < n)
-    for (int b = g; b < nblk; b += 8) a += part[(long)b * n + j];
-  red[g][c] = a;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (j < n) {
+    int b = g;
+    for (; b + 16 < nblk; b += 32) { a0 += part[(long)b * n + j]; a1 += part[(long)(b + 16) * n + j]; }
+    if (b < nblk) a0 += part[(long)b * n + j];
+  }
+  red[g][c] = a0 + a1;
   __syncthreads();
   if (g == 0 && j < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][c];
+    for (int k = 0; k < 16; ++k) t += red[k][c];
     float* o = (j < half) ? out0 + j : out1 + (j - half);
     *o = (beta != 0.f ? beta * *o : 0.f) + t;
   }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 1024;
+constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 }  // namespace
 
@@ -206,7 +209,7 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
   if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, s, part, nblk,
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, s, part, nblk,
                      (int)(2 * C), beta_acc, dgamma, dbeta, (int)C);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
