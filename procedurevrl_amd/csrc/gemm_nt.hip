@@ -256,6 +256,108 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 256x256 tile with EIGHT waves, each owning a 128(m) x 64(n) block (8 x 4 MFMA tiles, 128 accumulator VGPRs): 24
+// ds_read_b128 per 64 MFMAs instead of 32 per 64 for two 64x64 wave blocks, half as many waves meeting at each barrier.
+// Same LDS image, swizzles, staging (8 LDS-DMA instructions per wave and stage) and epilogue as gemm_nt_kernel.
+// MEASURED (same-process A/B, 50k-row shapes): within +-8 % of the 16-wave kernel (faster on the HBM-bound fp32-residual
+// epilogue, 450 vs 432 TFLOP/s; slower on K = 3072, 955 vs 1040) -- no net win, kept behind benchmark knob 5.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_w128_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int PER = (BM + BN) / 8 / NW;   // 8
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int GM = 8;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16* gsrc[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int it = wave * PER + j;
+    const int pc = lane & 7;
+    if (it < BM / 8) {
+      const int row = it * 8 + (lane >> 3);
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+    } else {
+      const int row = (it - BM / 8) * 8 + (lane >> 3);
+      gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
+    }
+  }
+  auto stage = [&](int buf, int k0) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);
+  };
+
+  int xoff[8], woff[4];
+  {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int rx = wm * 128 + t * 16 + i;
+      xoff[t] = rx * 128 + ((q ^ swz_x(rx)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = XBYTES + rw * 128 + ((q ^ swz_w<F32OUT>(rw)) << 4);
+    }
+  }
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[hh][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* b = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[8], wf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(b + (woff[t] ^ (ks << 6)));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(b + (xoff[t] ^ (ks << 6)));
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt >> 2][mt & 3][nt] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt >> 2][mt & 3][nt], 0, 0, 0);
+    }
+  }
+  nt_epilogue<EPI>(p, acc[0], m0, n0, 2 * wm, wn, lane);
+  nt_epilogue<EPI>(p, acc[1], m0, n0, 2 * wm + 1, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Deep-pipelined variant for the 256x256 tile: BK = 32 stages (32 KiB each) in a 4-deep LDS ring, LDS-DMA issued
 // THREE stages ahead, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so that loads stay in flight across barriers.
 // (`__syncthreads()` drains vmcnt(0) whenever an LDS-DMA is pending.)  MEASURED on MI355X (tools/bench_kernels.py, same-
@@ -429,9 +531,20 @@ int launch_pipe(GemmNT p, hipStream_t s) {
 }
 
 template <int EPI>
+int launch_w128(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / 256;
+  p.tiles_m = cdiv(p.M, 256);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_w128_kernel<EPI>), dim3(p.nwg), dim3(512), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   int t = g_force_tile;
   if (t == 4 && p.N % 256 == 0) return launch_pipe<EPI>(p, s);
+  if (t == 5 && p.N % 256 == 0) return launch_w128<EPI>(p, s);
   if (t == 0) t = (p.M >= 4096 && p.N % 256 == 0) ? 3 : (p.M >= 2048 ? 2 : 1);
   if (t == 3 && p.N % 256) t = 2;
   // (cutting the ragged last wave of 256x256 tiles off into a 128x128-tile launch was measured 12 % SLOWER:
