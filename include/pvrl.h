@@ -62,14 +62,16 @@ int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, in
 
 /* LayerNorm over fp32 rows, C in {512, 768} (vit.py:104,109,116,228 eps 1e-6; tfm_model.py:18-24 eps 1e-5).
  * fwd: y = (x - mean) * rstd * gamma + beta  -> bf16 (GEMM operand) or fp32.
- * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows. */
+ * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows; optionally also writes
+ *      dxs_bf16[m] = bf16(dxs_scale[m] * dx_out[m]) for m < dxs_rows (the next stage's bf16 GEMM operand, DropPath-scaled). */
 int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                        int64_t ldy, int out_is_f32, float* mean, float* rstd, int64_t M, int64_t C, void* stream);
 int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C);
 int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dx_in, int64_t ldi, float* dx_out,
                        int64_t ldo, float beta_acc, float* dgamma, float* dbeta, void* workspace,
-                       int64_t workspace_bytes, int64_t M, int64_t C, void* stream);
+                       int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16, int64_t ldxs, const float* dxs_scale,
+                       int64_t dxs_rows, void* stream);
 
 /* Temporal attention for T = 8 (Block.forward temporal branch, vit.py:129-135 via Attention.forward
  * vit.py:75-92): sequences are 8 consecutive rows of the packed qkv [rows][3*H*64]. */

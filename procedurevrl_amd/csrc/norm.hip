@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      long ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dx_in, long ldi, float* __restrict__ dx_out,
-                                                     long ldo, float* __restrict__ part, int M) {
+                                                     long ldo, float* __restrict__ part, int M, bf16* __restrict__ dxs,
+                                                     long ldxs, const float* __restrict__ dxs_scale, int dxs_rows) {
   constexpr int NV = C / 256;
   __shared__ float red[4][2][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,6 +117,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
       for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - c1 - xh[j][e] * c2);
       if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + (long)row * ldi + c);
       *reinterpret_cast<f32x4*>(dx_out + (long)row * ldo + c) = o;
+      if (dxs && row < dxs_rows) {   // bf16 (optionally DropPath-scaled) copy: the GEMM operand of the next backward stage
+        const float sc = dxs_scale ? dxs_scale[row] : 1.f;
+        Vec4IO<bf16>::store(dxs + (long)row * ldxs + c, sc * o);
+      }
     }
   }
 #pragma unroll
@@ -191,21 +196,25 @@ extern "C" int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C) {
 extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
                                   const float* mean, const float* rstd, const float* gamma, const float* dx_in,
                                   int64_t ldi, float* dx_out, int64_t ldo, float beta_acc, float* dgamma, float* dbeta,
-                                  void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* stream) {
+                                  void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16,
+                                  int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, void* stream) {
   if (M <= 0) return PVRL_OK;
   if (!dy || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta || !workspace) return PVRL_EINVAL;
   if ((ldx % 4) || (lddy % 4) || (ldo % 4) || (dx_in && (ldi % 4))) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_layernorm_bwd_workspace_bytes(M, C)) return PVRL_EINVAL;
+  if (dxs_bf16 && (ldxs % 4)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = cdiv(M, 4) < LN_BWD_MAX_BLOCKS ? cdiv(M, 4) : LN_BWD_MAX_BLOCKS;
   float* part = (float*)workspace;
 #define LN_BWD(CC)                                                                                                   \
   if (dy_is_f32)                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, float>), dim3(nblk), dim3(256), 0, s, (const float*)dy, (long)lddy, x,      \
-                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M);              \
+                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
+                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows);                                         \
   else                                                                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)dy, (long)lddy, x,        \
-                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M);
+                       (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
+                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows);
   if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();

@@ -271,14 +271,20 @@ class EncoderEngine:
         ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
                           dx_out=dx[R:], beta_acc=bg)
 
-        for i in range(len(m.blocks) - 1, -1, -1):
-            self._block_bwd(m.blocks[i], sv["blocks"][i], sv, dx, gs)
+        # dy = bf16(DropPath-scale * dx) is the operand of each block's first backward GEMMs; after the first block it is
+        # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
+        last = len(m.blocks) - 1
+        s3 = sv["blocks"][last]["dp"]["s3_all"] if sv["blocks"][last]["dp"] else None
+        dy = ops.cast_scale(dx, s3)
+        for i in range(last, -1, -1):
+            nxt = sv["blocks"][i - 1]["dp"] if i > 0 else None
+            dy = self._block_bwd(m.blocks[i], sv["blocks"][i], sv, dx, gs, dy, i > 0, nxt)
             sv["blocks"][i] = None  # free activations as we go
             if self.grad_hook is not None:
                 self.grad_hook(i)   # block i's parameter gradients are final: the reducer may start its all-reduce
 
         # ---- embedding prologue + patch embed (vit.py:174-180, 370-407) ----
-        dz = ops.cast_scale(dx[:R], None)
+        dz = dy[:R]     # block 0's last LayerNorm backward emitted the unscaled bf16 copy of dx[:R]
         w = m.patch_embed.proj.weight
         (dw, bw), (dbias, _) = gs.target(w), gs.target(m.patch_embed.proj.bias)
         self._wgrad(dz, sv["a_pe"], dw.view(C, -1), dbias, bw)
@@ -304,7 +310,7 @@ class EncoderEngine:
         else:
             tgt.add_(g.view_as(tgt))
 
-    def _block_bwd(self, blk, s, sv, dx, gs):
+    def _block_bwd(self, blk, s, sv, dx, gs, dy, has_prev, prev_dp):
         L = lib()
         B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
         C, H = self.C, self.H
@@ -320,22 +326,21 @@ class EncoderEngine:
             (dw, bw), (dbias, _) = gs.target(lin.weight), gs.target(lin.bias)
             self._wgrad(dy, xin, dw, dbias, bw)
 
-        def lnbwd(dh, x, st, ln, dx_in, dx_out):
+        def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None):
             (dg, bg), (db, _) = gs.target(ln.weight), gs.target(ln.bias)
-            ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg)
+            ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg,
+                              dxs=dxs, dxs_scale=dxs_scale)
 
-        # ---- MLP ----
-        dy = ops.cast_scale(dx, s3_all)
+        # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
         wgrad(dy, s["g"], blk.mlp.fc2)
         du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
         wgrad(du, s["h_m"], blk.mlp.fc1)
         dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
         del du
-        lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx)
+        dps = torch.empty((R + B * T, C), device=dev, dtype=BF16)
+        lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx, dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
 
         # ---- spatial ----
-        dps = torch.empty((R + B * T, C), device=dev, dtype=BF16)
-        ops.cast_scale(dx[:R], s2_tok, out=dps[:R])
         ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
         wgrad(dps, s["o_s"], blk.attn.proj)
         do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
@@ -346,10 +351,10 @@ class EncoderEngine:
         wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
         dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
         del dqkv, do, dps
-        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx)
+        dz = torch.empty((R, C), device=dev, dtype=BF16)
+        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz)                            # also emits bf16(dx[:R])
 
         # ---- temporal (rows [0, R); cls rows pass straight through) ----
-        dz = ops.cast_scale(dx[:R], None)
         wgrad(dz, s["p_t"], blk.temporal_fc)
         dpt = ops.gemm_nt(dz, self._weight(blk.temporal_fc.weight).t, L.PVRL_EPI_BF16, rowscale=s1_tok)
         wgrad(dpt, s["o_t"], blk.temporal_attn.proj)
@@ -360,4 +365,11 @@ class EncoderEngine:
             dqkv_t, _ = ops.attn_bwd(s["qkv_t"], s["o_t"], None, dot, None, s["lse_t"], B * N, T, H, self.scale, mode=0)
         wgrad(dqkv_t, s["h_t"], blk.temporal_attn.qkv)
         dh = ops.gemm_nt(dqkv_t, self._weight(blk.temporal_attn.qkv.weight).t, L.PVRL_EPI_BF16)
-        lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R])
+        # the block's input gradient is final after this kernel: it also emits the bf16 operand of the next stage
+        # (previous block's MLP backward with that block's DropPath scale, or the patch-embed weight gradient)
+        s3p = prev_dp["s3_all"] if (has_prev and prev_dp) else None
+        dy_next = torch.empty((M if has_prev else R, C), device=dev, dtype=BF16)
+        lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R], dxs=dy_next[:R], dxs_scale=s3p)
+        if has_prev:
+            ops.cast_scale(dx[R:], s3p[R:] if s3p is not None else None, out=dy_next[R:])
+        return dy_next

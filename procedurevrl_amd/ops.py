@@ -165,7 +165,8 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=BF16, out=None, save_stats=True
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0, dxs=None, dxs_scale=None):
+    """`dxs` (optional bf16 [rows <= M, C]) additionally receives bf16(dxs_scale[m] * dx_out[m])."""
     L = lib()
     _chk2d(dy); _chk2d(x, F32)
     M, C = x.shape
@@ -175,7 +176,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
     ws = workspace(nbytes, x.device, "ln")
     L.call("pvrl_layernorm_bwd", _ptr(dy), _ld(dy), 1 if dy.dtype == F32 else 0, _ptr(x), _ld(x), _ptr(mean),
            _ptr(rstd), _ptr(gamma), _ptr(dx_in), _ld(dx_in) if dx_in is not None else 0, _ptr(dx_out), _ld(dx_out),
-           float(beta_acc), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _stream())
+           float(beta_acc), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _ptr(dxs),
+           _ld(dxs) if dxs is not None else 0, _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _stream())
     return dx_out
 
 

@@ -95,8 +95,10 @@ def check_block_golden():
     gs = vt.grad_store()
     for p in vt.parameters():
         p.grad = None
+    from procedurevrl_amd import ops
     dx = to_rows(f["dy"]).to(DEV).clone()
-    eng._block_bwd(vt.blocks[0], sv["blocks"][0], sv, dx, gs)
+    eng._block_bwd(vt.blocks[0], sv["blocks"][0], sv, dx, gs, ops.cast_scale(dx, None), False, None)
+    eng.join_side_stream()
     out.append(("block bwd dx vs reference", rel(from_rows(dx, B), f["dx"]), TOL_GRAD))
     named = dict(vt.blocks[0].named_parameters())
     for k, g in f["grads"].items():

@@ -212,6 +212,11 @@ def check_layernorm():
         F.layer_norm(xr, (C,), gam, bet, eps).backward(dyb)
         dx = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg, db)
         out.append((f"ln_bwd dx (bf16 dy) {M}x{C}", rel(dx, xr.grad), TOL_F32))
+        rows = M - 5
+        sc = torch.rand(M, generator=g) + 0.5
+        dxs = torch.zeros(rows, C, device=dev(), dtype=BF)
+        dx2 = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg, db, dxs=dxs, dxs_scale=sc.to(dev()))
+        out.append((f"ln_bwd fused bf16 scaled copy {M}x{C}", rel(dxs, (sc[:, None] * dx2.cpu())[:rows]), 5e-3))
     return out
 
 
