@@ -104,6 +104,8 @@ int pvrl_batch_sum(const float* dx, int64_t ld, int64_t B, int64_t rows, int64_t
 int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* rowscale, void* out, int64_t ldo, int64_t M,
                          int64_t C, void* stream);
 int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, int64_t C, void* stream);
+/* both bf16 operand copies of an fp32 weight [R, C] in one pass: out [R, C] and (optional) out_t [C, R]. */
+int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream);
 /* cls-token bookkeeping of the spatial branch (vit.py:139-141,147-149):
  * out[g] = resid[g] + alpha * sum_t scale[g*G+t] * in[g*G+t];   out[g*G+t] = alpha*scale[g*G+t]*in[g]. */
 int pvrl_group_reduce(const void* in, int in_is_f32, int64_t ldi, int64_t groups, int64_t G, int64_t C,

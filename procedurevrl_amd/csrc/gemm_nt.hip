@@ -466,44 +466,60 @@ __global__ __launch_bounds__(1024) void gemm_nt_pipe_kernel(GemmNT p) {
 // HBM-bound on B (label_emb: 9871 x 512 fp32 = 20 MB): each workgroup streams 16
 // rows of B once, coalesced, against up to 64 rows of A held in LDS.
 // ---------------------------------------------------------------------------
-constexpr int SG_NB = 16, SG_MB = 64, SG_KB = 128;
+// 64x64 output tile, 32-deep K chunks, 4x4 outputs per thread from k-major LDS tiles (float4 reads); optional split-K
+// over grid.z with fp32 atomics (the logits backward has M = 32, N = 512, K = 9871: 8 output tiles only).
+constexpr int SG_T = 64, SG_K = 32, SG_LD = 68;
 __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __restrict__ A, long lda,
                                                              const float* __restrict__ B, long ldb,
                                                              const float* __restrict__ bias, float alpha,
-                                                             float* __restrict__ C, long ldc, int M, int N, int K) {
-  __shared__ float sa[SG_MB][SG_KB + 1];
-  __shared__ float sb[SG_NB][SG_KB + 1];
+                                                             float* __restrict__ C, long ldc, int M, int N, int K,
+                                                             int kchunk) {
+  __shared__ __attribute__((aligned(16))) float sa[SG_K][SG_LD];
+  __shared__ __attribute__((aligned(16))) float sb[SG_K][SG_LD];
   const int tid = threadIdx.x;
-  const int n0 = blockIdx.x * SG_NB, m0 = blockIdx.y * SG_MB;
-  const int tn = tid & 15, tmr = tid >> 4;  // thread: column n0+tn, rows m0 + tmr + 16*r
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += SG_KB) {
-    for (int idx = tid; idx < SG_MB * SG_KB; idx += 256) {
-      const int r = idx / SG_KB, c = idx - r * SG_KB;
-      const int m = m0 + r, k = k0 + c;
-      sa[r][c] = (m < M && k < K) ? A[(long)m * lda + k] : 0.f;
+  const int n0 = blockIdx.x * SG_T, m0 = blockIdx.y * SG_T;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int tx = tid & 15, ty = tid >> 4;
+  const int lrow = tid >> 2, lk = (tid & 3) * 8;      // loader: one tile row, 8 consecutive k
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += SG_K) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + lk + e;
+      va[e] = (m0 + lrow < M && k < kend) ? A[(long)(m0 + lrow) * lda + k] : 0.f;
+      vb[e] = (n0 + lrow < N && k < kend) ? B[(long)(n0 + lrow) * ldb + k] : 0.f;
     }
-    for (int idx = tid; idx < SG_NB * SG_KB; idx += 256) {
-      const int r = idx / SG_KB, c = idx - r * SG_KB;
-      const int n = n0 + r, k = k0 + c;
-      sb[r][c] = (n < N && k < K) ? B[(long)n * ldb + k] : 0.f;
-    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sa[lk + e][lrow] = va[e]; sb[lk + e][lrow] = vb[e]; }
     __syncthreads();
 #pragma unroll 8
-    for (int c = 0; c < SG_KB; ++c) {
-      const float b = sb[tn][c];
+    for (int k = 0; k < SG_K; ++k) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sa[k][ty * 4]);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sb[k][tx * 4]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = fmaf(sa[tmr + 16 * r][c], b, acc[r]);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
     }
-    __syncthreads();
   }
-  const int n = n0 + tn;
-  if (n < N) {
-    const float bb = bias ? bias[n] : 0.f;
+  const bool split = gridDim.z > 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + tmr + 16 * r;
-      if (m < M) C[(long)m * ldc + n] = alpha * acc[r] + bb;
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = alpha * acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
+      if (split) atomicAdd(&C[(long)m * ldc + n], v);
+      else C[(long)m * ldc + n] = v;
     }
   }
 }
@@ -595,9 +611,23 @@ extern "C" int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* 
                                       void* stream) {
   if (M <= 0 || N <= 0) return PVRL_OK;
   if (!A || !B || !C || K <= 0) return PVRL_EINVAL;
-  dim3 grid(cdiv(N, SG_NB), cdiv(M, SG_MB));
+  const int tiles = cdiv(N, SG_T) * cdiv(M, SG_T);
+  int splits = 1;
+  if (tiles < 128 && K >= 512) {           // few output tiles and a long reduction: split K over grid.z
+    splits = 256 / tiles;
+    const int maxs = (int)(K / 128);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int kchunk = cdiv(cdiv(K, splits), SG_K) * SG_K;
+  splits = cdiv(K, kchunk);
+  if (splits > 1) {
+    if (ldc != N) return PVRL_EINVAL;       // split-K accumulates into a zero-filled contiguous C
+    if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PVRL_EHIP;
+  }
+  dim3 grid(cdiv(N, SG_T), cdiv(M, SG_T), splits);
   hipLaunchKernelGGL(gemm_f32_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (long)lda, B, (long)ldb,
-                     bias, alpha, C, (long)ldc, (int)M, (int)N, (int)K);
+                     bias, alpha, C, (long)ldc, (int)M, (int)N, (int)K, kchunk);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

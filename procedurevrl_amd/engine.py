@@ -91,10 +91,11 @@ class EncoderEngine:
             self._w[id(p)] = e
         ver = (p._version, getattr(self.m, "weights_epoch", 0), p.data_ptr())
         if e.ver != ver or e.w is None or e.w.device != p.device:
-            w2 = p.detach().reshape(p.shape[0], -1)
-            e.w = ops.cast_scale(w2, None, out=e.w if e.w is not None and e.w.device == p.device else None)
+            w2 = p.detach().reshape(p.shape[0], -1).contiguous()
+            same = e.w is not None and e.w.device == p.device
+            e.w, t = ops.cast_weight(w2, out=e.w if same else None, out_t=e.t if same else None, need_t=need_t)
             if need_t:
-                e.t = ops.cast_transpose(w2.contiguous(), out=e.t if e.t is not None and e.t.device == p.device else None)
+                e.t = t
             e.ver = ver
         return e
 

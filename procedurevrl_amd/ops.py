@@ -293,6 +293,19 @@ def cast_transpose(w, out=None):
     return out
 
 
+def cast_weight(w, out=None, out_t=None, need_t=True):
+    """fp32 [R, C] -> (bf16 [R, C], bf16 [C, R] or None) in one kernel."""
+    L = lib()
+    assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous()
+    R, C = w.shape
+    if out is None:
+        out = torch.empty((R, C), device=w.device, dtype=BF16)
+    if need_t and out_t is None:
+        out_t = torch.empty((C, R), device=w.device, dtype=BF16)
+    L.call("pvrl_cast_weight_bf16", _ptr(w), _ptr(out), _ptr(out_t) if need_t else None, R, C, _stream())
+    return out, (out_t if need_t else None)
+
+
 def group_reduce(x, groups, G, scale=None, alpha=1.0, resid=None, out=None, out_dtype=F32):
     L = lib()
     _chk2d(x)

@@ -132,7 +132,7 @@ def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
     out = []
-    for (M, N, K) in [(32, 9871, 512), (104, 1000, 512), (5, 512, 768), (512, 40, 32)]:
+    for (M, N, K) in [(32, 9871, 512), (104, 1000, 512), (5, 512, 768), (512, 40, 32), (32, 512, 9871), (26, 768, 3000)]:
         A = torch.randn(M, K, generator=g)
         B = torch.randn(N, K, generator=g)
         bias = torch.randn(N, generator=g)
@@ -354,6 +354,9 @@ def check_elementwise():
     w = torch.randn(300, 130, generator=g)
     wt = ops.cast_transpose(w.to(dev()))
     out.append(("cast_transpose", rel(wt, w.t()), 5e-3))
+    wb, wtt = ops.cast_weight(w.to(dev()))
+    out.append(("cast_weight bf16", rel(wb, w), 5e-3))
+    out.append(("cast_weight transposed", rel(wtt, w.t()), 5e-3))
     groups, Gs = 5, 8
     xin = torch.randn(groups * Gs, C, generator=g)
     sc = torch.rand(groups * Gs, generator=g)

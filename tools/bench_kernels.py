@@ -102,6 +102,12 @@ def main():
         tn_case(f"tn[{tg}] wfc2  768x3072", M, 768, 3072)
     L.call("pvrl_debug_set_gemm_tn_tile", 0)
 
+    if want("f32"):
+        a = rnd(32, 512); lab = rnd(9871, 512); labt = lab.t().contiguous(); dyl = rnd(32, 9871)
+        us = timeit(lambda: ops.gemm_nt_f32(a, lab, alpha=50.0)); rows.append(("f32 logits fwd 32x9871x512", us, 2.0 * 32 * 9871 * 512 / us / 1e6))
+        us = timeit(lambda: ops.gemm_nt_f32(dyl, labt, alpha=50.0)); rows.append(("f32 logits bwd 32x512x9871", us, 2.0 * 32 * 9871 * 512 / us / 1e6))
+        f = rnd(32, 768); wh = rnd(512, 768)
+        us = timeit(lambda: ops.gemm_nt_f32(f, wh)); rows.append(("f32 head 32x512x768", us, 2.0 * 32 * 512 * 768 / us / 1e6))
     if want("attn"):
         H = 12
         qkv = rnd(M, 3 * C).to(BF)
