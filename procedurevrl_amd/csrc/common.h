@@ -33,6 +33,20 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// The same copy issued as raw ISA: wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset, LDS base in M0.
+// The compiler does not see an LDS write here, so it does not drain vmcnt(0) in front of later LDS reads: callers
+// order the copy against their reads themselves (counted `s_waitcnt vmcnt(N)` + `s_barrier`).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_raw(const void* uniform_base, unsigned lane_off, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(lane_off), "s"(uniform_base), "s"(lds_wave_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -26,6 +26,7 @@ struct GemmTN {
   float* part;   // [splits][N][K]
   float* cpart;  // [splits][N] or null
   const bf16* zero_page;  // 256 zero bytes (source of out-of-range rows for the LDS-DMA path)
+  int npairs, Ms_pairs;   // rt kernel: (slice, tile) pairs in total / per XCD
 };
 
 constexpr int TM = 64;   // reduction rows per pipeline stage (two K=32 MFMA steps)
@@ -454,6 +455,361 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_w128_kernel(GemmTN p) {
   }
 }
 
+// 256(n) x 256(k) tile, FOUR waves (2 x 2), each wave a 128 x 128 block of dW = 8 x 8 MFMA tiles = 256 accumulator
+// registers (one wave per SIMD, 512-register budget).  Per K=32 step a wave issues 32 transposing reads for 64 MFMAs --
+// half the LDS read bytes per FLOP of the 64x64 wave block, which is what bounds the kernels above (ds_read_b64_tr_b16
+// streams at half the LDS rate).  Staging is a 4-deep ring of 32-row stages (32 KiB each) filled by LDS-DMA three
+// stages ahead with counted vmcnt + raw s_barrier; the fragments of step s+1 are read while the MFMAs of step s run.
+// Requires M % 64 == 0 (token matrices: 1568 rows per clip, so an even clip count): every slice is an even number of
+// whole stages.
+__global__ __launch_bounds__(256, 1) void gemm_tn_ring_kernel(GemmTN p) {
+  constexpr int TS = 32, NB = 16, NS = 4;
+  constexpr int OPB = (TS / 4) * NB * 128;                 // 16 KiB per operand and stage
+  constexpr int STAGE = 2 * OPB;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = (j / p.tiles_nk) * 8 + xcd;
+  const int rem = j % p.tiles_nk;
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int nsteps = (mend - mbeg) / TS;
+
+  // Staging: waves 0,1 copy P (row blocks 0-3 / 4-7 of the stage), waves 2,3 copy Q; 8 LDS-DMA instructions per wave and
+  // stage, instruction e = row block (e>>1) of the wave's four, 256-byte half (e&1).  Address = uniform base (SGPR)
+  // + 32-bit lane offset; the column-block swizzle (row blocks 2,3 of every four) only changes the lane offset.
+  const bool isq = wave >= 2;
+  const long ld = isq ? p.ldq : p.ldp;
+  const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + ((long)mbeg + (wave & 1) * 16) * ld * 2;
+  unsigned loff[2];
+  {
+    const int r = (lane >> 1) & 3, h = lane & 1, c = lane >> 3;
+    loff[0] = (unsigned)(r * ld * 2 + (c * 16 + h * 8) * 2);
+    loff[1] = (unsigned)(r * ld * 2 + ((c ^ 1) * 16 + h * 8) * 2);
+  }
+  const int dbase = (isq ? OPB : 0) + (wave & 1) * 4 * (NB * 128);
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  auto stage = [&](int st, int buf) {
+    const int sc = st < nsteps ? st : nsteps - 1;            // surplus ring slots re-load the last stage (never read)
+    const char* g = ubase + (long)sc * TS * ld * 2;
+    const unsigned b = smem_base + buf * STAGE + dbase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      glds16_raw(g + (long)(e >> 1) * 4 * ld * 2 + (e & 1) * 256, loff[(e >> 2) & 1], b + (e >> 1) * (NB * 128) + (e & 1) * 1024);
+  };
+
+  // fragment addresses: lane (i, q) reads row blocks 2q (h=0) and 2q+1 (h=1) of column block t ^ (q&1):
+  // even t -> base + (q&1)*128 + t*128, odd t -> base - (q&1)*128 + t*128  (t*128 becomes the instruction offset)
+  const int q = lane >> 4, i = lane & 15;
+  int pb[2][2], qb[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rb = 2 * q + h;
+    const int sw = (q & 1) * 128;
+    pb[h][0] = (rb * NB + wn * 8) * 128 + i * 8 + sw;
+    pb[h][1] = (rb * NB + wn * 8) * 128 + i * 8 - sw;
+    qb[h][0] = OPB + (rb * NB + wk * 8) * 128 + i * 8 + sw;
+    qb[h][1] = OPB + (rb * NB + wk * 8) * 128 + i * 8 - sw;
+  }
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of P: one extra MFMA per P fragment against a fragment of ones (rows of D all equal)
+  f32x4 cacc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) cacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  // P fragments: ONE set, refreshed in place for step s+1 as soon as their row of MFMAs of step s has issued;
+  // Q fragments: two sets (all eight are live for the whole step).
+  bf16x8 pf[8], qfa[8], qfb[8];
+  auto step = [&](const bf16x8* qc, bf16x8* qn, const char* b) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc[kt], pf[nt], acc[nt][kt], 0, 0, 0);
+      pf[nt] = tr_frag(b + nt * 128, pb[0][nt & 1], pb[1][nt & 1]);
+      qn[nt] = tr_frag(b + nt * 128, qb[0][nt & 1], qb[1][nt & 1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    }
+  };
+  auto colsum = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) cacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[nt], cacc[nt], 0, 0, 0);
+  };
+
+  if (nsteps > 0) {     // nsteps is even (M % 64 == 0 and Ms % 64 == 0)
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      pf[t] = tr_frag(smem + t * 128, pb[0][t & 1], pb[1][t & 1]);
+      qfa[t] = tr_frag(smem + t * 128, qb[0][t & 1], qb[1][t & 1]);
+    }
+    // sub-step: wait until the next stage has landed (this wave's loads of the one after stay in flight), barrier (all
+    // waves' parts landed; everyone has finished reading the ring slot about to be refilled), refill it, then run the
+    // 64 MFMAs of this step while fetching the fragments of the next one.
+    for (int st = 0; st < nsteps; st += 2) {
+      const int hb = ((st >> 1) & 1) * 2;                     // ring slot of stage st: 0 or 2
+      if (do_csum) colsum();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage(st + 3, (hb + 3) & 3);
+      step(qfa, qfb, smem + (hb + 1) * STAGE);
+      if (do_csum) colsum();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage(st + 4, hb);
+      step(qfb, qfa, smem + (hb ^ 2) * STAGE);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int n = n0 + wn * 128 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const int k = k0 + wk * 128 + kt * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
+    }
+  }
+  if (do_csum && q == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = cacc[t][0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register-transposed staging ("rt"): measured on MI355X (tools/probe/lds_rate.hip) ds_read_b64_tr_b16 streams at
+// 110-170 B/ns/CU against 245-435 B/ns/CU for ds_read_b128, so every kernel above is bound by its transposing reads.
+// Here the transpose happens ONCE per element on the way in: each lane loads an 8(m) x 8(col) bf16 block as eight
+// 16-byte row segments (32 lanes cover a 512-byte tile row), transposes it inside its own registers with 32
+// v_perm_b32, and writes eight 16-byte [col][8 m] chunks; MFMA fragments are then plain ds_read_b128.
+// Tile 256(n) x 256(k), four waves of 128 x 128 (256 accumulator registers, one wave per SIMD), 32-row stages,
+// two LDS slots (64 KiB), global loads two steps ahead in two 32-register sets, one barrier per step; all of it
+// (32 fragment reads, 32 perms, 8 LDS writes, 8 global loads) is interleaved into the step's 64 MFMAs.
+// LDS image per operand and stage: chunk (g = m/8, col c) at ((g*16 + c/16)*16 + slot)*16 B with
+// slot = (c & 8) | ((c & 7) ^ (c/8 & 7)).  ds_read_b128 is served in lane groups {0-3,12-15,20-27}, ... with 64 banks:
+// such a group reads slots {0-7} of one 256-byte window and {8-15} of another -> conflict-free; ds_write_b128 is
+// served 8 consecutive lanes at a time with 32 banks: the 8 lanes hold 8 different (c/8 & 7) -> 8 different slots.
+// Any M: the last stage of the last slice is loaded row-clamped and zero-filled.
+__global__ __launch_bounds__(256, 1) void gemm_tn_rt_kernel(GemmTN p) {
+  constexpr int TS = 32;
+  constexpr int OPB = 4 * 256 * 16;                        // 16 KiB per operand and stage
+  constexpr int STAGE = 2 * OPB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  int s, rem;
+  {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int pair = xcd * p.Ms_pairs + jj;                // (slice, tile) pairs in slice-major order, one chunk per XCD
+    if (jj >= p.Ms_pairs || pair >= p.npairs) return;
+    s = pair / p.tiles_nk;
+    rem = pair - s * p.tiles_nk;
+  }
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int rows = mend - mbeg;
+  const int nsteps = (((rows + TS - 1) / TS) + 1) & ~1;    // stages, rounded up to even (the surplus one is all zeros)
+  if (rows <= 0) {                                         // empty slice: its partial tile must still be zero
+    float* part = p.part + (long)s * p.N * p.K;
+    const int q = lane >> 4, i = lane & 15;
+    for (int nt = 0; nt < 8; ++nt)
+      for (int kt = 0; kt < 8; ++kt)
+        *reinterpret_cast<f32x4*>(part + (long)(n0 + wn * 128 + nt * 16 + i) * p.K + k0 + wk * 128 + kt * 16 + 4 * q) =
+            (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.cpart && tk == 0 && wk == 0 && q == 0)
+      for (int t = 0; t < 8; ++t) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = 0.f;
+    return;
+  }
+
+  // staging role: waves 0,1 bring P rows [16 w, 16 w + 16) of the stage, waves 2,3 the same rows of Q
+  const bool isq = wave >= 2;
+  const long ld2 = (isq ? p.ldq : p.ldp) * 2;              // row pitch in bytes
+  const int rg = lane >> 5, cg = lane & 31;
+  const int g = 2 * (wave & 1) + rg;                       // 8-row block of the stage
+  const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + (long)mbeg * ld2;
+  const unsigned loff = (unsigned)(8 * g * ld2 + cg * 16);
+  const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
+  auto gload = [&](u32x4* r, int st) {
+    if ((st + 1) * TS <= rows) {                           // whole stage (uniform branch; every stage but the last)
+      const char* b = ubase + (long)st * TS * ld2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const u32x4*>(b + e * ld2 + loff);
+    } else {                                               // ragged or surplus stage: clamp the row, zero what is outside
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = st * TS + 8 * g + e;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (long)min(row, rows - 1) * ld2 + cg * 16);
+        const unsigned keep = row < rows ? 0xffffffffu : 0u;   // mask, not a branch: keeps the loads unconditional
+        r[e] = v & (u32x4){keep, keep, keep, keep};
+      }
+    }
+  };
+  auto twrite = [&](const u32x4* r, int j, char* slot) {   // column j of the lane's 8: gather its 8 m, store 16 B
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      o[d] = __builtin_amdgcn_perm(r[2 * d + 1][j >> 1], r[2 * d][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+    *reinterpret_cast<u32x4*>(slot + (wr ^ (j << 4))) = o;
+  };
+
+  const int q = lane >> 4, i = lane & 15;
+  int prd[8], qrd[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int slot = (i & 8) | ((i & 7) ^ ((2 * t + (i >> 3)) & 7));
+    prd[t] = wn * 2048 + q * 4096 + (slot << 4);
+    qrd[t] = OPB + wk * 2048 + q * 4096 + (slot << 4);
+  }
+  auto rfrag = [&](const char* slot, int off, int t) {
+    return *reinterpret_cast<const bf16x8*>(slot + off + t * 256);
+  };
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of P, taken from the P fragments with v_dot2_f32_bf16 against (1, 1)
+  float cacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+  bf16x2 ones2;
+  ones2[0] = (bf16)1.0f; ones2[1] = (bf16)1.0f;
+
+  // P fragments 0-6 live in ONE register set, refreshed in place for the next stage right after their row of MFMAs;
+  // P fragment 7 and all Q fragments are double-buffered, so the last LDS operation of a step is issued after row 6 and
+  // row 7 (128 MFMA clocks) covers its latency in front of the barrier.
+  bf16x8 pf[7], pa[1], pb[1], qfa[8], qfb[8];
+  u32x4 ra[8], rb[8];
+  // one step: MFMAs of stage st (qc, pf, pc) | fragments of stage st+1 from `rs` | transpose registers r -> slot `ws`
+  auto step = [&](const bf16x8* qc, bf16x8* qn, const bf16x8* pc, bf16x8* pn, const char* rs, const u32x4* r, char* ws) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc[kt], nt < 7 ? pf[nt] : pc[0], acc[nt][kt], 0, 0, 0);
+      if (nt < 4) {
+        qn[2 * nt] = rfrag(rs, qrd[2 * nt], 2 * nt);
+        qn[2 * nt + 1] = rfrag(rs, qrd[2 * nt + 1], 2 * nt + 1);
+        pf[nt] = rfrag(rs, prd[nt], nt);
+        twrite(r, nt, ws);
+      } else if (nt < 6) {
+        pf[nt] = rfrag(rs, prd[nt], nt);
+        if (nt == 4) pn[0] = rfrag(rs, prd[7], 7);
+        twrite(r, 2 * nt - 4, ws);
+        twrite(r, 2 * nt - 3, ws);
+      } else if (nt == 6) {
+        pf[6] = rfrag(rs, prd[6], 6);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 LDS reads
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 perms
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 LDS write
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  };
+  auto colsum = [&](const bf16x8* pc) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const bf16x8 f = nt < 7 ? pf[nt] : pc[0];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        cacc[nt] = __builtin_amdgcn_fdot2_f32_bf16((bf16x2){f[2 * d], f[2 * d + 1]}, ones2, cacc[nt], false);
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  char* slot0 = smem;
+  char* slot1 = smem + STAGE;
+  gload(ra, 0);
+  gload(rb, 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) twrite(ra, j, slot0);
+  gload(ra, 2);
+  lds_barrier();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) pf[t] = rfrag(slot0, prd[t], t);
+    else pa[0] = rfrag(slot0, prd[t], t);
+    qfa[t] = rfrag(slot0, qrd[t], t);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) twrite(rb, j, slot1);
+  gload(rb, 3);
+  // invariant at the top of step st (even): slot (st+1)%2 holds stage st+1 (written during step st-1), ra holds stage
+  // st+2, rb stage st+3 (both possibly still in flight), pf/qfa hold the fragments of stage st.
+  for (int st = 0; st < nsteps; st += 2) {
+    if (do_csum) colsum(pa);
+    lds_barrier();
+    step(qfa, qfb, pa, pb, slot1, ra, slot0);
+    gload(ra, st + 4);
+    if (do_csum) colsum(pb);
+    lds_barrier();
+    step(qfb, qfa, pb, pa, slot0, rb, slot1);
+    gload(rb, st + 5);
+  }
+
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int n = n0 + wn * 128 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const int k = k0 + wk * 128 + kt * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) = acc[nt][kt];
+    }
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v = cacc[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = v;
+    }
+  }
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -490,8 +846,10 @@ extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t sp
 extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
                                  int64_t K, int64_t splits, float beta, float* dW, float* dbias, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 8 || (splits % 8) || M < 0)
+  if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
     return PVRL_EINVAL;
+  const bool use_rt = g_tn_tile == 6 && (N % 256 == 0) && (K % 256 == 0);
+  if (!use_rt && (splits < 8 || (splits % 8))) return PVRL_EINVAL;   // slice s lives on XCD s % 8 in those kernels
   if ((ldp % 8) || (ldq % 8) || ((uintptr_t)P % 16) || ((uintptr_t)Q % 16)) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_gemm_tn_workspace_bytes(N, K, splits)) return PVRL_EINVAL;
   GemmTN p;
@@ -504,11 +862,20 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   hipStream_t s = (hipStream_t)stream;
   char* zp = (char*)workspace + splits * (N * K + N) * (int64_t)sizeof(float);
   p.zero_page = (const bf16*)zp;
-  if (hipMemsetAsync(zp, 0, 256, s) != hipSuccess) return PVRL_EHIP;
   // the 256x256 / 16-wave instantiation is register-starved at 128 VGPRs (spills; 2-3x slower on MI355X) and is
   // only reachable through the benchmark knob
   const bool big = g_tn_tile == 3 && (N % 256 == 0) && (K % 256 == 0);
-  if (g_tn_tile == 4 && (N % 256 == 0) && (K % 256 == 0)) {
+  if (use_rt) {
+    p.tiles_k = (int)(K / 256);
+    p.tiles_nk = (int)(N / 256) * p.tiles_k;
+    p.npairs = (int)splits * p.tiles_nk;
+    p.Ms_pairs = cdiv(p.npairs, 8);
+    hipLaunchKernelGGL(gemm_tn_rt_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
+  } else if (g_tn_tile == 5 && (N % 256 == 0) && (K % 256 == 0) && (M % 64 == 0)) {
+    p.tiles_k = (int)(K / 256);
+    p.tiles_nk = (int)(N / 256) * p.tiles_k;
+    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
+  } else if (g_tn_tile == 4 && (N % 256 == 0) && (K % 256 == 0)) {
     p.tiles_k = (int)(K / 256);
     p.tiles_nk = (int)(N / 256) * p.tiles_k;
     hipLaunchKernelGGL(gemm_tn_w128_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(512), 0, s, p);
@@ -522,9 +889,10 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
     // measured on MI355X (tools/bench_kernels.py, same process A/B): register staging 505-585 TFLOP/s, LDS-DMA
     // staging 485-550: the kernel is bound by the half-rate ds_read_b64_tr_b16 stream (32 per wave and stage),
     // not by the staging path, so the register-staged form stays the default; knob 2 selects the LDS-DMA form.
-    if (g_tn_tile == 2)
+    if (g_tn_tile == 2) {
+      if (hipMemsetAsync(zp, 0, 256, s) != hipSuccess) return PVRL_EHIP;   // LDS-DMA source for out-of-range rows
       hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
-    else
+    } else
       hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3((unsigned)(splits * p.tiles_nk)), dim3(256), 0, s, p);
   }
   PVRL_LAUNCH_CHECK();

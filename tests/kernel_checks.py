@@ -176,6 +176,17 @@ def check_gemm_tn_variants():
             ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, splits=16)
             out.append((f"gemm_tn[{name}] dW", rel(dW, ref), 1e-4))
             out.append((f"gemm_tn[{name}] dbias", rel(db, bf(P).sum(0)), 1e-4))
+        # the 4-wave 256x256 kernels need M % 64 == 0; slices of 2, 4, ... stages and empty slices
+        for knob, name in ((5, "ring"), (6, "rt")):
+            L.call("pvrl_debug_set_gemm_tn_tile", knob)
+            for (M2, N2, K2, sp) in [(1152, 512, 256, 8), (4160, 256, 768, 16), (128, 256, 256, 8), (6400, 768, 768, 32),
+                                     (3200, 768, 256, 9 if knob == 6 else 8)] + ([(1111, 512, 256, 5), (1569, 256, 256, 3), (40, 256, 512, 4)] if knob == 6 else []):
+                P2 = torch.randn(M2, N2, generator=g); Q2 = torch.randn(M2, K2, generator=g)
+                ref2 = bf(P2).t() @ bf(Q2)
+                dW = torch.zeros(N2, K2, device=dev()); db = torch.zeros(N2, device=dev())
+                ops.gemm_tn(P2.to(dev(), BF), Q2.to(dev(), BF), dW, db, splits=sp)
+                out.append((f"gemm_tn[{name}] dW {M2}x{N2}x{K2} s={sp}", rel(dW, ref2), 1e-4))
+                out.append((f"gemm_tn[{name}] dbias {M2}x{N2}x{K2}", rel(db, bf(P2).sum(0)), 1e-4))
     finally:
         L.call("pvrl_debug_set_gemm_tn_tile", 0)
     return out
