@@ -53,8 +53,12 @@ int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t 
 
 /* Weight gradient dW[N,K] = beta*dW + P[M,N]^T . Q[M,K]; dbias[N] = beta*dbias + colsum(P) (optional).
  * Backward of nn.Linear / the patch-embed conv (loss.backward(), tools/train_net.py:176-181).
- * N % 128 == 0, K % 128 == 0, splits a positive multiple of 8 (one slice of M per XCD).
+ * N % 128 == 0, K % 128 == 0.  M is cut into `splits` slices whose fp32 partial tiles a second kernel sums
+ * (deterministic, no atomics): take splits = pvrl_gemm_tn_plan_splits(M, N, K) (the count that fills the 256 CUs
+ * for the kernel the shape selects: N, K multiples of 256 -> 256x256 register-transposed kernel, any splits >= 1;
+ * otherwise the 128x128 kernel, splits a positive multiple of 8 = one slice per XCD).
  * workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
+int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K);
 int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
 int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,

@@ -833,11 +833,38 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
-int g_tn_tile = 0;   // 0/1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 (benchmark knob)
+// 0 = heuristic (register-transposed 256x256 kernel when N and K are multiples of 256, else 128x128 register-staged),
+// 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 / 16 waves, 4 = 256x256 / 8 waves,
+// 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed (benchmark / test knob)
+int g_tn_tile = 0;
+
+bool tn_use_rt(int64_t N, int64_t K) {
+  return (g_tn_tile == 0 || g_tn_tile == 6) && (N % 256 == 0) && (K % 256 == 0);
+}
 
 }  // namespace
 
 extern "C" int pvrl_debug_set_gemm_tn_tile(int tile) { g_tn_tile = tile; return PVRL_OK; }
+
+extern "C" int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0 || (N % 128) || (K % 128)) return PVRL_EINVAL;
+  if (tn_use_rt(N, K)) {
+    // one workgroup per CU and ONE round: as many (slice, tile) pairs as fit the 256 CUs, slices of >= 64 rows
+    const int64_t tiles = (N / 256) * (K / 256);
+    int64_t s = 256 / tiles;
+    const int64_t smax = M / 64;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+  }
+  // 128x128 kernels: a multiple of 8 (slice s lives on XCD s % 8), enough (n, k) tiles x slices to fill
+  // 8 XCDs x 64 resident workgroups about twice, but at least ~256 rows per slice
+  const int64_t tiles = (N / 128) * (K / 128);
+  int64_t per_xcd = cdiv(128, tiles);
+  if (per_xcd < 1) per_xcd = 1;
+  int64_t s = 8 * per_xcd;
+  while (s > 8 && M / s < 256) s -= 8;
+  return s;
+}
 
 extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits) {
   return splits * (N * K + N) * (int64_t)sizeof(float) + 256;   // + a zero page for out-of-range rows
@@ -848,7 +875,7 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
                                  int64_t workspace_bytes, void* stream) {
   if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
     return PVRL_EINVAL;
-  const bool use_rt = g_tn_tile == 6 && (N % 256 == 0) && (K % 256 == 0);
+  const bool use_rt = tn_use_rt(N, K);
   if (!use_rt && (splits < 8 || (splits % 8))) return PVRL_EINVAL;   // slice s lives on XCD s % 8 in those kernels
   if ((ldp % 8) || (ldq % 8) || ((uintptr_t)P % 16) || ((uintptr_t)Q % 16)) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_gemm_tn_workspace_bytes(N, K, splits)) return PVRL_EINVAL;

@@ -122,14 +122,8 @@ def workspace(nbytes, device, tag="default"):
 
 
 def tn_splits(M, N, K):
-    """Slices of M for the weight-gradient GEMM: a multiple of 8 (one XCD per slice), enough (n, k) tiles x slices
-    to fill 8 XCDs x 64 resident workgroups about twice, but at least ~256 rows per slice."""
-    tiles = (N // 128) * (K // 128)
-    per_xcd = max(1, -(-128 // tiles))          # slices per XCD so that slices*tiles >= 128 per XCD
-    s = 8 * per_xcd
-    while s > 8 and M // s < 256:
-        s -= 8
-    return s
+    """Slices of M for the weight-gradient GEMM (the C side owns the rule: it depends on which kernel the shape selects)."""
+    return lib().call("pvrl_gemm_tn_plan_splits", M, N, K)
 
 
 def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):

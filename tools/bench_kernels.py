@@ -86,23 +86,19 @@ def main():
             return
         P = rnd(M_, N_).to(BF); Q = rnd(M_, K_).to(BF)
         dW = torch.zeros(N_, K_, device=DEV); db = torch.zeros(N_, device=DEV)
-        if splits == 0:      # one round: as many (slice, tile) pairs as CUs
-            splits = max(1, 256 // ((N_ // 256) * (K_ // 256)))
-        if "256x256" in name and splits is None:
-            tiles = (N_ // 256) * (K_ // 256)
-            splits = 8 * max(1, -(-48 // tiles))
+        if splits is None:
+            splits = ops.tn_splits(M_, N_, K_)
         us = timeit(lambda: ops.gemm_tn(P, Q, dW, db, splits=splits))
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    for tile in (1, 6, 1, 6):
+    for tile in (1, 0, 1, 0):
         L.call("pvrl_debug_set_gemm_tn_tile", tile)
-        tg = {1: "128 regs", 4: "256x256 w128", 5: "256x256 ring", 6: "256x256 rt"}[tile]
-        for sp in ((None,) if tile == 1 else (0, 16, 24)):
-            tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768, sp)
-            tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768, sp)
-            tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768, sp)
-            tn_case(f"tn[{tg}] wfc2  768x3072", M, 768, 3072, sp)
+        tg = {1: "128x128 tr-read", 0: "default"}[tile]
+        tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
+        tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
+        tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
+        tn_case(f"tn[{tg}] wfc2  768x3072", M, 768, 3072)
     L.call("pvrl_debug_set_gemm_tn_tile", 0)
 
     if want("f32"):
