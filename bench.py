@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--classes", type=int, default=9871)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
     args = ap.parse_args()
 
     import torch
@@ -81,6 +82,8 @@ def main():
             torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
         torch.nn.init.trunc_normal_(vt.time_embed, std=0.02)
     model.train()
+    if args.no_wgrad_overlap:
+        vt.engine.overlap_wgrad = False
     optimizer = construct_optimizer(model, cfg)
     set_lr(optimizer, cfg.SOLVER.BASE_LR)
     optimizer.grad_scale = 1.0 / world
@@ -160,14 +163,14 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_b_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
-    path = os.path.join(ROOT, "profiles", "r1_b_traffic.json")
+    (profiles/r1_d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r1_d_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
     epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
     if kernel.startswith("gemm_tn"):
-        keys = [k for k in t if k.startswith("gemm_tn_kernel") or k.startswith("tn_reduce_kernel")]
+        keys = [k for k in t if k.startswith("gemm_tn_") or k.startswith("tn_reduce_kernel")]
     else:
         e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
         keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]
