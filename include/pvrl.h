@@ -100,6 +100,14 @@ int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t 
 /* PatchEmbed im2col: frames fp32 [B,3,T,HI,WI] -> bf16 rows (b, n, t) x (c, py, px) (vit.py:174-180,396). */
 int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t HI, int64_t WI, void* out, int64_t ldo,
                   void* stream);
+/* GPU-side input pipeline fused into the im2col: decoded uint8 frames [B,T,H0,W0,3] -> normalise ((v/255 - mean)/std),
+ * short-side rescale to (new_h, new_w) (bilinear, align_corners=False), crop at (y_off, x_off), optional horizontal
+ * flip -> bf16 patch rows of the crop x crop clip (same layout as pvrl_patchify).  Replaces the CPU-worker chain
+ * lib/datasets/howto100m.py:437-452 -> utils.py:110-160,309-326 -> transform.py:8-147; the random draws stay on the
+ * host (params int32 [B][5] = {new_h, new_w, y_off, x_off, flip}; mean3/std3 are HOST pointers to 3 floats). */
+int pvrl_frames_u8_patchify(const void* frames, const int32_t* params, int64_t B, int64_t T, int64_t H0, int64_t W0,
+                            int64_t crop, const float* mean3, const float* std3, void* out, int64_t ldo,
+                            void* stream);
 /* E[n*T+t] = bias + pos_embed[1+n] + time_embed[t]  (vit.py:370-407), and its batch-summed gradient. */
 int pvrl_embed_table(const float* pos, const float* time, const float* bias, float* E, int64_t N, int64_t T, int64_t C,
                      void* stream);

@@ -138,6 +138,31 @@ def forward_features(sd, x, depth, num_heads=12, droppath=None):
     return x[:, 0]
 
 
+def input_pipeline(frames_u8, params, mean, std, crop):
+    """CPU-worker input chain for ONE clip given its draws: tensor_normalize (lib/datasets/utils.py:309-326), 'T H W C ->
+    C T H W' (howto100m.py:439), bilinear short-side rescale with align_corners=False (transform.py:52-61), crop
+    (transform.py:109-111 / 184-186), horizontal flip (transform.py:142-143).
+    frames_u8 [T, H0, W0, 3] uint8, params = (new_h, new_w, y_off, x_off, flip) -> fp32 [3, T, crop, crop]."""
+    new_h, new_w, y_off, x_off, flip = [int(v) for v in params]
+    x = frames_u8.float() / 255.0
+    x = (x - torch.tensor(mean)) / torch.tensor(std)
+    x = x.permute(3, 0, 1, 2)
+    if (new_h, new_w) != tuple(x.shape[2:]):
+        x = F.interpolate(x, size=(new_h, new_w), mode="bilinear", align_corners=False)
+    x = x[:, :, y_off:y_off + crop, x_off:x_off + crop]
+    if flip:
+        x = x.flip((-1))
+    return x.contiguous()
+
+
+def patch_rows(x):
+    """fp32 clip(s) [B, 3, T, H, W] -> im2col rows ordered (b, n, t) x (c, py, px): the operand of PatchEmbed's
+    16x16/16 conv (vit.py:172-180) in the token order of vit.py:396."""
+    B, C, T, H, W = x.shape
+    p = x.reshape(B, C, T, H // 16, 16, W // 16, 16).permute(0, 3, 5, 2, 1, 4, 6)
+    return p.reshape(B * (H // 16) * (W // 16) * T, C * 256)
+
+
 def l2n(x):
     return x / x.norm(dim=1, keepdim=True)
 

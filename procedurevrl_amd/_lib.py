@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so")
 
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
-    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
+    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}

@@ -36,6 +36,59 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// GPU-side input pipeline fused into the patch-embed im2col (reference: CPU workers run tensor_normalize ->
+// permute -> random_short_side_scale_jitter (bilinear, align_corners=False) -> crop -> horizontal flip,
+// lib/datasets/howto100m.py:437-452, lib/datasets/utils.py:110-160,309-326, lib/datasets/transform.py:8-147).
+// frames uint8 [B][T][H0][W0][3] (decoder order) ; prm int32 [B][5] = {new_h, new_w, y_off, x_off, flip}
+//   ->  out bf16 [(b, n, t)][c*256 + py*16 + px] of the (crop x crop) clip, normalised (v/255 - mean)/std.
+// One thread = 8 consecutive output pixels of one row, all 3 channels (interleaved source bytes are read once).
+__global__ __launch_bounds__(256) void frames_u8_patchify_kernel(const unsigned char* __restrict__ frames,
+                                                                 const int* __restrict__ prm, bf16* __restrict__ out,
+                                                                 int B, int T, int H0, int W0, int crop, float m0,
+                                                                 float m1, float m2, float s0, float s1, float s2,
+                                                                 long ldo) {
+  const int xg = crop >> 3, PW = crop >> 4;
+  const long total = (long)B * T * crop * xg;
+  const float mean[3] = {m0, m1, m2}, istd[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    long r = idx;
+    const int x8 = (int)(r % xg); r /= xg;
+    const int y = (int)(r % crop); r /= crop;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const int* q = prm + b * 5;
+    const int nh = q[0], nw = q[1], yo = q[2], xo = q[3], flip = q[4];
+    const float sy = (float)H0 / (float)nh, sx = (float)W0 / (float)nw;
+    float fy = sy * ((float)(y + yo) + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H0 - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const unsigned char* f0 = frames + (((long)b * T + t) * H0 + y0) * W0 * 3;
+    const unsigned char* f1 = frames + (((long)b * T + t) * H0 + y1) * W0 * 3;
+    bf16x8 o[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int x = x8 * 8 + e;
+      const int X = (flip ? crop - 1 - x : x) + xo;
+      float fx = sx * ((float)X + 0.5f) - 0.5f;
+      fx = fx < 0.f ? 0.f : fx;
+      const int x0 = (int)fx, x1 = x0 + (x0 < W0 - 1 ? 1 : 0);
+      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = ly0 * (lx0 * (float)f0[x0 * 3 + c] + lx1 * (float)f0[x1 * 3 + c]) +
+                        ly1 * (lx0 * (float)f1[x0 * 3 + c] + lx1 * (float)f1[x1 * 3 + c]);
+        o[c][e] = (bf16)((v / 255.0f - mean[c]) * istd[c]);
+      }
+    }
+    const int n = (y >> 4) * PW + (x8 >> 1);
+    const long row = ((long)b * (crop >> 4) * PW + n) * T + t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *reinterpret_cast<bf16x8*>(out + row * ldo + c * 256 + (y & 15) * 16 + (x8 & 1) * 8) = o[c];
+  }
+}
+
 // E[n*T + t][c] = bias[c] + pos[1 + n][c] + time[t][c]
 __global__ __launch_bounds__(256) void embed_table_kernel(const float* __restrict__ pos, const float* __restrict__ time,
                                                           const float* __restrict__ bias, float* __restrict__ E, int N,
@@ -175,6 +228,22 @@ extern "C" int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t 
   const long total = B * 3 * T * HI * (WI >> 3);
   hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out,
                      (int)B, (int)T, (int)HI, (int)WI, (long)ldo);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_frames_u8_patchify(const void* frames, const int32_t* params, int64_t B, int64_t T, int64_t H0,
+                                       int64_t W0, int64_t crop, const float* mean3, const float* std3, void* out,
+                                       int64_t ldo, void* stream) {
+  if (B <= 0) return PVRL_OK;
+  if (!frames || !params || !mean3 || !std3 || !out || crop <= 0 || (crop % 16) || (ldo % 8) || ldo < 768 || H0 <= 0 ||
+      W0 <= 0)
+    return PVRL_EINVAL;
+  if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return PVRL_EINVAL;
+  const long total = B * T * crop * (crop >> 3);
+  hipLaunchKernelGGL(frames_u8_patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)frames, (const int*)params, (bf16*)out, (int)B, (int)T, (int)H0, (int)W0,
+                     (int)crop, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (long)ldo);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

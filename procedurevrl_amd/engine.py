@@ -20,6 +20,7 @@ import torch
 
 from . import ops
 from ._lib import lib
+from .transform import DecodedClips
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -168,7 +169,7 @@ class EncoderEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, frames, training, droppath=None, save=True):
-        """frames fp32 [B, 3, T, H, W] on the GPU -> (feat fp32 [B, C] = norm(x)[:, 0]).
+        """frames fp32 [B, 3, T, H, W] on the GPU (or transform.DecodedClips) -> (feat fp32 [B, C] = norm(x)[:, 0]).
         `droppath`: optional list (per block) of dicts from expand_droppath, to pin the RNG draws."""
         L = lib()
         m = self.m
@@ -181,7 +182,10 @@ class EncoderEngine:
         dev = frames.device
         sv = dict(B=B, T=T, N=N, R=R, M=M, Wp=Wp, blocks=[])
 
-        a_pe = ops.patchify(frames.contiguous())
+        if isinstance(frames, DecodedClips):     # decoded uint8 clips: GPU-side normalise/rescale/crop/flip + im2col
+            a_pe = ops.frames_u8_patchify(frames)
+        else:
+            a_pe = ops.patchify(frames.contiguous())
         pos, tim = self._pos_time(N, T, Wp)
         E = ops.embed_table(pos, tim, m.patch_embed.proj.bias.detach(), N, T)
         x = torch.empty((M, C), device=dev, dtype=F32)

@@ -250,6 +250,28 @@ def patchify(frames, out=None):
     return out
 
 
+def frames_u8_patchify(clips, out=None):
+    """transform.DecodedClips (uint8 [B,T,H0,W0,3] + per-clip draws) -> bf16 [(b,n,t), 768] of the normalised,
+    rescaled, cropped, flipped clip (the reference's CPU-worker chain, fused into the im2col)."""
+    import ctypes
+    L = lib()
+    fr = clips.frames
+    assert fr.is_cuda and fr.dtype == torch.uint8 and fr.is_contiguous()
+    B, T, H0, W0, _ = fr.shape
+    crop = clips.crop
+    ph = clips.params_host
+    if bool(((ph[:, 0] - ph[:, 2]) < crop).any()) or bool(((ph[:, 1] - ph[:, 3]) < crop).any()) or bool((ph[:, 2:4] < 0).any()):
+        raise ValueError("crop window leaves the rescaled frame")
+    rows = B * (crop // 16) * (crop // 16) * T
+    if out is None:
+        out = torch.empty((rows, 768), device=fr.device, dtype=BF16)
+    mean = (ctypes.c_float * 3)(*clips.mean)
+    std = (ctypes.c_float * 3)(*clips.std)
+    L.call("pvrl_frames_u8_patchify", _ptr(fr), _ptr(clips.params), B, T, H0, W0, crop,
+           ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std, ctypes.c_void_p), _ptr(out), _ld(out), _stream())
+    return out
+
+
 def embed_table(pos, time, bias, N, T):
     L = lib()
     C = pos.shape[-1]

@@ -283,5 +283,41 @@ def check_full_size():
     return out
 
 
-ALL_CHECKS = [check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
+def check_decoded_clips_train_step():
+    """The model fed decoded uint8 clips (GPU-side normalise / rescale / crop / flip fused into the im2col) gives the
+    logits and gradients of the same model fed the fp32 tensor the reference's CPU workers would have produced."""
+    import numpy as np
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    from procedurevrl_amd.transform import DecodedClips, spatial_sampling_params
+    g = torch.Generator().manual_seed(21)
+    B, T, H0, W0, crop, K = 3, 8, 40, 56, 32, 64
+    cfg = make_cfg(2, crop, K)
+    model = build(cfg, synthetic_label_emb(K, 512, seed=1)).to(DEV).train()
+    with torch.no_grad():
+        for blk in model.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    fr = torch.randint(0, 256, (B, T, H0, W0, 3), generator=g, dtype=torch.uint8)
+    np.random.seed(3)
+    prms = [spatial_sampling_params(H0, W0, -1, 36, 48, crop) for _ in range(B)]
+    mean, std = cfg.DATA.MEAN, cfg.DATA.STD
+    x32 = torch.stack([orc.input_pipeline(fr[b], prms[b], mean, std, crop) for b in range(B)]).to(DEV)
+    teacher = torch.randn(B, K, generator=g).to(DEV) * 3
+    res = []
+    for inp in (x32, DecodedClips(fr.to(DEV), prms, mean, std, crop)):
+        model.zero_grad(set_to_none=True)
+        pred = model(inp)
+        kl_topk_loss(pred, teacher, 5).backward()
+        model.model.adopt_grads()
+        res.append((pred.detach().clone(), model.model.patch_embed.proj.weight.grad.detach().clone(),
+                    model.model.blocks[0].attn.qkv.weight.grad.detach().clone()))
+    # the two patch matrices differ in 0.014 % of their bf16 values by one ulp (kernel_checks.check_input_pipeline);
+    # a random-init network at temperature 0.02 turns that into 2-4e-3 on logits / gradients (observed), the same
+    # sensitivity the bf16 datapath shows everywhere else -> same 1e-2 tolerance as the other end-to-end checks
+    return [("decoded-clips logits vs fp32-pipeline logits", rel(res[1][0], res[0][0]), 1e-2),
+            ("decoded-clips d patch_embed.weight", rel(res[1][1], res[0][1]), 1e-2),
+            ("decoded-clips d blocks.0.attn.qkv.weight", rel(res[1][2], res[0][2]), 1e-2)]
+
+
+ALL_CHECKS = [check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
               check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_full_size]

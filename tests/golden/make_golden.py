@@ -323,8 +323,42 @@ def make_lr_table(defaults, out):
     out["lr_table"] = tab
 
 
+def make_input_pipeline(out):
+    """The CPU-worker chain of howto100m.py:437-452 (tensor_normalize -> permute -> spatial_sampling) on random uint8
+    frames, for train (random scale / crop / flip, np.random seeded) and test (uniform crop) modes."""
+    import numpy as np
+    m = types.ModuleType("lib.datasets"); m.__path__ = [os.path.join(REF, "lib", "datasets")]
+    sys.modules["lib.datasets"] = m
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    fio = types.ModuleType("fvcore.common.file_io"); fio.PathManager = object
+    sys.modules["fvcore.common.file_io"] = fio
+    dutils = importlib.import_module("lib.datasets.utils")
+    cases = []
+    g = torch.Generator().manual_seed(77)
+    for (T, H0, W0, mn, mx, crop, sidx, flip, inv, seed) in [
+            (2, 40, 56, 36, 48, 32, -1, True, False, 1), (2, 56, 40, 36, 48, 32, -1, True, True, 2),
+            (3, 48, 64, 32, 32, 32, 1, False, False, 3), (2, 64, 48, 32, 32, 32, 2, False, False, 4),
+            (2, 32, 32, 32, 32, 32, -1, True, False, 5), (2, 40, 72, 48, 64, 48, -1, True, False, 6)]:
+        fr = torch.randint(0, 256, (T, H0, W0, 3), generator=g, dtype=torch.uint8)
+        np.random.seed(seed)
+        x = dutils.tensor_normalize(fr, [0.45, 0.45, 0.45], [0.225, 0.225, 0.225])
+        x = x.permute(3, 0, 1, 2)
+        x = dutils.spatial_sampling(x, spatial_idx=sidx, min_scale=mn, max_scale=mx, crop_size=crop,
+                                    random_horizontal_flip=flip, inverse_uniform_sampling=inv)
+        cases.append(dict(frames=fr, T=T, H0=H0, W0=W0, min_scale=mn, max_scale=mx, crop=crop, spatial_idx=sidx,
+                          flip=flip, inv=inv, seed=seed, out=x.contiguous()))
+    out["input_pipeline"] = dict(cases=cases, mean=[0.45] * 3, std=[0.225] * 3)
+
+
 def main():
     import tempfile
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "input_pipeline":
+        _install_stubs()
+        out = {}
+        make_input_pipeline(out)
+        torch.save(out["input_pipeline"], os.path.join(HERE, "input_pipeline.pt"))
+        print("wrote input_pipeline", os.path.getsize(os.path.join(HERE, "input_pipeline.pt")) // 1024, "KiB")
+        return
     defaults, vit, tfm, dist_mod, losses = import_reference()
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -335,6 +369,7 @@ def main():
     make_small_ops(vit, losses, out)
     make_lr_table(defaults, out)
     make_allgather(dist_mod, out)
+    make_input_pipeline(out)
     for k, v in out.items():
         torch.save(v, os.path.join(HERE, k + ".pt"))
         print("wrote", k, os.path.getsize(os.path.join(HERE, k + ".pt")) // 1024, "KiB")

@@ -440,5 +440,42 @@ def check_loss():
     return out
 
 
-ALL_CHECKS = [check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
+def check_input_pipeline():
+    """pvrl_frames_u8_patchify (normalise + bilinear rescale + crop + flip + im2col on decoded uint8 clips) against
+    (a) the REFERENCE's own CPU chain (tests/golden/input_pipeline.pt) and (b) the oracle on a ragged random batch.
+    Output is bf16: 1 bf16 ulp (2^-8 relative) on the few values whose fp32 result sits on a rounding boundary."""
+    import os
+    import numpy as np
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.transform import DecodedClips, spatial_sampling_params
+    from oracle import timesformer_oracle as orc
+    out = []
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "input_pipeline.pt"), weights_only=False)
+
+    def cmp(name, got, ref):
+        ref_b = ref.to(BF).float()
+        d = (got.float().cpu() - ref_b).abs()
+        ulp = ref_b.abs().clamp_min(2.0 ** -10) * 2.0 ** -7
+        out.append((name + " max err / bf16 ulp", float((d / ulp).max()), 1.01))
+        out.append((name + " fraction not bit-equal", float((d > 0).float().mean()), 2e-2))
+
+    for i, c in enumerate(gold["cases"]):
+        np.random.seed(c["seed"])
+        prm = spatial_sampling_params(c["H0"], c["W0"], c["spatial_idx"], c["min_scale"], c["max_scale"], c["crop"],
+                                      c["flip"], c["inv"])
+        clips = DecodedClips(c["frames"].unsqueeze(0).to(dev()), [prm], gold["mean"], gold["std"], c["crop"])
+        got = ops.frames_u8_patchify(clips)
+        cmp(f"u8 pipeline vs reference case {i}", got, orc.patch_rows(c["out"].unsqueeze(0)))
+    g = torch.Generator().manual_seed(5)
+    B, T, H0, W0, crop = 5, 3, 72, 100, 64
+    fr = torch.randint(0, 256, (B, T, H0, W0, 3), generator=g, dtype=torch.uint8)
+    np.random.seed(11)
+    prms = [spatial_sampling_params(H0, W0, -1, 64, 96, crop) for _ in range(B)]
+    ref = torch.stack([orc.input_pipeline(fr[b], prms[b], [0.45, 0.40, 0.5], [0.225, 0.25, 0.2], crop) for b in range(B)])
+    got = ops.frames_u8_patchify(DecodedClips(fr.to(dev()), prms, [0.45, 0.40, 0.5], [0.225, 0.25, 0.2], crop))
+    cmp("u8 pipeline vs oracle, batch of 5", got, orc.patch_rows(ref))
+    return out
+
+
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]

@@ -177,3 +177,19 @@ def test_forecast_eval():
     with torch.no_grad():
         probs = orc.vit_forward_forecast_eval(sd, f["x"], f["label_emb"], 0.02, f["depth"], 8)
     assert rel(probs, f["probs"]) < 1e-4
+
+
+def test_input_pipeline_oracle_and_host_draws_match_reference():
+    """tests/golden/input_pipeline.pt: the reference's tensor_normalize + spatial_sampling on random uint8 clips.
+    (1) the host mirror draws the same (size, offsets, flip) from the same numpy seed; (2) the oracle restatement of
+    the chain reproduces the reference's output from those draws."""
+    import numpy as np
+    from procedurevrl_amd.transform import spatial_sampling_params
+    g = load("input_pipeline")
+    for c in g["cases"]:
+        np.random.seed(c["seed"])
+        prm = spatial_sampling_params(c["H0"], c["W0"], c["spatial_idx"], c["min_scale"], c["max_scale"], c["crop"],
+                                      c["flip"], c["inv"])
+        got = orc.input_pipeline(c["frames"], prm, g["mean"], g["std"], c["crop"])
+        assert got.shape == c["out"].shape
+        assert torch.allclose(got, c["out"], atol=1e-6, rtol=1e-6), (prm, (got - c["out"]).abs().max())
