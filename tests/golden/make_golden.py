@@ -323,6 +323,76 @@ def make_lr_table(defaults, out):
     out["lr_table"] = tab
 
 
+MVIT_SMALL = dict(frames=4, crop=64, depth=4, dim_mul=[[1, 2.0], [3, 2.0]], head_mul=[[1, 2.0], [3, 2.0]],
+                  pool_q=[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]], kv_adaptive=[1, 4, 4])
+
+
+def mvit_cfg(defaults, frames, crop, small=None):
+    cfg = defaults.get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/HowTo100M/procedurevrl_mvitv2_adamw.yaml"))
+    cfg.DATA.NUM_FRAMES = frames
+    cfg.DATA.TRAIN_CROP_SIZE = cfg.DATA.TEST_CROP_SIZE = crop
+    if small is not None:
+        cfg.MVIT.DEPTH = small["depth"]
+        cfg.MVIT.DIM_MUL = small["dim_mul"]
+        cfg.MVIT.HEAD_MUL = small["head_mul"]
+        cfg.MVIT.POOL_Q_STRIDE = small["pool_q"]
+        cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE = small["kv_adaptive"]
+    return cfg
+
+
+def make_mvit(defaults, out):
+    """The reference MViT_encoder (lib/models/slowfast_mvit/mvit.py) on a reduced geometry that still has every block
+    flavour of MViTv2-S (plain, q-strided stage transition with max-pool skip + channel projection, rel-pos with
+    q/k ratios 4, 2 and 1): features, every block's output, gradients of parameters of every kind."""
+    from oracle import mvit_oracle as mo
+    mvit = importlib.import_module("lib.models.slowfast_mvit.mvit")
+    sm = MVIT_SMALL
+    cfg = mvit_cfg(defaults, sm["frames"], sm["crop"], sm)
+    torch.manual_seed(0)
+    net = mvit.MViT_encoder(cfg)
+    sd = load_seeded(net, 41)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(2, 3, sm["frames"], sm["crop"], sm["crop"], generator=g)
+    blocks = []
+    hooks = [b.register_forward_hook(lambda m, i, o: blocks.append(o[0].detach().clone())) for b in net.blocks]
+    net.train()
+    feat = net(x)
+    gout = torch.randn(feat.shape, generator=g)
+    (feat * gout).sum().backward()
+    for h in hooks:
+        h.remove()
+    names = ["cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias", "norm.weight", "norm.bias"]
+    for i in range(sm["depth"]):
+        p = f"blocks.{i}."
+        names += [p + n for n in ("norm1.weight", "norm2.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                                  "attn.pool_q.weight", "attn.pool_k.weight", "attn.pool_v.weight", "attn.norm_q.weight",
+                                  "attn.norm_k.bias", "attn.norm_v.weight", "attn.rel_pos_h", "attn.rel_pos_w",
+                                  "attn.rel_pos_t", "mlp.fc1.weight", "mlp.fc2.bias")]
+        if (p + "proj.weight") in sd:
+            names += [p + "proj.weight", p + "proj.bias"]
+    params = dict(net.named_parameters())
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == mo.encoder_shapes(dict(cfg.MVIT), sm["frames"], sm["crop"]), "oracle shape table != reference"
+    out["mvit_small"] = dict(cfg=sm, mvit={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in dict(cfg.MVIT).items()},
+                             seed=41, checksum=checksum(sd), x=x, gout=gout, feat=feat.detach().clone(), blocks=blocks,
+                             grads={n: (params[n].grad[:64] if params[n].grad.dim() == 2 else params[n].grad).clone() for n in names},
+                             keys=sorted(shapes))   # 2-D weight gradients: first 64 rows (fixture size)
+    # the full MViTv2-S geometry (16 x 224^2, 16 blocks): shapes of every parameter + one clip's features
+    cfg = mvit_cfg(defaults, 16, 224)
+    torch.manual_seed(0)
+    net = mvit.MViT_encoder(cfg)
+    sd = load_seeded(net, 43)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == mo.encoder_shapes(dict(cfg.MVIT), 16, 224), "oracle shape table != reference (MViTv2-S)"
+    xs = torch.randn(1, 3, 16, 224, 224, generator=torch.Generator().manual_seed(44))
+    net.eval()
+    with torch.no_grad():
+        feat = net(xs)
+    out["mvit_s"] = dict(mvit={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in dict(cfg.MVIT).items()},
+                         seed=43, x_seed=44, checksum=checksum(sd), feat=feat.clone(), shapes=shapes)
+
+
 def make_input_pipeline(out):
     """The CPU-worker chain of howto100m.py:437-452 (tensor_normalize -> permute -> spatial_sampling) on random uint8
     frames, for train (random scale / crop / flip, np.random seeded) and test (uniform crop) modes."""
@@ -352,6 +422,15 @@ def make_input_pipeline(out):
 
 def main():
     import tempfile
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit":
+        _install_stubs()
+        defaults = importlib.import_module("lib.config.defaults")
+        out = {}
+        make_mvit(defaults, out)
+        for k, v in out.items():
+            torch.save(v, os.path.join(HERE, k + ".pt"))
+            print("wrote", k, os.path.getsize(os.path.join(HERE, k + ".pt")) // 1024, "KiB")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "input_pipeline":
         _install_stubs()
         out = {}
@@ -370,6 +449,7 @@ def main():
     make_lr_table(defaults, out)
     make_allgather(dist_mod, out)
     make_input_pipeline(out)
+    make_mvit(defaults, out)
     for k, v in out.items():
         torch.save(v, os.path.join(HERE, k + ".pt"))
         print("wrote", k, os.path.getsize(os.path.join(HERE, k + ".pt")) // 1024, "KiB")

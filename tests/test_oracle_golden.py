@@ -193,3 +193,44 @@ def test_input_pipeline_oracle_and_host_draws_match_reference():
         got = orc.input_pipeline(c["frames"], prm, g["mean"], g["std"], c["crop"])
         assert got.shape == c["out"].shape
         assert torch.allclose(got, c["out"], atol=1e-6, rtol=1e-6), (prm, (got - c["out"]).abs().max())
+
+
+def _mvit_state(g, frames, crop):
+    from oracle import mvit_oracle as mo
+    sd = orc.seeded_state(mo.encoder_shapes(g["mvit"], frames, crop), g["seed"])
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - g["checksum"]) < 1e-6 * g["checksum"]
+    return sd
+
+
+def test_mvit_oracle_small_forward_blocks_and_grads():
+    """oracle/mvit_oracle.py vs the reference MViT_encoder on the reduced 4-block geometry (tests/golden/mvit_small.pt):
+    state_dict keys, every block's output, the features and the gradients of every kind of parameter."""
+    from oracle import mvit_oracle as mo
+    g = load("mvit_small")
+    c = g["cfg"]
+    sd = _mvit_state(g, c["frames"], c["crop"])
+    assert sorted(sd) == g["keys"]
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    outs = []
+    feat = mo.forward_features(p, g["x"], g["mvit"], block_outputs=outs)
+    for i, (a, b) in enumerate(zip(outs, g["blocks"])):
+        assert torch.allclose(a, b, atol=2e-5, rtol=2e-5), (i, (a - b).abs().max())
+    assert torch.allclose(feat, g["feat"], atol=2e-5, rtol=2e-5)
+    (feat * g["gout"]).sum().backward()
+    for n, ref in g["grads"].items():
+        got = p[n].grad[:64] if p[n].grad.dim() == 2 else p[n].grad
+        # norm_k.bias shifts every key by the same vector: softmax-invariant, its true gradient is 0 and the reference's
+        # value is rounding noise (4e-6 in norm) -> absolute floor next to the relative bound
+        assert (got - ref).norm() < 2e-4 * ref.norm() + 1e-6 * ref.numel() ** 0.5, (n, float((got - ref).norm()), float(ref.norm()))
+
+
+def test_mvit_oracle_full_size_features():
+    """MViTv2-S geometry (16 x 224^2, 16 blocks, 34 M parameters): parameter shapes and one clip's features."""
+    from oracle import mvit_oracle as mo
+    g = load("mvit_s")
+    assert {k: tuple(v) for k, v in g["shapes"].items()} == mo.encoder_shapes(g["mvit"], 16, 224)
+    sd = _mvit_state(g, 16, 224)
+    x = torch.randn(1, 3, 16, 224, 224, generator=torch.Generator().manual_seed(g["x_seed"]))
+    with torch.no_grad():
+        feat = mo.forward_features(sd, x, g["mvit"])
+    assert torch.allclose(feat, g["feat"], atol=5e-5, rtol=5e-5), (feat - g["feat"]).abs().max()
