@@ -149,6 +149,70 @@ int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float dampening,
                   float weight_decay, int nesterov, int first_step, float gscale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * MViTv2 encoder path (reference lib/models/slowfast_mvit/).  Token matrices: rows [0, B*L) patch tokens
+ * ordered (b, t, h, w), rows [B*L, B*L + B) the cls tokens; channel widths padded with zero columns to multiples of 128.
+ * Pooled per-head tensors: [B*H][L' + 1][96] bf16 with the cls token LAST.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* im2col of PatchEmbed's Conv3d (stem_helper.py:290-321): frames fp32 [B,Cin,T,H,W] -> bf16 rows (b,to,ho,wo) x ldo columns,
+ * column ((c*kt + a)*kh + y)*kw + x = the flatten order of Conv3d.weight; columns >= Cin*kt*kh*kw are zero. */
+int pvrl_im2col3d_bf16(const float* frames, int64_t B, int64_t Cin, int64_t T, int64_t H, int64_t W, int64_t kt,
+                       int64_t kh, int64_t kw, int64_t st, int64_t sh, int64_t sw, int64_t pt, int64_t ph, int64_t pw,
+                       void* out, int64_t ldo, void* stream);
+
+/* nn.LayerNorm of any width C <= 768 over fp32 rows with leading dimension ldx (mvit.py:78, attention.py:502,524);
+ * y (bf16, or fp32 when y_is_f32) gets zeros in columns [C, Cpad).  Backward: dx = dres + dLN(dy); dgamma / dbeta are
+ * ACCUMULATED (atomicAdd) into the given buffers. */
+int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                         int64_t ldy, int y_is_f32, int64_t M, int64_t C, int64_t Cpad, float* mean, float* rstd,
+                         void* stream);
+int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx, const float* mean,
+                         const float* rstd, const float* gamma, const float* dres, int64_t ldr, float* dx, int64_t lddx,
+                         int64_t M, int64_t C, int64_t Cpad, float* dgamma, float* dbeta, void* stream);
+
+/* attention_pool (attention.py:14-48) for mode "conv": depthwise Conv3d(96 ch, kernel 3x3x3, padding 1, stride st,sh,sw, no
+ * bias; weight fp32 [96][27]) + LayerNorm(96) on one of q / k / v taken in place from the packed qkv activation (bf16
+ * [B*T*Hh*Ww + B][ld], columns col0 + h*96 ..); the cls token skips the conv.  y / conv_out: [B*H][To*Ho*Wo + 1][96] bf16.
+ * Backward writes this tensor's slice of dqkv and ACCUMULATES dw [96][27], dgamma, dbeta; dc_scratch: bf16, size of y. */
+int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww,
+                       int64_t st, int64_t sh, int64_t sw, const float* w, const float* gamma, const float* beta,
+                       float eps, void* y, void* conv_out, void* stream);
+int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const void* qkv, void* dqkv, int64_t ld, int64_t col0,
+                       int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st, int64_t sh, int64_t sw,
+                       const float* w, const float* gamma, float eps, void* dc_scratch, float* dw, float* dgamma,
+                       float* dbeta, void* stream);
+
+/* MaxPool3d skip of MultiScaleBlock (attention.py:537-552): kernel (1,s+1,s+1), stride (1,s,s), padding (0,(s+1)/2,..),
+ * fp32 token matrix in / out, cls rows copied.  Backward routes to the first maximum (torch semantics). */
+int pvrl_mvit_maxpool_fwd(const float* x, int64_t ldi, int64_t B, int64_t T, int64_t H, int64_t W, int64_t s, int64_t C,
+                          float* y, int64_t ldo, void* stream);
+int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* dy, int64_t ldo, int64_t B, int64_t T, int64_t H,
+                          int64_t W, int64_t s, int64_t C, float* dx, void* stream);
+
+/* Decomposed relative-position terms (attention.py:67-159): rel[bh][q][j] = Q[bh][q] . R_j(q), j over kh heights, kw
+ * widths, kt times; R_j(q) = rel_pos_h[idx_h[qh(q)][j]] ... with the int32 index tables of attention.py:80-98,130-137.
+ * Backward: dQ += drel . R (in place on the bf16 dQ of the attention backward), dR* ACCUMULATED. */
+int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw,
+                      const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h, const int32_t* idx_w,
+                      const int32_t* idx_t, float* rel, void* stream);
+int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh, int64_t qw,
+                      int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw, const float* Rt,
+                      const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* dRh, float* dRw,
+                      float* dRt, void* stream);
+
+/* Pooling attention (attention.py:404-442): softmax(scale q k^T + rel bias) v (+ q, residual pooling) for head_dim 96;
+ * q [B*H][Lq+1][96], k / v [B*H][kt*kh*kw+1][96]; o / d_o token-major [B*Lq + B][ldo] with column h*96 + d.
+ * lse / delta fp32 [B*H][Lq+1]; drel fp32 [B*H][Lq][kh+kw+kt]. */
+int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
+                       int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo, float* lse, void* stream);
+int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
+                       int64_t kt, int64_t kh, int64_t kw, float scale, const void* o, const void* d_o, int64_t ldo,
+                       const float* lse, float* delta, void* dq, void* dk, void* dv, float* drel, void* stream);
+
+/* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
+int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,480 @@
+// Pooling attention of MViTv2 (reference: MultiScaleAttention.forward, lib/models/slowfast_mvit/attention.py:404-442):
+//     attn = (q * scale) @ k^T  + rel_h[q, kh(k)] + rel_w[q, kw(k)] + rel_t[q, kt(k)]   (patch queries x patch keys only)
+//     out  = softmax(attn) @ v  (+ q for patch queries: residual pooling, attention.py:431-435)
+// q / k / v are the pooled, LayerNorm-ed tensors [B*H][L+1][96] (cls token LAST), head_dim 96, up to 25,088 queries and
+// 392 or 1,568 keys per (clip, head).  Flash-style: 64 queries per workgroup (16 per wave), keys streamed in tiles of 32
+// through LDS, online softmax in the exp2 domain, the score tile never leaves registers.
+// MFMA operands are swapped (S^T = K Q^T, O^T = V^T P^T) so that one lane owns one query: the softmax statistics are
+// per-lane scalars, P feeds the second MFMA straight from registers, and V^T / K^T fragments come from the row-major LDS
+// tile through ds_read_b64_tr_b16.  The decomposed relative-position bias is a per-query row of J = kh + kw + kt numbers
+// (computed by pvrl_mvit_rel_fwd) indexed by the key's (t, h, w) decomposition.
+// Backward = two kernels (the contraction over queries needs the un-swapped layout): dQ (+ d rel) per query tile,
+// dK / dV per key tile.
+#include "attn_common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+constexpr int D = 96, NCB = 6;          // head_dim, 16-column blocks per row
+constexpr int KT = 32;                  // keys (or queries) per LDS tile
+constexpr int TILE_BYTES = KT * D * 2;  // 6 KiB
+constexpr int JMAX = 40;                // kh + kw + kt <= 36 (14 + 14 + 8)
+constexpr int MAXKEYS = 1664;           // 8*14*14 + 1 = 1569 keys, rounded
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct PA {
+  const bf16* q; const bf16* k; const bf16* v;   // [BH][L+1][96]
+  const float* rel;                              // [BH][Lq][J]
+  bf16* o; long ldo;                             // token-major [B*Lq + B][ldo], column h*96 + d
+  float* lse;                                    // [BH][Lq+1]   (log2 domain)
+  const bf16* d_o;                               // same layout as o
+  float* delta;                                  // [BH][Lq+1]
+  bf16* dq; bf16* dk; bf16* dv;                  // [BH][L+1][96]
+  float* drel;                                   // [BH][Lq][J]
+  int B, H, Lq, Lk, kt, kh, kw, J;
+  float scale;
+};
+
+// blocked [rows][96] bf16 tile: contiguous [4 rows][16 cols] 128-byte blocks, pairwise block swizzle
+__device__ __forceinline__ int pb_off(int row, int col) {
+  const int rb = row >> 2;
+  return (rb * NCB + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
+}
+__device__ __forceinline__ bf16x8 pb_row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + pb_off(row, chunk * 8));
+}
+// transposed fragment over the tile's 32 rows: lane (i, q) receives column 16*ct + i at rows {4q..4q+3, 16+4q..16+4q+3}
+__device__ __forceinline__ bf16x8 pb_tr_frag(const char* tile, int ct, int lane) {
+  const int q = lane >> 4, i = lane & 15;
+  const int rb0 = q, rb1 = q + 4;
+  return tr_frag8(tile, (rb0 * NCB + (ct ^ (rb0 & 1))) * 128 + i * 8, (rb1 * NCB + (ct ^ (rb1 & 1))) * 128 + i * 8);
+}
+
+// cooperative tile load: 32 rows x 12 chunks of 16 B = 384 chunks, rows >= nrows zero
+struct TileRegs { u32x4 v[2]; };
+__device__ __forceinline__ void tile_gload(TileRegs& t, const bf16* base, long ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = tid + 256 * e;
+    t.v[e] = (u32x4){0u, 0u, 0u, 0u};
+    if (c < 384) {
+      const int row = c / 12, ch = c - row * 12;
+      if (row0 + row < nrows) t.v[e] = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * ld + ch * 8);
+    }
+  }
+}
+__device__ __forceinline__ void tile_lstore(const TileRegs& t, char* tile, int tid) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = tid + 256 * e;
+    if (c < 384) {
+      const int row = c / 12, ch = c - row * 12;
+      *reinterpret_cast<u32x4*>(tile + pb_off(row, ch * 8)) = t.v[e];
+    }
+  }
+}
+
+// (h, kh + w, kh + kw + t) of key j packed in one word; 0xffffffff for the cls key and the padding
+__device__ __forceinline__ unsigned key_dec(const PA& p, int j) {
+  if (j >= p.Lk) return 0xffffffffu;
+  const int w = j % p.kw, h = (j / p.kw) % p.kh, t = j / (p.kw * p.kh);
+  return (unsigned)h | ((unsigned)(p.kh + w) << 8) | ((unsigned)(p.kh + p.kw + t) << 16);
+}
+__device__ __forceinline__ long tok_row(const PA& p, int b, int query) {
+  return query < p.Lq ? (long)b * p.Lq + query : (long)p.B * p.Lq + b;
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][K | V]
+  __shared__ float rel_s[4][16][JMAX];
+  __shared__ unsigned kdec_s[MAXKEYS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
+  const int query = blockIdx.x * 64 + wave * 16 + i;
+  const int qc = query < Lq1 ? query : Lq1 - 1;
+  const bf16* qrow = p.q + ((long)bh * Lq1 + qc) * D;
+  bf16x8 qf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + q4 * 8);
+  for (int j = tid; j < MAXKEYS; j += 256) kdec_s[j] = key_dec(p, j);
+  for (int e = lane; e < 16 * p.J; e += 64) {
+    const int qi = e / p.J, j = e - qi * p.J;
+    const int qq = blockIdx.x * 64 + wave * 16 + qi;
+    rel_s[wave][qi][j] = qq < p.Lq ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
+  }
+  const bf16* kb = p.k + (long)bh * Lk1 * D;
+  const bf16* vb = p.v + (long)bh * Lk1 * D;
+  const int ntiles = (Lk1 + KT - 1) / KT;
+  TileRegs rk, rv;
+  tile_gload(rk, kb, D, 0, Lk1, tid);
+  tile_gload(rv, vb, D, 0, Lk1, tid);
+  tile_lstore(rk, smem, tid);
+  tile_lstore(rv, smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  const bool qpatch = query < p.Lq;
+  float m = -INFINITY, l = 0.f;
+  f32x4 oacc[6];
+#pragma unroll
+  for (int dt = 0; dt < 6; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* relq = rel_s[wave][i];
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* Kb = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* Vb = Kb + TILE_BYTES;
+    if (t + 1 < ntiles) {
+      tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
+      tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+    }
+    float val[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * KT + u * 16 + 4 * q4 + r;
+        float x = s[r] * c;
+        const unsigned kd = kdec_s[key < MAXKEYS ? key : MAXKEYS - 1];
+        if (qpatch && kd != 0xffffffffu) x += relq[kd & 255] + relq[(kd >> 8) & 255] + relq[(kd >> 16) & 255];
+        val[u * 4 + r] = key < Lk1 ? x : -INFINITY;
+      }
+    }
+    float mx = val[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) mx = fmaxf(mx, val[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+    float pr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = __builtin_amdgcn_exp2f(val[e] - mn); ps += pr[e]; }
+    l = l * alpha + ps;
+    union { unsigned u[4]; bf16x8 v; } pf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(pr[2 * e], pr[2 * e + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) {
+      oacc[dt] *= alpha;
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      tile_lstore(rk, nb, tid);
+      tile_lstore(rv, nb + TILE_BYTES, tid);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (query < Lq1) {
+    const float inv = 1.f / l;
+    bf16* op = p.o + tok_row(p, b, query) * p.ldo + h * D + 4 * q4;
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) {
+      bf16x4 ov;
+      bf16x4 qv = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      if (qpatch) qv = *reinterpret_cast<const bf16x4*>(qrow + 16 * dt + 4 * q4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (bf16)(oacc[dt][r] * inv + (float)qv[r]);
+      *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+    }
+    if (q4 == 0) p.lse[(long)bh * Lq1 + query] = m + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward: dQ, d rel
+__global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  __shared__ float rel_s[4][16][JMAX];
+  __shared__ float drel_s[4][16][JMAX];
+  __shared__ unsigned kdec_s[MAXKEYS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
+  const int query = blockIdx.x * 64 + wave * 16 + i;
+  const int qc = query < Lq1 ? query : Lq1 - 1;
+  const bool qpatch = query < p.Lq;
+  const bf16* qrow = p.q + ((long)bh * Lq1 + qc) * D;
+  const long orow = tok_row(p, b, qc) * p.ldo + h * D;
+  bf16x8 qf[3], df[3];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + q4 * 8);
+    df[ks] = *reinterpret_cast<const bf16x8*>(p.d_o + orow + ks * 32 + q4 * 8);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(p.o + orow + ks * 32 + q4 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)df[ks][e] * ((float)of[e] - (qpatch ? (float)qf[ks][e] : 0.f));
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  const float lse2 = p.lse[(long)bh * Lq1 + qc];
+  if (query < Lq1 && q4 == 0) p.delta[(long)bh * Lq1 + query] = dl;
+  for (int j = tid; j < MAXKEYS; j += 256) kdec_s[j] = key_dec(p, j);
+  for (int e = lane; e < 16 * JMAX; e += 64) {
+    const int qi = e / JMAX, j = e - qi * JMAX;
+    const int qq = blockIdx.x * 64 + wave * 16 + qi;
+    rel_s[wave][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
+    drel_s[wave][qi][j] = 0.f;
+  }
+  const bf16* kb = p.k + (long)bh * Lk1 * D;
+  const bf16* vb = p.v + (long)bh * Lk1 * D;
+  const int ntiles = (Lk1 + KT - 1) / KT;
+  TileRegs rk, rv;
+  tile_gload(rk, kb, D, 0, Lk1, tid);
+  tile_gload(rv, vb, D, 0, Lk1, tid);
+  tile_lstore(rk, smem, tid);
+  tile_lstore(rv, smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  f32x4 dq[6];
+#pragma unroll
+  for (int dt = 0; dt < 6; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* relq = rel_s[wave][i];
+  float* drq = drel_s[wave][i];
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* Kb = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* Vb = Kb + TILE_BYTES;
+    if (t + 1 < ntiles) {
+      tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
+      tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+    }
+    float ds[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Vb, u * 16 + i, ks * 4 + q4), df[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * KT + u * 16 + 4 * q4 + r;
+        float x = s[r] * c;
+        const unsigned kd = kdec_s[key < MAXKEYS ? key : MAXKEYS - 1];
+        const bool hasb = qpatch && kd != 0xffffffffu;
+        if (hasb) x += relq[kd & 255] + relq[(kd >> 8) & 255] + relq[(kd >> 16) & 255];
+        const float pr = (key < Lk1 && query < Lq1) ? __builtin_amdgcn_exp2f(x - lse2) : 0.f;
+        const float g = pr * (dp[r] - dl);
+        ds[u * 4 + r] = g;
+        if (hasb) {
+          atomicAdd(drq + (kd & 255), g);
+          atomicAdd(drq + ((kd >> 8) & 255), g);
+          atomicAdd(drq + ((kd >> 16) & 255), g);
+        }
+      }
+    }
+    union { unsigned u[4]; bf16x8 v; } sf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sf.u[e] = pack_bf16x2(ds[2 * e], ds[2 * e + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt)
+      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
+    if (t + 1 < ntiles) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      tile_lstore(rk, nb, tid);
+      tile_lstore(rv, nb + TILE_BYTES, tid);
+    }
+    __syncthreads();
+  }
+  if (query < Lq1) {
+    bf16* op = p.dq + ((long)bh * Lq1 + query) * D + 4 * q4;
+    const bf16* dop = p.d_o + orow + 4 * q4;
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) {
+      bf16x4 ov;
+      bf16x4 dv = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      if (qpatch) dv = *reinterpret_cast<const bf16x4*>(dop + 16 * dt);     // residual pooling: d out / d q = 1
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (bf16)(dq[dt][r] * p.scale + (float)dv[r]);
+      *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+    }
+  }
+  // the wave's LDS atomics are complete once all its lanes reach this point (same wave, in-order LDS)
+  for (int e = lane; e < 16 * p.J; e += 64) {
+    const int qi = e / p.J, j = e - qi * p.J;
+    const int qq = blockIdx.x * 64 + wave * 16 + qi;
+    if (qq < p.Lq) p.drel[((long)bh * p.Lq + qq) * p.J + j] = drel_s[wave][qi][j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward: dK, dV
+// one wave = 16 keys (lane i owns key column i), workgroup = 64 keys; queries streamed in tiles of 32 (Q and dO in LDS)
+__global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][Q | dO]
+  __shared__ float rel_s[2][KT][JMAX];
+  __shared__ float lse_s[2][KT], dl_s[2][KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
+  const int key = blockIdx.x * 64 + wave * 16 + i;
+  const int kc = key < Lk1 ? key : Lk1 - 1;
+  bf16x8 kf[3], vf[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
+  }
+  const unsigned kd = key_dec(p, key);
+  const bool kpatch = kd != 0xffffffffu;
+  const int j0 = kd & 255, j1 = (kd >> 8) & 255, j2 = (kd >> 16) & 255;
+  const int ntiles = (Lq1 + KT - 1) / KT;
+  const bf16* qb = p.q + (long)bh * Lq1 * D;
+
+  // the dO tile is gathered from the token-major activation: rows (b, query) / cls row, columns h*96 ..
+  auto load_do = [&](TileRegs& t, int row0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cidx = tid + 256 * e;
+      t.v[e] = (u32x4){0u, 0u, 0u, 0u};
+      if (cidx < 384) {
+        const int row = cidx / 12, ch = cidx - row * 12;
+        const int qq = row0 + row;
+        if (qq < Lq1) t.v[e] = *reinterpret_cast<const u32x4*>(p.d_o + tok_row(p, b, qq) * p.ldo + h * D + ch * 8);
+      }
+    }
+  };
+  auto load_side = [&](int buf, int row0) {
+    for (int e = tid; e < KT * JMAX; e += 256) {
+      const int qi = e / JMAX, j = e - qi * JMAX;
+      const int qq = row0 + qi;
+      rel_s[buf][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
+    }
+    if (tid < KT) {
+      const int qq = row0 + tid;
+      lse_s[buf][tid] = qq < Lq1 ? p.lse[(long)bh * Lq1 + qq] : 0.f;
+      dl_s[buf][tid] = qq < Lq1 ? p.delta[(long)bh * Lq1 + qq] : 0.f;
+    }
+  };
+  TileRegs rq, rd;
+  tile_gload(rq, qb, D, 0, Lq1, tid);
+  load_do(rd, 0);
+  tile_lstore(rq, smem, tid);
+  tile_lstore(rd, smem + TILE_BYTES, tid);
+  load_side(0, 0);
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  f32x4 dk[6], dv[6];
+#pragma unroll
+  for (int dt = 0; dt < 6; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const char* Qb = smem + buf * 2 * TILE_BYTES;
+    const char* Db = Qb + TILE_BYTES;
+    if (t + 1 < ntiles) {
+      tile_gload(rq, qb, D, (t + 1) * KT, Lq1, tid);
+      load_do(rd, (t + 1) * KT);
+    }
+    float pr[8], ds[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Qb, u * 16 + i, ks * 4 + q4), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Db, u * 16 + i, ks * 4 + q4), vf[ks], dp, 0, 0, 0);
+      }
+      // s[r] = S[query = t*32 + 16u + 4*q4 + r][key]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = u * 16 + 4 * q4 + r;
+        const int qq = t * KT + ql;
+        float x = s[r] * c;
+        if (kpatch && qq < p.Lq) x += rel_s[buf][ql][j0] + rel_s[buf][ql][j1] + rel_s[buf][ql][j2];
+        const float pv = (qq < Lq1 && key < Lk1) ? __builtin_amdgcn_exp2f(x - lse_s[buf][ql]) : 0.f;
+        pr[u * 4 + r] = pv;
+        ds[u * 4 + r] = pv * (dp[r] - dl_s[buf][ql]);
+      }
+    }
+    union { unsigned u[4]; bf16x8 v; } pf, sf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pf.u[e] = pack_bf16x2(pr[2 * e], pr[2 * e + 1]);
+      sf.u[e] = pack_bf16x2(ds[2 * e], ds[2 * e + 1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) {
+      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Db, dt, lane), pf.v, dv[dt], 0, 0, 0);
+      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Qb, dt, lane), sf.v, dk[dt], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      tile_lstore(rq, nb, tid);
+      tile_lstore(rd, nb + TILE_BYTES, tid);
+      load_side((t + 1) & 1, (t + 1) * KT);
+    }
+    __syncthreads();
+  }
+  if (key < Lk1) {
+    bf16* kp = p.dk + ((long)bh * Lk1 + key) * D + 4 * q4;
+    bf16* vp = p.dv + ((long)bh * Lk1 + key) * D + 4 * q4;
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) {
+      bf16x4 a, c2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * p.scale); c2[r] = (bf16)dv[dt][r]; }
+      *reinterpret_cast<bf16x4*>(kp + 16 * dt) = a;
+      *reinterpret_cast<bf16x4*>(vp + 16 * dt) = c2;
+    }
+  }
+}
+
+int fill(PA& p, const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
+         int64_t kt, int64_t kh, int64_t kw, float scale, int64_t ldo) {
+  if (!q || !k || !v || !rel || B <= 0 || H <= 0 || Lq <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || (ldo % 8) || ldo < H * D)
+    return PVRL_EINVAL;
+  if (kh + kw + kt > JMAX || kt * kh * kw + 1 > MAXKEYS || kh + kw + kt > 255) return PVRL_EINVAL;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.rel = rel;
+  p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)(kt * kh * kw);
+  p.kt = (int)kt; p.kh = (int)kh; p.kw = (int)kw; p.J = (int)(kh + kw + kt);
+  p.scale = scale; p.ldo = ldo;
+  return PVRL_OK;
+}
+
+}  // namespace
+
+extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H,
+                                  int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo,
+                                  float* lse, void* stream) {
+  PA p = {};
+  if (!o || !lse || fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo)) return PVRL_EINVAL;
+  p.o = (bf16*)o; p.lse = lse;
+  hipLaunchKernelGGL(pattn_fwd_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H,
+                                  int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, const void* o,
+                                  const void* d_o, int64_t ldo, const float* lse, float* delta, void* dq, void* dk,
+                                  void* dv, float* drel, void* stream) {
+  PA p = {};
+  if (!o || !d_o || !lse || !delta || !dq || !dk || !dv || !drel || fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo))
+    return PVRL_EINVAL;
+  p.o = (bf16*)o; p.d_o = (const bf16*)d_o; p.lse = (float*)lse; p.delta = delta;
+  p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.drel = drel;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pattn_bwd_q_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pattn_bwd_kv_kernel, dim3((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

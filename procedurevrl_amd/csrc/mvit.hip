@@ -1,0 +1,789 @@
+// HBM-bound kernels of the MViTv2 encoder path (reference lib/models/slowfast_mvit/):
+//  * im2col of the 3-D patch-embed convolution (stem_helper.py:290-321, Conv3d k(3,7,7) s(2,4,4) p(1,3,3))
+//  * LayerNorm for any width <= 768 with a padded leading dimension (widths 96 / 192 / 384 / 768, attention.py:502,524)
+//  * attention_pool: depthwise 3x3x3 Conv3d + LayerNorm(head_dim) on q / k / v, cls token bypassing the conv
+//    (attention.py:14-48,239-290), forward, data gradient, weight gradient
+//  * max-pool skip connection (attention.py:537-552), forward and backward
+//  * decomposed relative-position terms rel[q][j] = q . R_j (attention.py:67-159) and their gradients
+// Token layout everywhere: rows [0, B*L) are the patch tokens ordered (b, t, h, w); rows [B*L, B*L+B) the cls tokens.
+// Channel widths are padded to multiples of 128 (zero columns) so the bf16 MFMA GEMMs of gemm_nt.hip / gemm_tn.hip apply.
+#include "common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+constexpr int HD = 96;   // head_dim of every MViTv2 block (96/1, 192/2, 384/4, 768/8)
+
+inline unsigned grid_for(long total, int per_block = 256) {
+  long b = (total + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 65535L * 16) b = 65535L * 16;
+  return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------------- im2col 3-D
+struct Conv3dGeom {
+  int B, Cin, T, H, W, kt, kh, kw, st, sh, sw, pt, ph, pw, To, Ho, Wo, K;   // K = Cin*kt*kh*kw
+};
+
+// out bf16 [(b, to, ho, wo)][ldo]; column k = ((c*kt + a)*kh + y)*kw + x (the flatten order of Conv3d.weight), zero for k >= K
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ frames, bf16* __restrict__ out,
+                                                       Conv3dGeom g, long ldo) {
+  const int chunks = (int)(ldo >> 3);
+  const long rows = (long)g.B * g.To * g.Ho * g.Wo;
+  const long total = rows * chunks;
+  const int khw = g.kh * g.kw, kvol = g.kt * khw;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int ch = (int)(idx % chunks);
+    long r = idx / chunks;
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho); r /= g.Ho;
+    const int to = (int)(r % g.To);
+    const int b = (int)(r / g.To);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ch * 8 + e;
+      float v = 0.f;
+      if (k < g.K) {
+        const int c = k / kvol;
+        int rem = k - c * kvol;
+        const int a = rem / khw;
+        rem -= a * khw;
+        const int y = rem / g.kw, x = rem - y * g.kw;
+        const int ti = to * g.st - g.pt + a, yi = ho * g.sh - g.ph + y, xi = wo * g.sw - g.pw + x;
+        if (ti >= 0 && ti < g.T && yi >= 0 && yi < g.H && xi >= 0 && xi < g.W)
+          v = frames[((((long)b * g.Cin + c) * g.T + ti) * g.H + yi) * g.W + xi];
+      }
+      o[e] = (bf16)v;
+    }
+    *reinterpret_cast<bf16x8*>(out + (idx / chunks) * ldo + ch * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- LayerNorm (any C <= 768)
+constexpr int LNG_MAX = 12;   // 64 lanes x 12 = 768
+
+__device__ __forceinline__ void st_val(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_val(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float ld_val(const float* p) { return *p; }
+__device__ __forceinline__ float ld_val(const bf16* p) { return (float)*p; }
+
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_g_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, TO* __restrict__ y, long ldy, int C, int Cpad,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, long M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    float v[LNG_MAX];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNG_MAX; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < C ? x[row * ldx + c] : 0.f;
+      s += v[j];
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNG_MAX; ++j) {
+      const int c = lane + 64 * j;
+      const float d = c < C ? v[j] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < LNG_MAX; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) st_val(y + row * ldy + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
+      else if (c < Cpad) st_val(y + row * ldy + c, 0.f);
+    }
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gamma * dy ; dgamma += dy * xhat ; dbeta += dy
+template <typename TD>
+__global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                       long ldx, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ dres, long ldr, float* __restrict__ dx,
+                                                       long lddx, int C, int Cpad, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, long M) {
+  __shared__ float red[2][4][64 * LNG_MAX / 4];   // reduced in four column quarters to stay small
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[LNG_MAX], ab[LNG_MAX];
+#pragma unroll
+  for (int j = 0; j < LNG_MAX; ++j) ag[j] = ab[j] = 0.f;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LNG_MAX], xh[LNG_MAX];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNG_MAX; ++j) {
+      const int c = lane + 64 * j;
+      g[j] = 0.f; xh[j] = 0.f;
+      if (c < C) {
+        const float d = ld_val(dy + row * lddy + c);
+        xh[j] = (x[row * ldx + c] - mu) * rs;
+        g[j] = d * gamma[c];
+        ag[j] += d * xh[j];
+        ab[j] += d;
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < LNG_MAX; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        float o = rs * (g[j] - s1 - xh[j] * s2);
+        if (dres) o += dres[row * ldr + c];
+        dx[row * lddx + c] = o;
+      } else if (c < Cpad) {
+        dx[row * lddx + c] = 0.f;
+      }
+    }
+  }
+  // cross-wave reduction of the parameter gradients, three j at a time
+  for (int j0 = 0; j0 < LNG_MAX; j0 += 3) {
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      red[0][wave][jj * 64 + lane] = ag[j0 + jj];
+      red[1][wave][jj * 64 + lane] = ab[j0 + jj];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int c = lane + 64 * (j0 + jj);
+        if (c < C) {
+          const float a = red[0][0][jj * 64 + lane] + red[0][1][jj * 64 + lane] + red[0][2][jj * 64 + lane] + red[0][3][jj * 64 + lane];
+          const float b = red[1][0][jj * 64 + lane] + red[1][1][jj * 64 + lane] + red[1][2][jj * 64 + lane] + red[1][3][jj * 64 + lane];
+          atomicAdd(dgamma + c, a);
+          atomicAdd(dbeta + c, b);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- attention_pool
+struct PoolGeom {
+  int B, H, T, Hh, Ww;      // input token grid (per clip) and heads
+  int st, sh, sw;           // conv stride (kernel 3x3x3, padding 1)
+  int To, Ho, Wo;
+  long cls_row0;            // row of clip 0's cls token in the packed activation (= B*T*Hh*Ww)
+  long ld;                  // leading dimension of the packed qkv activation
+  int col0;                 // first column of this tensor (q / k / v) in the packed activation; head h adds h*96
+};
+
+__device__ __forceinline__ void ld6(const bf16* p, float* v) {
+  const unsigned* u = reinterpret_cast<const unsigned*>(p);   // 4-byte aligned (6-channel groups of 2-byte values)
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const unsigned w = u[e];
+    v[2 * e] = __uint_as_float(w << 16);
+    v[2 * e + 1] = __uint_as_float(w & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st6(bf16* p, const float* v) {
+  unsigned* u = reinterpret_cast<unsigned*>(p);
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    union { bf16x2 h; unsigned w; } x;
+    x.h[0] = (bf16)v[2 * e]; x.h[1] = (bf16)v[2 * e + 1];
+    u[e] = x.w;
+  }
+}
+__device__ __forceinline__ float sum16(float v) {   // over the 16 lanes that share one token
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// y[bh][lo][96] = LayerNorm_96(conv3d_depthwise(x)[lo]) for lo < Lo, = LayerNorm_96(x_cls) for lo = Lo; conv output kept
+// (bf16) for the backward.  16 lanes per output token, 6 channels per lane.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ qkv, PoolGeom g,
+                                                       const float* __restrict__ w, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, bf16* __restrict__ y,
+                                                       bf16* __restrict__ cbuf) {
+  __shared__ float ws[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];   // [tap][c]
+  __syncthreads();
+  const int sub = threadIdx.x & 15, c0 = sub * 6;
+  const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
+  const long ntok = (long)g.B * g.H * (Lo + 1);
+  float gm[6], bt[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
+  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
+    const int lo = (int)(tok % (Lo + 1));
+    const long bh = tok / (Lo + 1);
+    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+    const int col = g.col0 + h * HD + c0;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lo == Lo) {
+      ld6(qkv + (g.cls_row0 + b) * g.ld + col, acc);
+    } else {
+      const int xo = lo % g.Wo, yo = (lo / g.Wo) % g.Ho, to = lo / (g.Wo * g.Ho);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int ti = to * g.st - 1 + a;
+        if (ti < 0 || ti >= g.T) continue;
+#pragma unroll
+        for (int yy = 0; yy < 3; ++yy) {
+          const int yi = yo * g.sh - 1 + yy;
+          if (yi < 0 || yi >= g.Hh) continue;
+#pragma unroll
+          for (int xx = 0; xx < 3; ++xx) {
+            const int xi = xo * g.sw - 1 + xx;
+            if (xi < 0 || xi >= g.Ww) continue;
+            float v[6];
+            ld6(qkv + ((long)b * L + ((long)ti * g.Hh + yi) * g.Ww + xi) * g.ld + col, v);
+            const float* wt = ws + ((a * 3 + yy) * 3 + xx) * HD + c0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) acc[e] = fmaf(v[e], wt[e], acc[e]);
+          }
+        }
+      }
+    }
+    st6(cbuf + tok * HD + c0, acc);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s += acc[e];
+    const float mu = sum16(s) * (1.f / HD);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) q += (acc[e] - mu) * (acc[e] - mu);
+    const float rs = rsqrtf(sum16(q) * (1.f / HD) + eps);
+    float o[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) o[e] = (acc[e] - mu) * rs * gm[e] + bt[e];
+    st6(y + tok * HD + c0, o);
+  }
+}
+
+// LayerNorm backward of the pooled tensor: dc = dLN(dy | c) (bf16, same layout), dgamma / dbeta accumulated atomically;
+// the cls token's dc goes straight to its row of the packed activation gradient (it bypassed the conv).
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ cbuf,
+                                                          PoolGeom g, const float* __restrict__ gamma, float eps,
+                                                          bf16* __restrict__ dc, bf16* __restrict__ dqkv,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][16][HD];
+  const int sub = threadIdx.x & 15, c0 = sub * 6, tl = threadIdx.x >> 4;
+  const int Lo = g.To * g.Ho * g.Wo;
+  const long ntok = (long)g.B * g.H * (Lo + 1);
+  float gm[6], ag[6], ab[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { gm[e] = gamma[c0 + e]; ag[e] = ab[e] = 0.f; }
+  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
+    float c[6], d[6];
+    ld6(cbuf + tok * HD + c0, c);
+    ld6(dy + tok * HD + c0, d);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s += c[e];
+    const float mu = sum16(s) * (1.f / HD);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) q += (c[e] - mu) * (c[e] - mu);
+    const float rs = rsqrtf(sum16(q) * (1.f / HD) + eps);
+    float xh[6], gg[6], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      xh[e] = (c[e] - mu) * rs;
+      gg[e] = d[e] * gm[e];
+      ag[e] += d[e] * xh[e];
+      ab[e] += d[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+    }
+    s1 = sum16(s1) * (1.f / HD);
+    s2 = sum16(s2) * (1.f / HD);
+    float o[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) o[e] = rs * (gg[e] - s1 - xh[e] * s2);
+    st6(dc + tok * HD + c0, o);
+    const int lo = (int)(tok % (Lo + 1));
+    if (lo == Lo) {
+      const long bh = tok / (Lo + 1);
+      const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+      st6(dqkv + (g.cls_row0 + b) * g.ld + g.col0 + h * HD + c0, o);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { red[0][tl][c0 + e] = ag[e]; red[1][tl][c0 + e] = ab[e]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * HD) {
+    const int which = threadIdx.x / HD, c = threadIdx.x % HD;
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a += red[which][t][c];
+    atomicAdd((which ? dbeta : dgamma) + c, a);
+  }
+}
+
+// data gradient of the depthwise conv: dX[b, l_in, h, c] = sum_taps dc[out(l_in, tap)][c] * w[c][tap]
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict__ dc, PoolGeom g,
+                                                         const float* __restrict__ w, bf16* __restrict__ dqkv) {
+  __shared__ float ws[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, c0 = sub * 6;
+  const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
+  const long ntok = (long)g.B * g.H * L;
+  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
+    const int l = (int)(tok % L);
+    const long bh = tok / L;
+    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+    const int xi = l % g.Ww, yi = (l / g.Ww) % g.Hh, ti = l / (g.Ww * g.Hh);
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int tn = ti + 1 - a;
+      if (tn < 0 || tn % g.st) continue;
+      const int to = tn / g.st;
+      if (to >= g.To) continue;
+#pragma unroll
+      for (int yy = 0; yy < 3; ++yy) {
+        const int yn = yi + 1 - yy;
+        if (yn < 0 || yn % g.sh) continue;
+        const int yo = yn / g.sh;
+        if (yo >= g.Ho) continue;
+#pragma unroll
+        for (int xx = 0; xx < 3; ++xx) {
+          const int xn = xi + 1 - xx;
+          if (xn < 0 || xn % g.sw) continue;
+          const int xo = xn / g.sw;
+          if (xo >= g.Wo) continue;
+          float v[6];
+          ld6(dc + (bh * (Lo + 1) + ((long)to * g.Ho + yo) * g.Wo + xo) * HD + c0, v);
+          const float* wt = ws + ((a * 3 + yy) * 3 + xx) * HD + c0;
+#pragma unroll
+          for (int e = 0; e < 6; ++e) acc[e] = fmaf(v[e], wt[e], acc[e]);
+        }
+      }
+    }
+    st6(dqkv + ((long)b * L + l) * g.ld + g.col0 + h * HD + c0, acc);
+  }
+}
+
+// weight gradient of the depthwise conv: dW[c][tap] += sum_{b,h,out} dc[out][c] * x[in(out, tap)][c]
+// block = 2 token lanes x 96 channels; each thread keeps its 27 tap sums in registers.
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(const bf16* __restrict__ dc, const bf16* __restrict__ qkv,
+                                                         PoolGeom g, float* __restrict__ dw) {
+  __shared__ float red[27][HD];
+  const int c = threadIdx.x % HD, tl = threadIdx.x / HD;
+  const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
+  const long ntok = (long)g.B * g.H * Lo;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (long tok = (long)blockIdx.x * 2 + tl; tok < ntok; tok += (long)gridDim.x * 2) {
+    const int lo = (int)(tok % Lo);
+    const long bh = tok / Lo;
+    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+    const int xo = lo % g.Wo, yo = (lo / g.Wo) % g.Ho, to = lo / (g.Wo * g.Ho);
+    const float d = (float)dc[(bh * (Lo + 1) + lo) * HD + c];
+    const bf16* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int ti = to * g.st - 1 + a;
+#pragma unroll
+      for (int yy = 0; yy < 3; ++yy) {
+        const int yi = yo * g.sh - 1 + yy;
+#pragma unroll
+        for (int xx = 0; xx < 3; ++xx) {
+          const int xi = xo * g.sw - 1 + xx;
+          if (ti >= 0 && ti < g.T && yi >= 0 && yi < g.Hh && xi >= 0 && xi < g.Ww)
+            acc[(a * 3 + yy) * 3 + xx] += d * (float)xb[(((long)ti * g.Hh + yi) * g.Ww + xi) * g.ld];
+        }
+      }
+    }
+  }
+  if (tl == 1) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[t][c] = acc[t];
+  }
+  __syncthreads();
+  if (tl == 0) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) atomicAdd(dw + c * 27 + t, acc[t] + red[t][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- max-pool skip
+struct MaxPoolGeom {
+  int B, T, H, W, k, s, Ho, Wo, C;   // kernel (1,k,k), stride (1,s,s), padding (0,k/2,k/2)
+  long ldi, ldo;
+};
+
+// out rows: (b, t, ho, wo) then the B cls rows (copied).  4 channels per thread.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, MaxPoolGeom g,
+                                                          float* __restrict__ y) {
+  const int c4n = g.C >> 2;
+  const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
+  const long rows = g.B * Lo + g.B;
+  const long total = rows * c4n;
+  const int pad = g.k / 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c4 = (int)(idx % c4n);
+    const long row = idx / c4n;
+    f32x4 m;
+    if (row >= g.B * Lo) {
+      m = *reinterpret_cast<const f32x4*>(x + (g.B * L + (row - g.B * Lo)) * g.ldi + c4 * 4);
+    } else {
+      const int wo = (int)(row % g.Wo), ho = (int)((row / g.Wo) % g.Ho);
+      const long bt = row / ((long)g.Wo * g.Ho);       // b*T + t
+      m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int yy = 0; yy < g.k; ++yy) {
+        const int yi = ho * g.s - pad + yy;
+        if (yi < 0 || yi >= g.H) continue;
+        for (int xx = 0; xx < g.k; ++xx) {
+          const int xi = wo * g.s - pad + xx;
+          if (xi < 0 || xi >= g.W) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bt * g.H + yi) * g.W + xi) * g.ldi + c4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + row * g.ldo + c4 * 4) = m;
+  }
+}
+
+// dx (pre-zeroed by the caller for the token rows) += routed dy: every output sends its gradient to the FIRST maximum of its
+// window in scan order (torch max_pool3d keeps the first `val > maxval`); cls rows are copied.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          MaxPoolGeom g, float* __restrict__ dx) {
+  const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
+  const long rows = g.B * Lo + g.B;
+  const long total = rows * g.C;
+  const int pad = g.k / 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % g.C);
+    const long row = idx / g.C;
+    const float d = dy[row * g.ldo + c];
+    if (row >= g.B * Lo) {
+      dx[(g.B * L + (row - g.B * Lo)) * g.ldi + c] = d;
+      continue;
+    }
+    const int wo = (int)(row % g.Wo), ho = (int)((row / g.Wo) % g.Ho);
+    const long bt = row / ((long)g.Wo * g.Ho);
+    float m = -INFINITY;
+    long arg = -1;
+    for (int yy = 0; yy < g.k; ++yy) {
+      const int yi = ho * g.s - pad + yy;
+      if (yi < 0 || yi >= g.H) continue;
+      for (int xx = 0; xx < g.k; ++xx) {
+        const int xi = wo * g.s - pad + xx;
+        if (xi < 0 || xi >= g.W) continue;
+        const long r = (bt * g.H + yi) * g.W + xi;
+        const float v = x[r * g.ldi + c];
+        if (v > m || arg < 0) { m = v; arg = r; }
+      }
+    }
+    atomicAdd(dx + arg * g.ldi + c, d);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- relative position
+struct RelGeom {
+  int BH, qt, qh, qw, kt, kh, kw;   // J = kh + kw + kt columns: [0,kh) height, [kh,kh+kw) width, then time
+};
+
+// rel[bh][q][j] = sum_c Q[bh][q][c] * R_j(q)[c],  R_j(q) = rel_pos_h[idx_h[qh(q)][j]] etc. (attention.py:97-115,139-151)
+__global__ __launch_bounds__(256) void rel_fwd_kernel(const bf16* __restrict__ Q, RelGeom g, const float* __restrict__ Rh,
+                                                      const float* __restrict__ Rw, const float* __restrict__ Rt,
+                                                      const int* __restrict__ ih, const int* __restrict__ iw,
+                                                      const int* __restrict__ it, float* __restrict__ rel) {
+  const int J = g.kh + g.kw + g.kt;
+  const int Lq = g.qt * g.qh * g.qw;
+  const long total = (long)g.BH * Lq * J;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int j = (int)(idx % J);
+    const long bq = idx / J;
+    const int q = (int)(bq % Lq);
+    const long bh = bq / Lq;
+    const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
+    const float* R;
+    if (j < g.kh) R = Rh + (long)ih[y * g.kh + j] * HD;
+    else if (j < g.kh + g.kw) R = Rw + (long)iw[x * g.kw + (j - g.kh)] * HD;
+    else R = Rt + (long)it[t * g.kt + (j - g.kh - g.kw)] * HD;
+    const bf16* qp = Q + (bh * (Lq + 1) + q) * HD;
+    float a = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < HD; ++c) a = fmaf((float)qp[c], R[c], a);
+    rel[idx] = a;
+  }
+}
+
+// dQ[bh][q][c] += sum_j drel[bh][q][j] * R_j(q)[c]     (dQ is the bf16 gradient written by the attention backward)
+__global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
+                                                        const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                        const float* __restrict__ Rt, const int* __restrict__ ih,
+                                                        const int* __restrict__ iw, const int* __restrict__ it,
+                                                        bf16* __restrict__ dQ) {
+  const int J = g.kh + g.kw + g.kt;
+  const int Lq = g.qt * g.qh * g.qw;
+  const long total = (long)g.BH * Lq * HD;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % HD);
+    const long bq = idx / HD;
+    const int q = (int)(bq % Lq);
+    const long bh = bq / Lq;
+    const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
+    const float* d = drel + bq * J;
+    float a = 0.f;
+    for (int j = 0; j < g.kh; ++j) a = fmaf(d[j], Rh[(long)ih[y * g.kh + j] * HD + c], a);
+    for (int j = 0; j < g.kw; ++j) a = fmaf(d[g.kh + j], Rw[(long)iw[x * g.kw + j] * HD + c], a);
+    for (int j = 0; j < g.kt; ++j) a = fmaf(d[g.kh + g.kw + j], Rt[(long)it[t * g.kt + j] * HD + c], a);
+    bf16* p = dQ + (bh * (Lq + 1) + q) * HD + c;
+    *p = (bf16)((float)*p + a);
+  }
+}
+
+// dR_axis[idx[coord][j]][c] += sum over all (bh, q with that axis coordinate) drel[bh][q][off + j] * Q[bh][q][c]
+// grid (q_n, k_n); block 96 channels x 2 slices.
+__global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const bf16* __restrict__ Q,
+                                                            RelGeom g, int axis, const int* __restrict__ idx,
+                                                            float* __restrict__ dR) {
+  __shared__ float red[HD];
+  const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
+  const int coord = blockIdx.x, j = blockIdx.y;
+  const int J = g.kh + g.kw + g.kt;
+  const int Lq = g.qt * g.qh * g.qw;
+  int n_other, off, kn;
+  if (axis == 0) { n_other = g.qt * g.qw; off = 0; kn = g.kh; }
+  else if (axis == 1) { n_other = g.qt * g.qh; off = g.kh; kn = g.kw; }
+  else { n_other = g.qh * g.qw; off = g.kh + g.kw; kn = g.kt; }
+  const long n = (long)g.BH * n_other;
+  float a = 0.f;
+  for (long i = sl; i < n; i += 2) {
+    const int o = (int)(i % n_other);
+    const long bh = i / n_other;
+    int q;
+    if (axis == 0) { const int t = o / g.qw, x = o % g.qw; q = (t * g.qh + coord) * g.qw + x; }
+    else if (axis == 1) { q = o * g.qw + coord; }                 // o = t*qh + y
+    else { q = coord * g.qh * g.qw + o; }
+    a = fmaf(drel[(bh * Lq + q) * J + off + j], (float)Q[(bh * (Lq + 1) + q) * HD + c], a);
+  }
+  if (sl == 1) red[c] = a;
+  __syncthreads();
+  if (sl == 0) atomicAdd(dR + (long)idx[coord * kn + j] * HD + c, a + red[c]);
+}
+
+// ------------------------------------------------------------------------------------------------- misc
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                     long ldo, long R, int C, float beta) {
+  const long total = R * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const float v = in[r * ldi + c];
+    out[r * ldo + c] = beta != 0.f ? beta * out[r * ldo + c] + v : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int pvrl_im2col3d_bf16(const float* frames, int64_t B, int64_t Cin, int64_t T, int64_t H, int64_t W,
+                                  int64_t kt, int64_t kh, int64_t kw, int64_t st, int64_t sh, int64_t sw, int64_t pt,
+                                  int64_t ph, int64_t pw, void* out, int64_t ldo, void* stream) {
+  if (B <= 0) return PVRL_OK;
+  if (!frames || !out || (ldo % 8) || kt <= 0 || kh <= 0 || kw <= 0 || st <= 0 || sh <= 0 || sw <= 0) return PVRL_EINVAL;
+  Conv3dGeom g;
+  g.B = (int)B; g.Cin = (int)Cin; g.T = (int)T; g.H = (int)H; g.W = (int)W;
+  g.kt = (int)kt; g.kh = (int)kh; g.kw = (int)kw; g.st = (int)st; g.sh = (int)sh; g.sw = (int)sw;
+  g.pt = (int)pt; g.ph = (int)ph; g.pw = (int)pw;
+  g.To = (int)((T + 2 * pt - kt) / st + 1); g.Ho = (int)((H + 2 * ph - kh) / sh + 1); g.Wo = (int)((W + 2 * pw - kw) / sw + 1);
+  g.K = (int)(Cin * kt * kh * kw);
+  if (ldo < g.K) return PVRL_EINVAL;
+  const long total = (long)B * g.To * g.Ho * g.Wo * (ldo >> 3);
+  hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out, g,
+                     (long)ldo);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                    void* y, int64_t ldy, int y_is_f32, int64_t M, int64_t C, int64_t Cpad, float* mean,
+                                    float* rstd, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!x || !gamma || !beta || !y || C <= 0 || C > 64 * LNG_MAX || Cpad < C || Cpad > 64 * LNG_MAX || ldx < C || ldy < Cpad)
+    return PVRL_EINVAL;
+  const unsigned grid = grid_for(M, 4);
+  if (y_is_f32)
+    hipLaunchKernelGGL(ln_g_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
+                       eps, (float*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
+  else
+    hipLaunchKernelGGL(ln_g_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
+                       eps, (bf16*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
+                                    const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                    int64_t ldr, float* dx, int64_t lddx, int64_t M, int64_t C, int64_t Cpad,
+                                    float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || C <= 0 || C > 64 * LNG_MAX || Cpad < C ||
+      Cpad > 64 * LNG_MAX)
+    return PVRL_EINVAL;
+  long blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (dy_is_f32)
+    hipLaunchKernelGGL(ln_g_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
+                       (int)C, (int)Cpad, dgamma, dbeta, (long)M);
+  else
+    hipLaunchKernelGGL(ln_g_bwd_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
+                       (int)C, (int)Cpad, dgamma, dbeta, (long)M);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+static int pool_geom(PoolGeom& g, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st, int64_t sh,
+                     int64_t sw, int64_t ld, int64_t col0) {
+  if (B <= 0 || H <= 0 || T <= 0 || Hh <= 0 || Ww <= 0 || st <= 0 || sh <= 0 || sw <= 0 || (ld % 2) || (col0 % 2))
+    return PVRL_EINVAL;
+  g.B = (int)B; g.H = (int)H; g.T = (int)T; g.Hh = (int)Hh; g.Ww = (int)Ww;
+  g.st = (int)st; g.sh = (int)sh; g.sw = (int)sw;
+  g.To = (int)((T + 2 - 3) / st + 1); g.Ho = (int)((Hh + 2 - 3) / sh + 1); g.Wo = (int)((Ww + 2 - 3) / sw + 1);
+  g.cls_row0 = (long)B * T * Hh * Ww;
+  g.ld = (long)ld; g.col0 = (int)col0;
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh,
+                                  int64_t Ww, int64_t st, int64_t sh, int64_t sw, const float* w, const float* gamma,
+                                  const float* beta, float eps, void* y, void* conv_out, void* stream) {
+  PoolGeom g;
+  if (!qkv || !w || !gamma || !beta || !y || !conv_out || pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0)) return PVRL_EINVAL;
+  const long ntok = (long)B * H * ((long)g.To * g.Ho * g.Wo + 1);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, g,
+                     w, gamma, beta, eps, (bf16*)y, (bf16*)conv_out);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const void* qkv, void* dqkv, int64_t ld,
+                                  int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st,
+                                  int64_t sh, int64_t sw, const float* w, const float* gamma, float eps, void* dc_scratch,
+                                  float* dw, float* dgamma, float* dbeta, void* stream) {
+  PoolGeom g;
+  if (!dy || !conv_out || !qkv || !dqkv || !w || !gamma || !dc_scratch || !dw || !dgamma || !dbeta ||
+      pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0))
+    return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long Lo = (long)g.To * g.Ho * g.Wo;
+  const long ntok = (long)B * H * (Lo + 1);
+  long blocks = (ntok * 16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)conv_out,
+                     g, gamma, eps, (bf16*)dc_scratch, (bf16*)dqkv, dgamma, dbeta);
+  PVRL_LAUNCH_CHECK();
+  const long nin = (long)B * H * T * Hh * Ww;
+  hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
+                     (bf16*)dqkv);
+  PVRL_LAUNCH_CHECK();
+  long wb = (B * H * Lo + 1) / 2;
+  if (wb > 1024) wb = 1024;
+  if (wb < 1) wb = 1;
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(192), 0, s, (const bf16*)dc_scratch, (const bf16*)qkv,
+                     g, dw);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+static int maxpool_geom(MaxPoolGeom& g, int64_t B, int64_t T, int64_t H, int64_t W, int64_t s, int64_t C, int64_t ldi,
+                        int64_t ldo) {
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || s < 2 || C <= 0 || (C % 4) || (ldi % 4) || (ldo % 4) || ldi < C || ldo < C)
+    return PVRL_EINVAL;
+  g.B = (int)B; g.T = (int)T; g.H = (int)H; g.W = (int)W; g.s = (int)s; g.k = (int)s + 1; g.C = (int)C;
+  const int pad = g.k / 2;
+  g.Ho = (int)((H + 2 * pad - g.k) / s + 1); g.Wo = (int)((W + 2 * pad - g.k) / s + 1);
+  g.ldi = (long)ldi; g.ldo = (long)ldo;
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_maxpool_fwd(const float* x, int64_t ldi, int64_t B, int64_t T, int64_t H, int64_t W, int64_t s,
+                                     int64_t C, float* y, int64_t ldo, void* stream) {
+  MaxPoolGeom g;
+  if (!x || !y || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
+  const long total = ((long)B * T * g.Ho * g.Wo + B) * (C >> 2);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, g, y);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* dy, int64_t ldo, int64_t B, int64_t T,
+                                     int64_t H, int64_t W, int64_t s, int64_t C, float* dx, void* stream) {
+  MaxPoolGeom g;
+  if (!x || !dy || !dx || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
+  if (hipMemsetAsync(dx, 0, (size_t)B * T * H * W * ldi * sizeof(float), (hipStream_t)stream) != hipSuccess) return PVRL_EHIP;
+  const long total = ((long)B * T * g.Ho * g.Wo + B) * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+static int rel_geom(RelGeom& g, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw) {
+  if (BH <= 0 || qt <= 0 || qh <= 0 || qw <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return PVRL_EINVAL;
+  g.BH = (int)BH; g.qt = (int)qt; g.qh = (int)qh; g.qw = (int)qw; g.kt = (int)kt; g.kh = (int)kh; g.kw = (int)kw;
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
+                                 int64_t kw, const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h,
+                                 const int32_t* idx_w, const int32_t* idx_t, float* rel, void* stream) {
+  RelGeom g;
+  if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !rel || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
+  const long total = (long)BH * qt * qh * qw * (kh + kw + kt);
+  hipLaunchKernelGGL(rel_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)Q, g, Rh, Rw,
+                     Rt, idx_h, idx_w, idx_t, rel);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh,
+                                 int64_t qw, int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw,
+                                 const float* Rt, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
+                                 float* dRh, float* dRw, float* dRt, void* stream) {
+  RelGeom g;
+  if (!drel || !Q || !dQ || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !dRh || !dRw || !dRt ||
+      rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
+    return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)BH * qt * qh * qw * HD;
+  hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
+                     (bf16*)dQ);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qh, (unsigned)kh), dim3(192), 0, s, drel, (const bf16*)Q, g, 0,
+                     idx_h, dRh);
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qw, (unsigned)kw), dim3(192), 0, s, drel, (const bf16*)Q, g, 1,
+                     idx_w, dRw);
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qt, (unsigned)kt), dim3(192), 0, s, drel, (const bf16*)Q, g, 2,
+                     idx_t, dRt);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta,
+                               void* stream) {
+  if (R <= 0 || C <= 0) return PVRL_OK;
+  if (!in || !out || ldi < C || ldo < C) return PVRL_EINVAL;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(R * C)), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, out,
+                     (long)ldo, (long)R, (int)C, beta);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}

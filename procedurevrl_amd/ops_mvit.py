@@ -1,0 +1,145 @@
+"""Tensor-level wrappers over the MViTv2 entry points of the C ABI (include/pvrl.h, csrc/mvit.hip, csrc/attn_pool.hip).
+Same rules as ops.py: device tensors in, device tensors out, raw pointers to libpvrl_hip.so on the current stream,
+no PyTorch compute fallback.  Pooled per-head tensors are [B*H, L+1, 96] bf16 with the cls token LAST."""
+import torch
+
+from ._lib import lib
+from .ops import BF16, F32, _ptr, _stream
+
+I32 = torch.int32
+HD = 96
+
+
+def pad128(c):
+    return (int(c) + 127) // 128 * 128
+
+
+def im2col3d(frames, kernel, stride, padding, ldo):
+    """fp32 [B,Cin,T,H,W] -> (bf16 [B*To*Ho*Wo, ldo], (To, Ho, Wo))"""
+    L = lib()
+    assert frames.is_cuda and frames.dtype == F32 and frames.is_contiguous()
+    B, Cin, T, H, W = frames.shape
+    out_thw = tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip((T, H, W), kernel, stride, padding))
+    out = torch.empty((B * out_thw[0] * out_thw[1] * out_thw[2], ldo), device=frames.device, dtype=BF16)
+    L.call("pvrl_im2col3d_bf16", _ptr(frames), B, Cin, T, H, W, *kernel, *stride, *padding, _ptr(out), ldo, _stream())
+    return out, out_thw
+
+
+def ln_fwd(x, C, gamma, beta, eps, out_dtype=BF16, Cpad=None, stats=True):
+    """x fp32 [M, ld>=C] -> (y [M, Cpad] (zeros beyond C), mean, rstd)"""
+    L = lib()
+    assert x.is_cuda and x.dtype == F32 and x.stride(1) == 1
+    M = x.shape[0]
+    Cpad = C if Cpad is None else Cpad
+    y = torch.empty((M, Cpad), device=x.device, dtype=out_dtype)
+    mean = torch.empty(M, device=x.device, dtype=F32) if stats else None
+    rstd = torch.empty(M, device=x.device, dtype=F32) if stats else None
+    L.call("pvrl_layernorm_g_fwd", _ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y), y.stride(0),
+           int(out_dtype == F32), M, C, Cpad, _ptr(mean), _ptr(rstd), _stream())
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, C, mean, rstd, gamma, dgamma, dbeta, dres=None, Cpad=None):
+    """-> dx fp32 [M, Cpad] = dres + dLN(dy); dgamma / dbeta (fp32 [C]) are accumulated into."""
+    L = lib()
+    M = x.shape[0]
+    Cpad = C if Cpad is None else Cpad
+    dx = torch.empty((M, Cpad), device=x.device, dtype=F32)
+    assert dy.dtype in (F32, BF16) and dy.stride(1) == 1 and dgamma.dtype == F32 and dgamma.is_contiguous()
+    L.call("pvrl_layernorm_g_bwd", _ptr(dy), dy.stride(0), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean),
+           _ptr(rstd), _ptr(gamma), _ptr(dres), dres.stride(0) if dres is not None else 0, _ptr(dx), dx.stride(0), M, C,
+           Cpad, _ptr(dgamma), _ptr(dbeta), _stream())
+    return dx
+
+
+def pool_out_thw(thw, stride):
+    return tuple((s + 2 - 3) // st + 1 for s, st in zip(thw, stride))
+
+
+def pool_fwd(qkv, col0, B, H, thw, stride, w, gamma, beta, eps):
+    """-> (y, conv_out) both bf16 [B*H, Lo+1, 96]"""
+    L = lib()
+    To, Ho, Wo = pool_out_thw(thw, stride)
+    n = B * H * (To * Ho * Wo + 1)
+    y = torch.empty((B * H, To * Ho * Wo + 1, HD), device=qkv.device, dtype=BF16)
+    c = torch.empty_like(y)
+    L.call("pvrl_mvit_pool_fwd", _ptr(qkv), qkv.stride(0), col0, B, H, *thw, *stride, _ptr(w), _ptr(gamma), _ptr(beta),
+           float(eps), _ptr(y), _ptr(c), _stream())
+    return y, c
+
+
+def pool_bwd(dy, conv_out, qkv, dqkv, col0, B, H, thw, stride, w, gamma, eps, dw, dgamma, dbeta):
+    L = lib()
+    scratch = torch.empty_like(conv_out)
+    assert dy.dtype == BF16 and dy.is_contiguous() and dw.is_contiguous() and dw.dtype == F32
+    L.call("pvrl_mvit_pool_bwd", _ptr(dy), _ptr(conv_out), _ptr(qkv), _ptr(dqkv), qkv.stride(0), col0, B, H, *thw,
+           *stride, _ptr(w), _ptr(gamma), float(eps), _ptr(scratch), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _stream())
+
+
+def maxpool_fwd(x, B, thw, s, C):
+    L = lib()
+    T, H, W = thw
+    k = s + 1
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    y = torch.empty((B * T * Ho * Wo + B, x.shape[1]), device=x.device, dtype=F32)
+    if x.shape[1] > C:
+        y[:, C:].zero_()
+    L.call("pvrl_mvit_maxpool_fwd", _ptr(x), x.stride(0), B, T, H, W, s, C, _ptr(y), y.stride(0), _stream())
+    return y
+
+
+def maxpool_bwd(x, dy, B, thw, s, C):
+    L = lib()
+    T, H, W = thw
+    dx = torch.empty_like(x)
+    if x.shape[1] > C:
+        dx[B * T * H * W:, C:].zero_()
+    L.call("pvrl_mvit_maxpool_bwd", _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), B, T, H, W, s, C, _ptr(dx), _stream())
+    return dx
+
+
+def rel_fwd(Q, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it):
+    L = lib()
+    Lq = q_thw[0] * q_thw[1] * q_thw[2]
+    J = k_thw[1] + k_thw[2] + k_thw[0]
+    rel = torch.empty((BH, Lq, J), device=Q.device, dtype=F32)
+    L.call("pvrl_mvit_rel_fwd", _ptr(Q), BH, *q_thw, *k_thw, _ptr(Rh), _ptr(Rw), _ptr(Rt), _ptr(ih), _ptr(iw), _ptr(it),
+           _ptr(rel), _stream())
+    return rel
+
+
+def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt):
+    L = lib()
+    L.call("pvrl_mvit_rel_bwd", _ptr(drel), _ptr(Q), _ptr(dQ), BH, *q_thw, *k_thw, _ptr(Rh), _ptr(Rw), _ptr(Rt), _ptr(ih),
+           _ptr(iw), _ptr(it), _ptr(dRh), _ptr(dRw), _ptr(dRt), _stream())
+
+
+def attn_fwd(q, k, v, rel, B, H, Lq, k_thw, scale, ldo):
+    """-> (o bf16 [B*Lq + B, ldo] token-major (zeros beyond H*96), lse fp32 [B*H, Lq+1])"""
+    L = lib()
+    o = torch.zeros((B * Lq + B, ldo), device=q.device, dtype=BF16) if ldo > H * HD else \
+        torch.empty((B * Lq + B, ldo), device=q.device, dtype=BF16)
+    lse = torch.empty((B * H, Lq + 1), device=q.device, dtype=F32)
+    L.call("pvrl_mvit_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), ldo,
+           _ptr(lse), _stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, rel, B, H, Lq, k_thw, scale, o, d_o, lse):
+    """-> (dq, dk, dv bf16 like q / k / v, drel fp32 like rel)"""
+    L = lib()
+    assert d_o.dtype == BF16 and d_o.stride(0) == o.stride(0)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    drel = torch.empty_like(rel)
+    delta = torch.empty_like(lse)
+    L.call("pvrl_mvit_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), _ptr(d_o),
+           o.stride(0), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(drel), _stream())
+    return dq, dk, dv, drel
+
+
+def copy2d(src, dst, R, C, beta=0.0):
+    """dst[:R, :C] = beta*dst[:R, :C] + src[:R, :C] (fp32, row-major with their own leading dimensions)"""
+    L = lib()
+    L.call("pvrl_copy2d_f32", _ptr(src), src.stride(0), _ptr(dst), dst.stride(0) if dst.dim() > 1 else C, R, C,
+           float(beta), _stream())
+    return dst

@@ -1,0 +1,209 @@
+"""Parity checks of the MViTv2 kernels (csrc/mvit.hip, csrc/attn_pool.hip) against CPU fp32 restatements built from
+oracle/mvit_oracle.py pieces and autograd.  Inputs are rounded to bf16 first where the kernel consumes bf16, so the
+tolerances only cover accumulation order and the bf16 rounding of outputs (2^-8 relative)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import mvit_oracle as mo
+
+BF = torch.bfloat16
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(BF).float()
+
+
+def rel(a, b):
+    a = a.detach().float().cpu(); b = b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def check_mvit_im2col_ln():
+    from procedurevrl_amd import ops_mvit as om
+    g = torch.Generator().manual_seed(1)
+    out = []
+    B, T, H, W = 2, 4, 20, 24
+    x = bf(torch.randn(B, 3, T, H, W, generator=g))
+    a, thw = om.im2col3d(x.to(DEV), (3, 7, 7), (2, 4, 4), (1, 3, 3), 512)
+    xp = F.pad(x, (3, 3, 3, 3, 1, 1))
+    u = xp.unfold(2, 3, 2).unfold(3, 7, 4).unfold(4, 7, 4)            # [B,C,To,Ho,Wo,kt,kh,kw]
+    ref = u.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(-1, 441)
+    out.append(("im2col3d columns", rel(a[:, :441], ref), 1e-6))
+    out.append(("im2col3d zero padding", float(a[:, 441:].float().abs().max()), 0.0))
+    out.append(("im2col3d geometry", float(thw != (2, 5, 6)), 0.0))
+    for C, Cpad, M in [(96, 128, 300), (192, 256, 77), (384, 384, 65), (768, 768, 9)]:
+        xx = torch.randn(M, Cpad, generator=g); xx[:, C:] = 0
+        gm = 1 + 0.1 * torch.randn(C, generator=g); bt = 0.1 * torch.randn(C, generator=g)
+        dy = torch.randn(M, C, generator=g); dres = torch.randn(M, Cpad, generator=g)
+        xr = xx[:, :C].clone().requires_grad_(True); gr = gm.clone().requires_grad_(True); br = bt.clone().requires_grad_(True)
+        yr = F.layer_norm(xr, (C,), gr, br, 1e-6)
+        yr.backward(dy)
+        y, mean, rstd = om.ln_fwd(xx.to(DEV), C, gm.to(DEV), bt.to(DEV), 1e-6, out_dtype=torch.float32, Cpad=Cpad)
+        out.append((f"ln_g fwd C={C}", rel(y[:, :C], yr), 1e-5))
+        if Cpad > C:
+            out.append((f"ln_g fwd pad zeros C={C}", float(y[:, C:].abs().max()), 0.0))
+        dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+        dyp = torch.zeros(M, Cpad); dyp[:, :C] = dy
+        dx = om.ln_bwd(dyp.to(DEV), xx.to(DEV), C, mean, rstd, gm.to(DEV), dg, db, dres=dres.to(DEV), Cpad=Cpad)
+        out.append((f"ln_g bwd dx C={C}", rel(dx[:, :C], xr.grad + dres[:, :C]), 1e-5))
+        out.append((f"ln_g bwd dgamma C={C}", rel(dg, gr.grad), 1e-5))
+        out.append((f"ln_g bwd dbeta C={C}", rel(db, br.grad), 1e-5))
+        yb, _, _ = om.ln_fwd(xx.to(DEV), C, gm.to(DEV), bt.to(DEV), 1e-6, Cpad=Cpad)
+        out.append((f"ln_g fwd bf16 C={C}", rel(yb[:, :C], yr), 4e-3))
+    return out
+
+
+def _pool_ref(t, w, stride, thw, gm, bt):
+    """t [B, H, 1+L, 96] with cls FIRST (reference order) -> pooled, same convention"""
+    return mo.attention_pool(t, w, stride, thw, gm, bt)
+
+
+def check_mvit_pool():
+    from procedurevrl_amd import ops_mvit as om
+    g = torch.Generator().manual_seed(2)
+    out = []
+    for (B, H, thw, stride) in [(2, 2, (2, 8, 8), (1, 2, 2)), (1, 1, (3, 6, 10), (1, 1, 1)), (2, 4, (2, 8, 8), (1, 4, 4))]:
+        T, Hh, Ww = thw
+        L = T * Hh * Ww
+        dout = H * 96
+        ld = om.pad128(3 * dout)
+        qkv = torch.zeros(B * L + B, ld)
+        qkv[:, :3 * dout] = bf(torch.randn(B * L + B, 3 * dout, generator=g))
+        w = torch.randn(96, 1, 3, 3, 3, generator=g) * 0.2
+        gm = 1 + 0.1 * torch.randn(96, generator=g); bt = 0.1 * torch.randn(96, generator=g)
+        col0 = dout          # the "k" slice
+        # reference tensor [B, H, 1+L, 96], cls first
+        tok = qkv[:B * L, col0:col0 + dout].reshape(B, L, H, 96).permute(0, 2, 1, 3)
+        cls = qkv[B * L:, col0:col0 + dout].reshape(B, 1, H, 96).permute(0, 2, 1, 3)
+        tr = torch.cat((cls, tok), dim=2).clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True); gr = gm.clone().requires_grad_(True); br = bt.clone().requires_grad_(True)
+        yr, othw = _pool_ref(tr, wr, stride, thw, gr, br)
+        Lo = othw[0] * othw[1] * othw[2]
+        dy = bf(torch.randn(B * H, Lo + 1, 96, generator=g))
+        dyr = torch.cat((dy[:, Lo:], dy[:, :Lo]), dim=1).reshape(B, H, Lo + 1, 96)
+        yr.backward(dyr)
+        y, c = om.pool_fwd(qkv.to(DEV, BF), col0, B, H, thw, stride, w.reshape(96, 27).contiguous().to(DEV), gm.to(DEV),
+                           bt.to(DEV), 1e-6)
+        yr2 = yr.reshape(B * H, Lo + 1, 96)
+        out.append((f"pool fwd tokens {thw}/{stride}", rel(y[:, :Lo], yr2[:, 1:]), 6e-3))
+        out.append((f"pool fwd cls {thw}/{stride}", rel(y[:, Lo], yr2[:, 0]), 6e-3))
+        dqkv = torch.zeros(B * L + B, ld, device=DEV, dtype=BF)
+        dw = torch.zeros(96, 27, device=DEV); dg = torch.zeros(96, device=DEV); db = torch.zeros(96, device=DEV)
+        om.pool_bwd(dy.to(DEV, BF), c, qkv.to(DEV, BF), dqkv, col0, B, H, thw, stride,
+                    w.reshape(96, 27).contiguous().to(DEV), gm.to(DEV), 1e-6, dw, dg, db)
+        gt = tr.grad                                            # [B, H, 1+L, 96]
+        ref_tok = gt[:, :, 1:].permute(0, 2, 1, 3).reshape(B * L, dout)
+        ref_cls = gt[:, :, 0].reshape(B, dout)
+        out.append((f"pool bwd d tokens {thw}/{stride}", rel(dqkv[:B * L, col0:col0 + dout], ref_tok), 1.5e-2))
+        out.append((f"pool bwd d cls {thw}/{stride}", rel(dqkv[B * L:, col0:col0 + dout], ref_cls), 1.5e-2))
+        out.append((f"pool bwd other columns untouched {thw}", float(dqkv[:, :col0].float().abs().max()), 0.0))
+        out.append((f"pool bwd dw {thw}/{stride}", rel(dw, wr.grad.reshape(96, 27)), 1.5e-2))
+        out.append((f"pool bwd dgamma {thw}/{stride}", rel(dg, gr.grad), 1.5e-2))
+        out.append((f"pool bwd dbeta {thw}/{stride}", rel(db, br.grad), 1.5e-2))
+    return out
+
+
+def check_mvit_maxpool_rel():
+    from procedurevrl_amd import ops_mvit as om
+    g = torch.Generator().manual_seed(3)
+    out = []
+    B, thw, C, Cp = 2, (2, 8, 6), 192, 256
+    T, H, W = thw
+    L = T * H * W
+    x = torch.zeros(B * L + B, Cp); x[:, :C] = torch.randn(B * L + B, C, generator=g)
+    xr = torch.cat((x[B * L:, :C].reshape(B, 1, C), x[:B * L, :C].reshape(B, L, C)), dim=1).clone().requires_grad_(True)
+    yr = mo.pool_skip(xr, (1, 2, 2), thw)
+    Lo = yr.shape[1] - 1
+    dy = torch.randn(B * Lo + B, Cp, generator=g); dy[:, C:] = 0
+    yr.backward(torch.cat((dy[B * Lo:, :C].reshape(B, 1, C), dy[:B * Lo, :C].reshape(B, Lo, C)), dim=1))
+    y = om.maxpool_fwd(x.to(DEV), B, thw, 2, C)
+    out.append(("maxpool fwd tokens", rel(y[:B * Lo, :C], yr[:, 1:].reshape(B * Lo, C)), 0.0))
+    out.append(("maxpool fwd cls", rel(y[B * Lo:, :C], yr[:, 0]), 0.0))
+    dx = om.maxpool_bwd(x.to(DEV), dy.to(DEV), B, thw, 2, C)
+    out.append(("maxpool bwd tokens", rel(dx[:B * L, :C], xr.grad[:, 1:].reshape(B * L, C)), 1e-6))
+    out.append(("maxpool bwd cls", rel(dx[B * L:, :C], xr.grad[:, 0]), 0.0))
+    # relative-position tables
+    for q_thw, k_thw in [((2, 8, 8), (2, 2, 2)), ((2, 4, 4), (2, 4, 4)), ((3, 4, 8), (3, 4, 2))]:
+        BH = 3
+        Lq = q_thw[0] * q_thw[1] * q_thw[2]
+        Q = bf(torch.randn(BH, Lq + 1, 96, generator=g))
+        nh = 2 * max(q_thw[1], k_thw[1]) - 1; nw = 2 * max(q_thw[2], k_thw[2]) - 1; nt = 2 * max(q_thw[0], k_thw[0]) - 1
+        Rh = torch.randn(nh, 96, generator=g) * 0.1; Rw = torch.randn(nw, 96, generator=g) * 0.1; Rt = torch.randn(nt, 96, generator=g) * 0.1
+        ih = mo.rel_index(q_thw[1], k_thw[1]); iw = mo.rel_index(q_thw[2], k_thw[2]); it = mo.rel_index(q_thw[0], k_thw[0])
+        Qr = Q.clone().requires_grad_(True); Rhr = Rh.clone().requires_grad_(True); Rwr = Rw.clone().requires_grad_(True); Rtr = Rt.clone().requires_grad_(True)
+        rq = Qr[:, :Lq].reshape(BH, *q_thw, 96)
+        ref = torch.cat((torch.einsum("bthwc,hkc->bthwk", rq, Rhr[ih]), torch.einsum("bthwc,wkc->bthwk", rq, Rwr[iw]),
+                         torch.einsum("bthwc,tkc->bthwk", rq, Rtr[it])), dim=-1).reshape(BH, Lq, -1)
+        d = lambda t: t.to(DEV)
+        di = lambda t: t.to(DEV, torch.int32).contiguous()
+        relg = om.rel_fwd(d(Q).to(BF), BH, q_thw, k_thw, d(Rh), d(Rw), d(Rt), di(ih), di(iw), di(it))
+        out.append((f"rel fwd {q_thw}x{k_thw}", rel(relg, ref), 1e-5))
+        drel = torch.randn(ref.shape, generator=g)
+        ref.backward(drel)
+        dQ0 = bf(torch.randn(BH, Lq + 1, 96, generator=g))
+        dQ = d(dQ0).to(BF)
+        dRh = torch.zeros(nh, 96, device=DEV); dRw = torch.zeros(nw, 96, device=DEV); dRt = torch.zeros(nt, 96, device=DEV)
+        om.rel_bwd(d(drel), d(Q).to(BF), dQ, BH, q_thw, k_thw, d(Rh), d(Rw), d(Rt), di(ih), di(iw), di(it), dRh, dRw, dRt)
+        out.append((f"rel bwd dQ {q_thw}x{k_thw}", rel(dQ, dQ0 + Qr.grad), 6e-3))
+        out.append((f"rel bwd dRh {q_thw}x{k_thw}", rel(dRh, Rhr.grad), 1e-4))
+        out.append((f"rel bwd dRw {q_thw}x{k_thw}", rel(dRw, Rwr.grad), 1e-4))
+        out.append((f"rel bwd dRt {q_thw}x{k_thw}", rel(dRt, Rtr.grad), 1e-4))
+    return out
+
+
+def _attn_ref(q, k, v, relb, q_thw, k_thw, scale):
+    """q [BH, Lq+1, 96], k / v [BH, Lk+1, 96] (cls LAST), relb [BH, Lq, J] -> out [BH, Lq+1, 96] incl. residual pooling"""
+    BH, Lq1, _ = q.shape
+    Lq, Lk = Lq1 - 1, k.shape[1] - 1
+    kt, kh, kw = k_thw
+    s = (q * scale) @ k.transpose(1, 2)
+    j = torch.arange(Lk)
+    bias = relb[:, :, (j // kw) % kh] + relb[:, :, kh + j % kw] + relb[:, :, kh + kw + j // (kw * kh)]
+    s = torch.cat((torch.cat((s[:, :Lq, :Lk] + bias, s[:, :Lq, Lk:]), dim=2), s[:, Lq:]), dim=1)
+    o = s.softmax(-1) @ v
+    return torch.cat((o[:, :Lq] + q[:, :Lq], o[:, Lq:]), dim=1)
+
+
+def check_mvit_attention():
+    from procedurevrl_amd import ops_mvit as om
+    g = torch.Generator().manual_seed(4)
+    out = []
+    for (B, H, q_thw, k_thw) in [(2, 2, (2, 8, 8), (2, 2, 2)), (1, 1, (2, 6, 6), (2, 6, 6)), (2, 4, (1, 3, 5), (1, 3, 5)),
+                                 (1, 2, (4, 8, 8), (4, 4, 4))]:
+        BH = B * H
+        Lq = q_thw[0] * q_thw[1] * q_thw[2]; Lk = k_thw[0] * k_thw[1] * k_thw[2]
+        J = k_thw[1] + k_thw[2] + k_thw[0]
+        q = bf(torch.randn(BH, Lq + 1, 96, generator=g)); k = bf(torch.randn(BH, Lk + 1, 96, generator=g))
+        v = bf(torch.randn(BH, Lk + 1, 96, generator=g)); relb = torch.randn(BH, Lq, J, generator=g)
+        scale = 96 ** -0.5
+        qr, kr, vr, rr = (t.clone().requires_grad_(True) for t in (q, k, v, relb))
+        ref = _attn_ref(qr, kr, vr, rr, q_thw, k_thw, scale)
+        ldo = om.pad128(H * 96)
+        d = lambda t: t.to(DEV)
+        o, lse = om.attn_fwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), d(relb), B, H, Lq, k_thw, scale, ldo)
+        # token-major [B*Lq + B, ldo] -> [BH, Lq+1, 96]
+        ot = torch.cat((o[:B * Lq, :H * 96].float().reshape(B, Lq, H, 96), o[B * Lq:, :H * 96].float().reshape(B, 1, H, 96)), dim=1)
+        ot = ot.permute(0, 2, 1, 3).reshape(BH, Lq + 1, 96)
+        tag = f"B{B} H{H} q{q_thw} k{k_thw}"
+        out.append((f"attn fwd {tag}", rel(ot, ref), 6e-3))
+        if ldo > H * 96:
+            out.append((f"attn fwd pad zero {tag}", float(o[:, H * 96:].float().abs().max()), 0.0))
+        do_ = bf(torch.randn(BH, Lq + 1, 96, generator=g))
+        ref.backward(do_)
+        dot = do_.reshape(B, H, Lq + 1, 96).permute(0, 2, 1, 3)             # [B, Lq+1, H, 96]
+        d_o = torch.zeros(B * Lq + B, ldo)
+        d_o[:B * Lq, :H * 96] = dot[:, :Lq].reshape(B * Lq, H * 96)
+        d_o[B * Lq:, :H * 96] = dot[:, Lq].reshape(B, H * 96)
+        dq, dk, dv, drel = om.attn_bwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), d(relb), B, H, Lq, k_thw, scale, o,
+                                       d(d_o).to(BF), lse)
+        out.append((f"attn bwd dq {tag}", rel(dq, qr.grad), 1.5e-2))
+        out.append((f"attn bwd dk {tag}", rel(dk, kr.grad), 1.5e-2))
+        out.append((f"attn bwd dv {tag}", rel(dv, vr.grad), 1.5e-2))
+        out.append((f"attn bwd drel {tag}", rel(drel, rr.grad), 1.5e-2))
+    return out
+
+
+ALL_CHECKS = [check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]

@@ -14,10 +14,11 @@ def main():
     import torch
     import kernel_checks as kc
     import e2e_checks as ec
+    import mvit_checks as mc
     names = sys.argv[1:]
     rows = []
     ok = True
-    for chk in kc.ALL_CHECKS + ec.ALL_CHECKS:
+    for chk in kc.ALL_CHECKS + ec.ALL_CHECKS + mc.ALL_CHECKS:
         if names and not any(n in chk.__name__ for n in names):
             continue
         t0 = time.time()
