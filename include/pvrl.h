@@ -210,6 +210,11 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float*
                        int64_t kt, int64_t kh, int64_t kw, float scale, const void* o, const void* d_o, int64_t ldo,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, float* drel, void* stream);
 
+/* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
+ * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */
+int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R, int64_t C,
+                              void* stream);
+
 /* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
 int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);
 

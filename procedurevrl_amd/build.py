@@ -45,7 +45,7 @@ def build_model(cfg, gpu_id=None):
         assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
     else:
         assert cfg.NUM_GPUS == 0, "Cuda is not available. Please set `NUM_GPUS: 0 for running on CPUs."
-    from . import vit  # noqa: F401  (registers the models)
+    from . import vit, mvit  # noqa: F401  (register the models)
     model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
     if cfg.NUM_GPUS:
         cur_device = torch.cuda.current_device() if gpu_id is None else gpu_id

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 }
 
 // W fp32 [R][C] -> Wb bf16 [R][C] and Wt bf16 [C][R] in one pass (both GEMM operand copies of a weight matrix)
+// (ldo / ldt: leading dimensions of the two copies -- larger than C / R when the copies live in zero-padded buffers)
 __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                          bf16* __restrict__ out_t, int R, int C) {
+                                                          bf16* __restrict__ out_t, int R, int C, long ldo, long ldt) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -166,14 +167,14 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     const int r = r0 + ty + 8 * k, c = c0 + tx;
     const float v = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
     tile[ty + 8 * k][tx] = v;
-    if (r < R && c < C) out[(long)r * C + c] = (bf16)v;
+    if (r < R && c < C) out[(long)r * ldo + c] = (bf16)v;
   }
   __syncthreads();
   if (out_t) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < R && c < C) out_t[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+      if (r < R && c < C) out_t[(long)c * ldt + r] = (bf16)tile[tx][ty + 8 * k];
     }
   }
 }
@@ -286,7 +287,16 @@ extern "C" int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, i
 extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream) {
   if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C);
+                     (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)C, (long)R);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R,
+                                         int64_t C, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || ldo < C || (out_t && ldt < R)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
+                     (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)ldo, (long)ldt);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -104,6 +104,27 @@ class VisionTransformer(nn.Module):
         self.norm = norm_layer(embed_dim)
         self.ln_eps = self.norm.eps
 
+        self._init_heads(embed_dim, label_emb, mlp, text_model, num_seg, num_classes, cfg)
+        trunc_normal_(self.pos_embed, std=0.02)
+        trunc_normal_(self.cls_token, std=0.02)
+        # vit.py:272-281 zeroes temporal_fc of EVERY block (the ModuleList itself consumes i == 0)
+        if depth != 0 and attention_type == "divided_space_time":
+            for blk in self.blocks:
+                nn.init.constant_(blk.temporal_fc.weight, 0)
+                nn.init.constant_(blk.temporal_fc.bias, 0)
+
+        self.engine = EncoderEngine(self)
+        self.weight_cache = self.engine._weight
+        self._grad_store = None
+        self._label_cache = None
+        if hasattr(self, "order_tfm"):
+            self.order_tfm.bind(self)
+        if hasattr(self, "text_model"):
+            self.text_model.bind(self)
+
+    def _init_heads(self, embed_dim, label_emb, mlp, text_model, num_seg, num_classes, cfg):
+        """Projection head, step embeddings, order transformer and frozen text tower (vit.py:228-267; the MViT wrapper
+        lib/models/mvit.py:72-107 is line-for-line the same block)."""
         self.mlp = mlp
         self.label = label_emb
         if not (isinstance(label_emb, str) and label_emb == ""):   # pre-training (vit.py:231-237)
@@ -141,22 +162,6 @@ class VisionTransformer(nn.Module):
             self.num_seg = num_seg
             self.order_tfm = OrderTransformer(num_seg=num_seg, tfm_layers=self.order_tfm_layers, dropout=cfg.MODEL.DROP_E,
                                               hidden_size=self.head.weight.shape[0], cfg=cfg)
-        trunc_normal_(self.pos_embed, std=0.02)
-        trunc_normal_(self.cls_token, std=0.02)
-        # vit.py:272-281 zeroes temporal_fc of EVERY block (the ModuleList itself consumes i == 0)
-        if depth != 0 and attention_type == "divided_space_time":
-            for blk in self.blocks:
-                nn.init.constant_(blk.temporal_fc.weight, 0)
-                nn.init.constant_(blk.temporal_fc.bias, 0)
-
-        self.engine = EncoderEngine(self)
-        self.weight_cache = self.engine._weight
-        self._grad_store = None
-        self._label_cache = None
-        if hasattr(self, "order_tfm"):
-            self.order_tfm.bind(self)
-        if hasattr(self, "text_model"):
-            self.text_model.bind(self)
 
     # ----------------------------------------------------------------------------- plumbing
     def _init_weights(self, m):
