@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
+    ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
+                    help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
     args = ap.parse_args()
 
     import torch
@@ -69,6 +71,24 @@ def main():
     cfg.MODEL.DROP_PATH = 0.1
     cfg.DEV.MATCH_LANG_EMB = True
     cfg.DATA.NUM_FRAMES = args.frames
+    if args.arch == "mvit":        # configs/HowTo100M/procedurevrl_mvitv2_adamw.yaml (MViTv2-S)
+        if args.frames == 8:
+            args.frames = 16
+        cfg.MODEL.MODEL_NAME = "MViT"
+        cfg.MODEL.ARCH = "mvit"
+        cfg.DATA.NUM_FRAMES = args.frames
+        cfg.DATA.INPUT_CHANNEL_NUM = [3]
+        cfg.DATA.TRAIN_CROP_SIZE = cfg.DATA.TEST_CROP_SIZE = 224
+        mv = cfg.MVIT
+        mv.ZERO_DECAY_POS_CLS, mv.USE_ABS_POS, mv.REL_POS_SPATIAL, mv.REL_POS_TEMPORAL = False, False, True, True
+        mv.DEPTH, mv.NUM_HEADS, mv.EMBED_DIM = 16, 1, 96
+        mv.PATCH_KERNEL, mv.PATCH_STRIDE, mv.PATCH_PADDING = [3, 7, 7], [2, 4, 4], [1, 3, 3]
+        mv.DROPPATH_RATE, mv.MODE, mv.CLS_EMBED_ON = 0.0, "conv", True
+        mv.DIM_MUL = [[1, 2.0], [3, 2.0], [14, 2.0]]
+        mv.HEAD_MUL = [[1, 2.0], [3, 2.0], [14, 2.0]]
+        mv.POOL_KVQ_KERNEL, mv.POOL_KV_STRIDE_ADAPTIVE = [3, 3, 3], [1, 8, 8]
+        mv.POOL_Q_STRIDE = [[i, 1, 2, 2] if i in (1, 3, 14) else [i, 1, 1, 1] for i in range(16)]
+        mv.DIM_MUL_IN_ATT, mv.RESIDUAL_POOLING = True, True
     cfg.NUM_GPUS = 1
     cfg.SOLVER.OPTIMIZING_METHOD = "adamw"
     cfg.SOLVER.BASE_LR = 5e-5
@@ -77,10 +97,11 @@ def main():
     cfg.TRAIN.LABEL_EMB = synthetic_label_emb(args.classes, 512, seed=0)   # tensor instead of a path (synthetic)
     model = build_model(cfg, gpu_id=local_rank)
     vt = model.model
-    with torch.no_grad():   # randomise the branches that the reference zero-initialises so no kernel is idle
-        for blk in vt.blocks:
-            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
-        torch.nn.init.trunc_normal_(vt.time_embed, std=0.02)
+    if args.arch == "vit":
+        with torch.no_grad():   # randomise the branches that the reference zero-initialises so no kernel is idle
+            for blk in vt.blocks:
+                torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+            torch.nn.init.trunc_normal_(vt.time_embed, std=0.02)
     model.train()
     if args.no_wgrad_overlap:
         vt.engine.overlap_wgrad = False
@@ -134,11 +155,15 @@ def main():
         clips = B * world * args.steps
         value = clips / dt
         wtrain = W_TRAIN_GFLOP.get(args.frames, W_TRAIN_GFLOP[8] * args.frames / 8) * 1e9
+        if args.arch == "mvit":
+            wtrain = 3 * 128.45e9 * args.frames / 16      # MViTv2-S forward 128.45 GFLOP/clip at 16 frames
         out = {
-            "metric": "training clips/sec (8f x 224^2, ViT-B TimeSformer)", "value": round(value, 3), "unit": "clips/s",
+            "metric": "training clips/sec (8f x 224^2, ViT-B TimeSformer)" if args.arch == "vit" else
+                      f"training clips/sec ({args.frames}f x 224^2, MViTv2-S)", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"TimeSformer ViT-B {args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
+            "config": {"workload": ("MViTv2-S " if args.arch == "mvit" else "TimeSformer ViT-B ") +
+                                   f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": float(loss.item()),

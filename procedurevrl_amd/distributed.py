@@ -142,7 +142,7 @@ class GradReducer:
 
     def _block_range(self, i):
         gs = self.vt.grad_store()
-        pre = f"blocks.{i}."
+        pre = f"{getattr(self.vt, 'block_prefix', 'blocks.')}{i}."
         idx = [k for k, n in enumerate(gs.names) if n.startswith(pre)]
         a = gs.offsets[idx[0]]
         last = idx[-1]
@@ -152,7 +152,7 @@ class GradReducer:
     def _hook(self, i):
         a, b = self._block_range(i)
         gs = self.vt.grad_store()
-        side = self.vt.engine._side if self.vt.engine.overlap_wgrad else None
+        side = getattr(self.vt.engine, "_side", None) if getattr(self.vt.engine, "overlap_wgrad", False) else None
         if side is not None and gs.flat.is_cuda:
             # block i's weight gradients were produced on the side stream, its LayerNorm gradients on the main one:
             # order the collective after both

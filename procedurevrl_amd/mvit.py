@@ -486,6 +486,8 @@ class VisionTransformer(_StepMatchingModel):
         if hasattr(self, "text_model"):
             self.text_model.bind(self)
 
+    block_prefix = "video_encoder.blocks."      # distributed.GradReducer: per-block slices of the flat gradient buffer
+
     @property
     def cls_token(self):
         return self.video_encoder.cls_token

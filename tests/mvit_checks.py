@@ -285,4 +285,46 @@ def check_mvit_s_features():
     return [("mvit-S features vs reference", rel(feat, g["feat"]), 1.5e-2)]
 
 
-ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
+def check_mvit_pretrain_steps():
+    """The registered `MViT` model through the reference's call surface: model([inputs, meta]) -> (pred, teacher, mse)
+    with the frozen text tower and the order transformer, KL + MSE loss, backward, fused AdamW -- five steps on one
+    fixed batch of 2 videos x 9 clips: finite everywhere and the loss goes down."""
+    from procedurevrl_amd.build import build_model
+    from procedurevrl_amd.datasets import SyntheticHowTo100M, synthetic_label_emb
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+    from procedurevrl_amd.vit import pretrain_loss
+    g = _load("mvit_small")
+    cfg = _mvit_cfg(g["mvit"], 4, 64, K=128)
+    cfg.MODEL.TEXT_MODEL = "clip_vit_b_16"
+    cfg.SYNTHETIC.TEXT_LAYERS = 2
+    cfg.DEV.ORDER_PRETRAIN_ENABLED = True
+    cfg.SOLVER.OPTIMIZING_METHOD = "adamw"
+    cfg.SOLVER.BASE_LR = 1e-4
+    cfg.TRAIN.LABEL_EMB = synthetic_label_emb(128, 512, seed=1)
+    torch.manual_seed(0)
+    model = build_model(cfg, gpu_id=0).train()
+    model.model.text_model.eval()
+    opt = construct_optimizer(model, cfg)
+    set_lr(opt, 1e-4)
+    ds = SyntheticHowTo100M(cfg, num_videos=2, seed=3)
+    items = [ds[i] for i in range(2)]
+    inputs = torch.stack([it[0] for it in items]).to(DEV)
+    meta = {k: torch.stack([it[3][k] for it in items]).to(DEV) for k in ("clip_text_ids", "clip_vis_feat")}
+    meta = {k: v.view(-1, v.shape[-1]) for k, v in meta.items()}
+    losses = []
+    for _ in range(5):
+        pred, teacher, mse = model([inputs, meta])
+        loss, l1, l2 = pretrain_loss(pred, teacher, mse, cfg)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        model.model.adopt_grads()
+        opt.step()
+        losses.append(float(loss))
+    gs = model.model.grad_store()
+    return [("mvit pretraining: non-finite loss", float(not all(math.isfinite(v) for v in losses)), 0.0),
+            ("mvit pretraining: non-finite gradient", float(not bool(torch.isfinite(gs.flat).all())), 0.0),
+            ("mvit pretraining: pred rows = 13 b", float(pred.shape[0] != 26), 0.0),
+            ("mvit pretraining: loss after 5 steps / first loss", losses[-1] / losses[0], 0.999)]
+
+
+ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]

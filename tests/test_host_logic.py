@@ -150,3 +150,54 @@ def test_test_meter_multi_view_ensemble():
         stats = m.finalize_metrics(ks=(1, 5))
         top1 = (ref.argmax(1) == labels_v).float().mean().item() * 100
         assert stats["top1_acc"] == "{:.2f}".format(top1)
+
+
+def _mvit_cfg_from_golden(name, frames, crop):
+    import os
+    from procedurevrl_amd.config import get_cfg
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", name + ".pt"), weights_only=False)
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "MViT"
+    cfg.MODEL.PRETRAINED = False
+    cfg.DATA.NUM_FRAMES = frames
+    cfg.DATA.TRAIN_CROP_SIZE = cfg.DATA.TEST_CROP_SIZE = crop
+    cfg.DATA.INPUT_CHANNEL_NUM = [3]
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.NUM_GPUS = 0
+    cfg.TRAIN.LABEL_EMB = synthetic_label_emb(16, 512, seed=1)
+    for k, v in g["mvit"].items():
+        setattr(cfg.MVIT, k, v)
+    return cfg, g
+
+
+def test_mvit_module_tree_matches_reference_shapes():
+    """MViTv2-S (16 x 224^2): every parameter name and shape of the reference MViT_encoder (tests/golden/mvit_s.pt),
+    under the reference wrapper's prefix `model.video_encoder.`; geometry of the four stages."""
+    from procedurevrl_amd.build import MODEL_REGISTRY
+    from procedurevrl_amd import mvit  # noqa: F401
+    cfg, g = _mvit_cfg_from_golden("mvit_s", 16, 224)
+    model = MODEL_REGISTRY.get("MViT")(cfg)
+    sd = model.state_dict()
+    got = {k[len("model.video_encoder."):]: tuple(v.shape) for k, v in sd.items() if k.startswith("model.video_encoder.")}
+    assert got == {k: tuple(v) for k, v in g["shapes"].items()}
+    assert {"model.head.weight", "model.head.bias"} <= set(sd)
+    plan = model.model.video_encoder.plan
+    assert [(b["dim"], b["dim_out"], b["heads"]) for b in plan][:4] == [(96, 96, 1), (96, 192, 2), (192, 192, 2), (192, 384, 4)]
+    assert plan[0]["in_thw"] == [8, 56, 56] and plan[0]["stride_kv"] == [1, 8, 8]
+    assert plan[1]["stride_q"] == [1, 2, 2] and plan[1]["stride_kv"] == [1, 4, 4]
+    assert plan[14]["in_thw"] == [8, 14, 14] and plan[15]["in_thw"] == [8, 7, 7] and plan[15]["dim_out"] == 768
+    import math
+    assert sum(p.numel() for p in model.model.video_encoder.parameters()) == sum(math.prod(v) for v in g["shapes"].values()) == 34230144   # 34.23 M
+
+
+def test_mvit_unsupported_settings_raise():
+    from procedurevrl_amd import mvit
+    cfg, _ = _mvit_cfg_from_golden("mvit_small", 4, 64)
+    cfg.MVIT.MODE = "max"
+    with pytest.raises(NotImplementedError):
+        mvit.MViT(cfg)
+    cfg, _ = _mvit_cfg_from_golden("mvit_small", 4, 64)
+    cfg.MVIT.DROPPATH_RATE = 0.2
+    with pytest.raises(NotImplementedError):
+        mvit.MViT(cfg)
