@@ -18,7 +18,7 @@ namespace {
 constexpr int D = 96, NCB = 6;          // head_dim, 16-column blocks per row
 constexpr int KT = 32;                  // keys (or queries) per LDS tile
 constexpr int TILE_BYTES = KT * D * 2;  // 6 KiB
-constexpr int JMAX = 40;                // kh + kw + kt <= 36 (14 + 14 + 8)
+constexpr int JMAX = 40;                // kh + kw + kt <= 36 (14 + 14 + 8); the d-rel MFMA covers 48 columns
 constexpr int MAXKEYS = 1664;           // 8*14*14 + 1 = 1569 keys, rounded
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
 __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   __shared__ float rel_s[4][16][JMAX];
-  __shared__ float drel_s[4][16][JMAX];
+  // E^T tile: [48 rel columns][32 keys] 0/1 indicators (bf16) of the key tile, double buffered: d rel = dS . E by MFMA
+  __shared__ __attribute__((aligned(16))) bf16 et_s[2][48][KT];
   __shared__ unsigned kdec_s[MAXKEYS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
@@ -226,7 +227,6 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
     const int qi = e / JMAX, j = e - qi * JMAX;
     const int qq = blockIdx.x * 64 + wave * 16 + qi;
     rel_s[wave][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
-    drel_s[wave][qi][j] = 0.f;
   }
   const bf16* kb = p.k + (long)bh * Lk1 * D;
   const bf16* vb = p.v + (long)bh * Lk1 * D;
@@ -236,6 +236,18 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   tile_gload(rv, vb, D, 0, Lk1, tid);
   tile_lstore(rk, smem, tid);
   tile_lstore(rv, smem + TILE_BYTES, tid);
+  __syncthreads();          // kdec_s complete
+  auto build_et = [&](int t) {
+    for (int e = tid; e < 48 * KT; e += 256) {
+      const int j = e / KT, kk = e - j * KT;
+      const int key = t * KT + kk;
+      const unsigned kd = key < MAXKEYS ? kdec_s[key] : 0xffffffffu;
+      const bool hit = kd != 0xffffffffu && (j == (int)(kd & 255) || j == (int)((kd >> 8) & 255) || j == (int)((kd >> 16) & 255));
+      et_s[t & 1][j][kk] = (bf16)(hit ? 1.f : 0.f);
+    }
+  };
+  const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
+  if (qpatch_any) build_et(0);
   __syncthreads();
 
   const float c = p.scale * LOG2E;
@@ -243,7 +255,9 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* relq = rel_s[wave][i];
-  float* drq = drel_s[wave][i];
+  f32x4 dracc[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) dracc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < ntiles; ++t) {
     const char* Kb = smem + (t & 1) * 2 * TILE_BYTES;
@@ -271,11 +285,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
         const float pr = (key < Lk1 && query < Lq1) ? __builtin_amdgcn_exp2f(x - lse2) : 0.f;
         const float g = pr * (dp[r] - dl);
         ds[u * 4 + r] = g;
-        if (hasb) {
-          atomicAdd(drq + (kd & 255), g);
-          atomicAdd(drq + ((kd >> 8) & 255), g);
-          atomicAdd(drq + ((kd >> 16) & 255), g);
-        }
+        (void)hasb;
       }
     }
     union { unsigned u[4]; bf16x8 v; } sf;
@@ -284,10 +294,21 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt)
       dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
+    if (qpatch_any) {
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) {
+        // A = E^T rows j = 16 jt + i, k-slots = the tile's keys in the same permuted order as sf (4q4+e | 16+4q4+e)
+        union { struct { u32x2 a, b; } s2; bf16x8 v; } ef;
+        ef.s2.a = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][4 * q4]);
+        ef.s2.b = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][16 + 4 * q4]);
+        dracc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef.v, sf.v, dracc[jt], 0, 0, 0);
+      }
+    }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
       tile_lstore(rk, nb, tid);
       tile_lstore(rv, nb + TILE_BYTES, tid);
+      if (qpatch_any) build_et(t + 1);
     }
     __syncthreads();
   }
@@ -304,11 +325,16 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
       *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
     }
   }
-  // the wave's LDS atomics are complete once all its lanes reach this point (same wave, in-order LDS)
-  for (int e = lane; e < 16 * p.J; e += 64) {
-    const int qi = e / p.J, j = e - qi * p.J;
-    const int qq = blockIdx.x * 64 + wave * 16 + qi;
-    if (qq < p.Lq) p.drel[((long)bh * p.Lq + qq) * p.J + j] = drel_s[wave][qi][j];
+  // dracc[jt][r] = d rel[query][16 jt + 4 q4 + r] (cls-query rows hold the un-biased scores' dS: not part of rel)
+  if (qpatch) {
+    float* dr = p.drel + ((long)bh * p.Lq + query) * p.J;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * q4 + r;
+        if (j < p.J) dr[j] = dracc[jt][r];
+      }
   }
 }
 

@@ -551,13 +551,14 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
 }
 
 // dR_axis[idx[coord][j]][c] += sum over all (bh, q with that axis coordinate) drel[bh][q][off + j] * Q[bh][q][c]
-// grid (q_n, k_n); block 96 channels x 2 slices.
+// grid (q_n, chunks of the (bh, other) range); block = 96 channels x 2 slices; a thread keeps all k_n <= 16 sums of its channel.
+constexpr int REL_KMAX = 16;
 __global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const bf16* __restrict__ Q,
                                                             RelGeom g, int axis, const int* __restrict__ idx,
                                                             float* __restrict__ dR) {
-  __shared__ float red[HD];
+  __shared__ float red[REL_KMAX][HD];
   const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
-  const int coord = blockIdx.x, j = blockIdx.y;
+  const int coord = blockIdx.x;
   const int J = g.kh + g.kw + g.kt;
   const int Lq = g.qt * g.qh * g.qw;
   int n_other, off, kn;
@@ -565,19 +566,34 @@ __global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restr
   else if (axis == 1) { n_other = g.qt * g.qh; off = g.kh; kn = g.kw; }
   else { n_other = g.qh * g.qw; off = g.kh + g.kw; kn = g.kt; }
   const long n = (long)g.BH * n_other;
-  float a = 0.f;
-  for (long i = sl; i < n; i += 2) {
+  const long per = (n + gridDim.y - 1) / gridDim.y;
+  const long i0 = (long)blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+  float a[REL_KMAX];
+#pragma unroll
+  for (int j = 0; j < REL_KMAX; ++j) a[j] = 0.f;
+  for (long i = i0 + sl; i < i1; i += 2) {
     const int o = (int)(i % n_other);
     const long bh = i / n_other;
     int q;
     if (axis == 0) { const int t = o / g.qw, x = o % g.qw; q = (t * g.qh + coord) * g.qw + x; }
     else if (axis == 1) { q = o * g.qw + coord; }                 // o = t*qh + y
     else { q = coord * g.qh * g.qw + o; }
-    a = fmaf(drel[(bh * Lq + q) * J + off + j], (float)Q[(bh * (Lq + 1) + q) * HD + c], a);
+    const float qv = (float)Q[(bh * (Lq + 1) + q) * HD + c];
+    const float* d = drel + (bh * Lq + q) * J + off;
+#pragma unroll
+    for (int j = 0; j < REL_KMAX; ++j)
+      if (j < kn) a[j] = fmaf(d[j], qv, a[j]);
   }
-  if (sl == 1) red[c] = a;
+  if (sl == 1) {
+#pragma unroll
+    for (int j = 0; j < REL_KMAX; ++j) red[j][c] = a[j];
+  }
   __syncthreads();
-  if (sl == 0) atomicAdd(dR + (long)idx[coord * kn + j] * HD + c, a + red[c]);
+  if (sl == 0) {
+#pragma unroll
+    for (int j = 0; j < REL_KMAX; ++j)
+      if (j < kn) atomicAdd(dR + (long)idx[coord * kn + j] * HD + c, a[j] + red[j][c]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- misc
@@ -768,12 +784,18 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
   hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
                      (bf16*)dQ);
   PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qh, (unsigned)kh), dim3(192), 0, s, drel, (const bf16*)Q, g, 0,
-                     idx_h, dRh);
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qw, (unsigned)kw), dim3(192), 0, s, drel, (const bf16*)Q, g, 1,
-                     idx_w, dRw);
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qt, (unsigned)kt), dim3(192), 0, s, drel, (const bf16*)Q, g, 2,
-                     idx_t, dRt);
+  if (kh > REL_KMAX || kw > REL_KMAX || kt > REL_KMAX) return PVRL_EINVAL;
+  auto chunks = [&](int64_t qn, int64_t n_other) {     // ~2048 blocks per axis, at least 64 (bh, other) pairs each
+    int64_t c = 2048 / qn, m = (BH * n_other + 63) / 64;
+    if (c > m) c = m;
+    return (unsigned)(c < 1 ? 1 : c);
+  };
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qh, chunks(qh, qt * qw)), dim3(192), 0, s, drel, (const bf16*)Q,
+                     g, 0, idx_h, dRh);
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qw, chunks(qw, qt * qh)), dim3(192), 0, s, drel, (const bf16*)Q,
+                     g, 1, idx_w, dRw);
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qt, chunks(qt, qh * qw)), dim3(192), 0, s, drel, (const bf16*)Q,
+                     g, 2, idx_t, dRt);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
