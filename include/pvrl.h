@@ -203,12 +203,15 @@ int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, in
 
 /* Pooling attention (attention.py:404-442): softmax(scale q k^T + rel bias) v (+ q, residual pooling) for head_dim 96;
  * q [B*H][Lq+1][96], k / v [B*H][kt*kh*kw+1][96]; o / d_o token-major [B*Lq + B][ldo] with column h*96 + d.
- * lse / delta fp32 [B*H][Lq+1]; drel fp32 [B*H][Lq][kh+kw+kt]. */
+ * lse / delta fp32 [B*H][Lq+1]; drel fp32 [B*H][Lq][kh+kw+kt].  The dK / dV kernel shares the query range out over
+ * workgroups (fp32 partials in `workspace`, pvrl_mvit_attn_bwd_workspace_bytes) and reduces deterministically. */
 int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
                        int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo, float* lse, void* stream);
+int64_t pvrl_mvit_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw);
 int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
                        int64_t kt, int64_t kh, int64_t kw, float scale, const void* o, const void* d_o, int64_t ldo,
-                       const float* lse, float* delta, void* dq, void* dk, void* dv, float* drel, void* stream);
+                       const float* lse, float* delta, void* dq, void* dk, void* dv, float* drel, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
  * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */

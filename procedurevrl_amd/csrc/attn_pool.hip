@@ -31,6 +31,7 @@ struct PA {
   float* delta;                                  // [BH][Lq+1]
   bf16* dq; bf16* dk; bf16* dv;                  // [BH][L+1][96]
   float* drel;                                   // [BH][Lq][J]
+  float* kv_part;                                // [nsplit][2][BH][Lk+1][96] fp32 partial dK / dV
   int B, H, Lq, Lk, kt, kh, kw, J;
   float scale;
 };
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
   const unsigned kd = key_dec(p, key);
   const bool kpatch = kd != 0xffffffffu;
   const int j0 = kd & 255, j1 = (kd >> 8) & 255, j2 = (kd >> 16) & 255;
-  const int ntiles = (Lq1 + KT - 1) / KT;
+  const int ntiles_all = (Lq1 + KT - 1) / KT;
+  const int per = (ntiles_all + gridDim.z - 1) / gridDim.z;          // query tiles of this z-slice
+  const int tbeg = blockIdx.z * per, ntiles = min(ntiles_all, tbeg + per);
   const bf16* qb = p.q + (long)bh * Lq1 * D;
 
   // the dO tile is gathered from the token-major activation: rows (b, query) / cls row, columns h*96 ..
@@ -388,11 +391,11 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     }
   };
   TileRegs rq, rd;
-  tile_gload(rq, qb, D, 0, Lq1, tid);
-  load_do(rd, 0);
-  tile_lstore(rq, smem, tid);
-  tile_lstore(rd, smem + TILE_BYTES, tid);
-  load_side(0, 0);
+  tile_gload(rq, qb, D, tbeg * KT, Lq1, tid);
+  load_do(rd, tbeg * KT);
+  tile_lstore(rq, smem + (tbeg & 1) * 2 * TILE_BYTES, tid);
+  tile_lstore(rd, smem + (tbeg & 1) * 2 * TILE_BYTES + TILE_BYTES, tid);
+  load_side(tbeg & 1, tbeg * KT);
   __syncthreads();
 
   const float c = p.scale * LOG2E;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tbeg; t < ntiles; ++t) {
     const int buf = t & 1;
     const char* Qb = smem + buf * 2 * TILE_BYTES;
     const char* Db = Qb + TILE_BYTES;
@@ -449,16 +452,31 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     __syncthreads();
   }
   if (key < Lk1) {
-    bf16* kp = p.dk + ((long)bh * Lk1 + key) * D + 4 * q4;
-    bf16* vp = p.dv + ((long)bh * Lk1 + key) * D + 4 * q4;
+    const long nkv = (long)gridDim.y * Lk1 * D;
+    float* kp = p.kv_part + ((long)blockIdx.z * 2) * nkv + ((long)bh * Lk1 + key) * D + 4 * q4;
+    float* vp = kp + nkv;
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      bf16x4 a, c2;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * p.scale); c2[r] = (bf16)dv[dt][r]; }
-      *reinterpret_cast<bf16x4*>(kp + 16 * dt) = a;
-      *reinterpret_cast<bf16x4*>(vp + 16 * dt) = c2;
+      *reinterpret_cast<f32x4*>(kp + 16 * dt) = dk[dt];
+      *reinterpret_cast<f32x4*>(vp + 16 * dt) = dv[dt];
     }
+  }
+}
+
+// dK = scale * sum_z partial, dV = sum_z partial  (bf16 out)
+__global__ __launch_bounds__(256) void pattn_kv_reduce_kernel(const float* __restrict__ part, int nsplit, long nkv,
+                                                              float scale, bf16* __restrict__ dk, bf16* __restrict__ dv) {
+  const long n4 = nkv >> 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < 2 * n4; idx += (long)gridDim.x * 256) {
+    const int which = idx >= n4;
+    const long e = (idx - which * n4) * 4;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; ++z) a += *reinterpret_cast<const f32x4*>(part + ((long)z * 2 + which) * nkv + e);
+    const float sc = which ? 1.f : scale;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (bf16)(a[r] * sc);
+    *reinterpret_cast<bf16x4*>((which ? dv : dk) + e) = o;
   }
 }
 
@@ -488,19 +506,37 @@ extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, c
   return PVRL_OK;
 }
 
+static int kv_splits(int64_t Lq) {   // query tiles are shared out so that a workgroup streams >= ~2048 queries
+  int64_t s = (Lq + 1 + 2047) / 2048;
+  return (int)(s < 1 ? 1 : (s > 16 ? 16 : s));
+}
+
+extern "C" int64_t pvrl_mvit_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw) {
+  return (int64_t)kv_splits(Lq) * 2 * B * H * (kt * kh * kw + 1) * D * (int64_t)sizeof(float);
+}
+
 extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H,
                                   int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, const void* o,
                                   const void* d_o, int64_t ldo, const float* lse, float* delta, void* dq, void* dk,
-                                  void* dv, float* drel, void* stream) {
+                                  void* dv, float* drel, void* workspace, int64_t workspace_bytes, void* stream) {
   PA p = {};
-  if (!o || !d_o || !lse || !delta || !dq || !dk || !dv || !drel || fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo))
+  if (!o || !d_o || !lse || !delta || !dq || !dk || !dv || !drel || !workspace ||
+      fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo))
     return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_mvit_attn_bwd_workspace_bytes(B, H, Lq, kt, kh, kw)) return PVRL_EINVAL;
+  p.kv_part = (float*)workspace;
   p.o = (bf16*)o; p.d_o = (const bf16*)d_o; p.lse = (float*)lse; p.delta = delta;
   p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.drel = drel;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pattn_bwd_q_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pattn_bwd_kv_kernel, dim3((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
+  const int ns = kv_splits(Lq);
+  hipLaunchKernelGGL(pattn_bwd_kv_kernel, dim3((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H), (unsigned)ns), dim3(256), 0,
+                     s, p);
+  PVRL_LAUNCH_CHECK();
+  const long nkv = (long)B * H * (p.Lk + 1) * D;
+  hipLaunchKernelGGL(pattn_kv_reduce_kernel, dim3((unsigned)cdiv(2 * (nkv >> 2), 256)), dim3(256), 0, s, p.kv_part, ns,
+                     nkv, scale, p.dk, p.dv);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

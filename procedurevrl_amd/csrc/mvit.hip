@@ -376,46 +376,61 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict_
 }
 
 // weight gradient of the depthwise conv: dW[c][tap] += sum_{b,h,out} dc[out][c] * x[in(out, tap)][c]
-// block = 2 token lanes x 96 channels; each thread keeps its 27 tap sums in registers.
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(const bf16* __restrict__ dc, const bf16* __restrict__ qkv,
-                                                         PoolGeom g, float* __restrict__ dw) {
-  __shared__ float red[27][HD];
+// block = 4 token lanes x 96 channels; each thread keeps its 27 tap sums in registers.  The 27 neighbour loads of a token
+// are unconditional (clamped address, 0/1 mask) so they are all in flight together.
+constexpr int PW_LANES = 4;
+__global__ __launch_bounds__(96 * PW_LANES) void pool_wgrad_kernel(const bf16* __restrict__ dc,
+                                                                   const bf16* __restrict__ qkv, PoolGeom g,
+                                                                   float* __restrict__ dw) {
+  __shared__ float red[PW_LANES - 1][27][HD];
   const int c = threadIdx.x % HD, tl = threadIdx.x / HD;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
   const long ntok = (long)g.B * g.H * Lo;
   float acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = 0.f;
-  for (long tok = (long)blockIdx.x * 2 + tl; tok < ntok; tok += (long)gridDim.x * 2) {
+  for (long tok = (long)blockIdx.x * PW_LANES + tl; tok < ntok; tok += (long)gridDim.x * PW_LANES) {
     const int lo = (int)(tok % Lo);
     const long bh = tok / Lo;
     const int h = (int)(bh % g.H), b = (int)(bh / g.H);
     const int xo = lo % g.Wo, yo = (lo / g.Wo) % g.Ho, to = lo / (g.Wo * g.Ho);
     const float d = (float)dc[(bh * (Lo + 1) + lo) * HD + c];
     const bf16* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c;
+    float xv[27];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int ti = to * g.st - 1 + a;
+      const int tc = min(max(ti, 0), g.T - 1);
 #pragma unroll
       for (int yy = 0; yy < 3; ++yy) {
         const int yi = yo * g.sh - 1 + yy;
+        const int yc = min(max(yi, 0), g.Hh - 1);
 #pragma unroll
         for (int xx = 0; xx < 3; ++xx) {
           const int xi = xo * g.sw - 1 + xx;
-          if (ti >= 0 && ti < g.T && yi >= 0 && yi < g.Hh && xi >= 0 && xi < g.Ww)
-            acc[(a * 3 + yy) * 3 + xx] += d * (float)xb[(((long)ti * g.Hh + yi) * g.Ww + xi) * g.ld];
+          const int xc = min(max(xi, 0), g.Ww - 1);
+          const bool ok = ti == tc && yi == yc && xi == xc;
+          const float v = (float)xb[(((long)tc * g.Hh + yc) * g.Ww + xc) * g.ld];
+          xv[(a * 3 + yy) * 3 + xx] = ok ? v : 0.f;
         }
       }
     }
-  }
-  if (tl == 1) {
 #pragma unroll
-    for (int t = 0; t < 27; ++t) red[t][c] = acc[t];
+    for (int t = 0; t < 27; ++t) acc[t] = fmaf(d, xv[t], acc[t]);
+  }
+  if (tl > 0) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[tl - 1][t][c] = acc[t];
   }
   __syncthreads();
   if (tl == 0) {
 #pragma unroll
-    for (int t = 0; t < 27; ++t) atomicAdd(dw + c * 27 + t, acc[t] + red[t][c]);
+    for (int t = 0; t < 27; ++t) {
+      float a = acc[t];
+#pragma unroll
+      for (int l = 0; l < PW_LANES - 1; ++l) a += red[l][t][c];
+      atomicAdd(dw + c * 27 + t, a);
+    }
   }
 }
 
@@ -712,11 +727,11 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
                      (bf16*)dqkv);
   PVRL_LAUNCH_CHECK();
-  long wb = (B * H * Lo + 1) / 2;
-  if (wb > 1024) wb = 1024;
+  long wb = (B * H * Lo + PW_LANES - 1) / PW_LANES;
+  if (wb > 2048) wb = 2048;
   if (wb < 1) wb = 1;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(192), 0, s, (const bf16*)dc_scratch, (const bf16*)qkv,
-                     g, dw);
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(96 * PW_LANES), 0, s, (const bf16*)dc_scratch,
+                     (const bf16*)qkv, g, dw);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -132,8 +132,11 @@ def attn_bwd(q, k, v, rel, B, H, Lq, k_thw, scale, o, d_o, lse):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     drel = torch.empty_like(rel)
     delta = torch.empty_like(lse)
+    from .ops import workspace
+    nbytes = L.call("pvrl_mvit_attn_bwd_workspace_bytes", B, H, Lq, *k_thw)
+    ws = workspace(nbytes, q.device, "mvit_attn_bwd")
     L.call("pvrl_mvit_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), _ptr(d_o),
-           o.stride(0), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(drel), _stream())
+           o.stride(0), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(drel), _ptr(ws), ws.numel(), _stream())
     return dq, dk, dv, drel
 
 
