@@ -376,27 +376,33 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict_
 }
 
 // weight gradient of the depthwise conv: dW[c][tap] += sum_{b,h,out} dc[out][c] * x[in(out, tap)][c]
-// block = 4 token lanes x 96 channels; each thread keeps its 27 tap sums in registers.  The 27 neighbour loads of a token
-// are unconditional (clamped address, 0/1 mask) so they are all in flight together.
-constexpr int PW_LANES = 4;
-__global__ __launch_bounds__(96 * PW_LANES) void pool_wgrad_kernel(const bf16* __restrict__ dc,
-                                                                   const bf16* __restrict__ qkv, PoolGeom g,
-                                                                   float* __restrict__ dw) {
-  __shared__ float red[PW_LANES - 1][27][HD];
-  const int c = threadIdx.x % HD, tl = threadIdx.x / HD;
+// block = 8 token lanes x 24 channel quads (8-byte loads); each thread keeps 27 x 4 sums in registers.  The 27 neighbour
+// loads of a token are unconditional (clamped address, 0/1 mask) so they are all in flight together.
+constexpr int PW_LANES = 8, PW_CQ = HD / 4;
+__device__ __forceinline__ f32x4 ld4bf(const bf16* p) {
+  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+  return (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
+                 __uint_as_float(w[1] & 0xffff0000u)};
+}
+__global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16* __restrict__ dc,
+                                                                      const bf16* __restrict__ qkv, PoolGeom g,
+                                                                      float* __restrict__ dw) {
+  __shared__ float red[27][HD];
+  const int cq = threadIdx.x % PW_CQ, tl = threadIdx.x / PW_CQ, c0 = cq * 4;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
   const long ntok = (long)g.B * g.H * Lo;
-  float acc[27];
+  f32x4 acc[27];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) red[i / HD][i % HD] = 0.f;
   for (long tok = (long)blockIdx.x * PW_LANES + tl; tok < ntok; tok += (long)gridDim.x * PW_LANES) {
     const int lo = (int)(tok % Lo);
     const long bh = tok / Lo;
     const int h = (int)(bh % g.H), b = (int)(bh / g.H);
     const int xo = lo % g.Wo, yo = (lo / g.Wo) % g.Ho, to = lo / (g.Wo * g.Ho);
-    const float d = (float)dc[(bh * (Lo + 1) + lo) * HD + c];
-    const bf16* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c;
-    float xv[27];
+    const f32x4 d = ld4bf(dc + (bh * (Lo + 1) + lo) * HD + c0);
+    const bf16* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c0;
+    f32x4 xv[27];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int ti = to * g.st - 1 + a;
@@ -409,29 +415,21 @@ __global__ __launch_bounds__(96 * PW_LANES) void pool_wgrad_kernel(const bf16* _
         for (int xx = 0; xx < 3; ++xx) {
           const int xi = xo * g.sw - 1 + xx;
           const int xc = min(max(xi, 0), g.Ww - 1);
-          const bool ok = ti == tc && yi == yc && xi == xc;
-          const float v = (float)xb[(((long)tc * g.Hh + yc) * g.Ww + xc) * g.ld];
-          xv[(a * 3 + yy) * 3 + xx] = ok ? v : 0.f;
+          const float ok = (ti == tc && yi == yc && xi == xc) ? 1.f : 0.f;
+          xv[(a * 3 + yy) * 3 + xx] = ld4bf(xb + (((long)tc * g.Hh + yc) * g.Ww + xc) * g.ld) * ok;
         }
       }
     }
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = fmaf(d, xv[t], acc[t]);
-  }
-  if (tl > 0) {
-#pragma unroll
-    for (int t = 0; t < 27; ++t) red[tl - 1][t][c] = acc[t];
+    for (int t = 0; t < 27; ++t) acc[t] += d * xv[t];
   }
   __syncthreads();
-  if (tl == 0) {
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      float a = acc[t];
+  for (int t = 0; t < 27; ++t)
 #pragma unroll
-      for (int l = 0; l < PW_LANES - 1; ++l) a += red[l][t][c];
-      atomicAdd(dw + c * 27 + t, a);
-    }
-  }
+    for (int e = 0; e < 4; ++e) atomicAdd(&red[t][c0 + e], acc[t][e]);      // LDS: 8 lanes per address
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) atomicAdd(dw + (i % HD) * 27 + i / HD, red[i / HD][i % HD]);
 }
 
 // ------------------------------------------------------------------------------------------------- max-pool skip
@@ -685,7 +683,7 @@ extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32,
 
 static int pool_geom(PoolGeom& g, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st, int64_t sh,
                      int64_t sw, int64_t ld, int64_t col0) {
-  if (B <= 0 || H <= 0 || T <= 0 || Hh <= 0 || Ww <= 0 || st <= 0 || sh <= 0 || sw <= 0 || (ld % 2) || (col0 % 2))
+  if (B <= 0 || H <= 0 || T <= 0 || Hh <= 0 || Ww <= 0 || st <= 0 || sh <= 0 || sw <= 0 || (ld % 4) || (col0 % 4))
     return PVRL_EINVAL;
   g.B = (int)B; g.H = (int)H; g.T = (int)T; g.Hh = (int)Hh; g.Ww = (int)Ww;
   g.st = (int)st; g.sh = (int)sh; g.sw = (int)sw;
@@ -727,10 +725,10 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
                      (bf16*)dqkv);
   PVRL_LAUNCH_CHECK();
-  long wb = (B * H * Lo + PW_LANES - 1) / PW_LANES;
-  if (wb > 2048) wb = 2048;
+  long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
+  if (wb > 1024) wb = 1024;
   if (wb < 1) wb = 1;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(96 * PW_LANES), 0, s, (const bf16*)dc_scratch,
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const bf16*)dc_scratch,
                      (const bf16*)qkv, g, dw);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
