@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 // one wave = 16 keys (lane i owns key column i), workgroup = 64 keys; queries streamed in tiles of 32 (Q and dO in LDS)
 __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][Q | dO]
-  __shared__ float rel_s[2][KT][JMAX];
+  __shared__ float rel_s[2][KT * JMAX];          // [32 queries][J] rows of the query tile, contiguous as in HBM
   __shared__ float lse_s[2][KT], dl_s[2][KT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
@@ -378,24 +378,39 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
       }
     }
   };
-  auto load_side = [&](int buf, int row0) {
-    for (int e = tid; e < KT * JMAX; e += 256) {
-      const int qi = e / JMAX, j = e - qi * JMAX;
-      const int qq = row0 + qi;
-      rel_s[buf][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
+  // the rel rows / lse / delta of a query tile are one contiguous run in HBM: fetched to registers with the tiles
+  // (latency under the MFMAs), stored to LDS after the step
+  struct SideRegs { float r[5]; float l, d; };
+  const float* relb = p.rel + (long)bh * p.Lq * p.J;
+  auto side_gload = [&](SideRegs& sr, int row0) {
+    const int n = (min(row0 + KT, p.Lq) - row0) * p.J;      // valid floats (patch queries only)
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      const int idx = tid + 256 * e;
+      sr.r[e] = idx < n ? relb[(long)row0 * p.J + idx] * LOG2E : 0.f;
     }
-    if (tid < KT) {
-      const int qq = row0 + tid;
-      lse_s[buf][tid] = qq < Lq1 ? p.lse[(long)bh * Lq1 + qq] : 0.f;
-      dl_s[buf][tid] = qq < Lq1 ? p.delta[(long)bh * Lq1 + qq] : 0.f;
+    sr.l = sr.d = 0.f;
+    if (tid < KT && row0 + tid < Lq1) {
+      sr.l = p.lse[(long)bh * Lq1 + row0 + tid];
+      sr.d = p.delta[(long)bh * Lq1 + row0 + tid];
     }
+  };
+  auto side_lstore = [&](const SideRegs& sr, int buf) {
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      const int idx = tid + 256 * e;
+      if (idx < KT * JMAX) rel_s[buf][idx] = sr.r[e];
+    }
+    if (tid < KT) { lse_s[buf][tid] = sr.l; dl_s[buf][tid] = sr.d; }
   };
   TileRegs rq, rd;
   tile_gload(rq, qb, D, tbeg * KT, Lq1, tid);
   load_do(rd, tbeg * KT);
   tile_lstore(rq, smem + (tbeg & 1) * 2 * TILE_BYTES, tid);
   tile_lstore(rd, smem + (tbeg & 1) * 2 * TILE_BYTES + TILE_BYTES, tid);
-  load_side(tbeg & 1, tbeg * KT);
+  SideRegs rs;
+  side_gload(rs, tbeg * KT);
+  side_lstore(rs, tbeg & 1);
   __syncthreads();
 
   const float c = p.scale * LOG2E;
@@ -410,6 +425,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     if (t + 1 < ntiles) {
       tile_gload(rq, qb, D, (t + 1) * KT, Lq1, tid);
       load_do(rd, (t + 1) * KT);
+      side_gload(rs, (t + 1) * KT);
     }
     float pr[8], ds[8];
 #pragma unroll
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
         const int ql = u * 16 + 4 * q4 + r;
         const int qq = t * KT + ql;
         float x = s[r] * c;
-        if (kpatch && qq < p.Lq) x += rel_s[buf][ql][j0] + rel_s[buf][ql][j1] + rel_s[buf][ql][j2];
+        if (kpatch && qq < p.Lq) x += rel_s[buf][ql * p.J + j0] + rel_s[buf][ql * p.J + j1] + rel_s[buf][ql * p.J + j2];
         const float pv = (qq < Lq1 && key < Lk1) ? __builtin_amdgcn_exp2f(x - lse_s[buf][ql]) : 0.f;
         pr[u * 4 + r] = pv;
         ds[u * 4 + r] = pv * (dp[r] - dl_s[buf][ql]);
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
       tile_lstore(rq, nb, tid);
       tile_lstore(rd, nb + TILE_BYTES, tid);
-      load_side((t + 1) & 1, (t + 1) * KT);
+      side_lstore(rs, (t + 1) & 1);
     }
     __syncthreads();
   }
