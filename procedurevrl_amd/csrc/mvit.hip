@@ -331,26 +331,20 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict
 }
 
 // data gradient of the depthwise conv: dX[b, l_in, h, c] = sum_taps dc[out(l_in, tap)][c] * w[c][tap]
-// 24 threads per input token (4 channels, 8-byte loads)
-__device__ __forceinline__ f32x4 ld4bf_(const bf16* p) {
-  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-  return (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
-                 __uint_as_float(w[1] & 0xffff0000u)};
-}
-__global__ __launch_bounds__(192) void pool_dgrad_kernel(const bf16* __restrict__ dc, PoolGeom g,
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict__ dc, PoolGeom g,
                                                          const float* __restrict__ w, bf16* __restrict__ dqkv) {
-  __shared__ __attribute__((aligned(16))) float ws[27 * HD];
-  for (int i = threadIdx.x; i < 27 * HD; i += 192) ws[i] = w[(i % HD) * 27 + i / HD];
+  __shared__ float ws[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];
   __syncthreads();
-  const int cq = threadIdx.x % 24, c0 = cq * 4, tl = threadIdx.x / 24;
+  const int sub = threadIdx.x & 15, c0 = sub * 6;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
   const long ntok = (long)g.B * g.H * L;
-  for (long tok = (long)blockIdx.x * 8 + tl; tok < ntok; tok += (long)gridDim.x * 8) {
+  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
     const int l = (int)(tok % L);
     const long bh = tok / L;
     const int h = (int)(bh % g.H), b = (int)(bh / g.H);
     const int xi = l % g.Ww, yi = (l / g.Ww) % g.Hh, ti = l / (g.Ww * g.Hh);
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int tn = ti + 1 - a;
@@ -369,15 +363,15 @@ __global__ __launch_bounds__(192) void pool_dgrad_kernel(const bf16* __restrict_
           if (xn < 0 || xn % g.sw) continue;
           const int xo = xn / g.sw;
           if (xo >= g.Wo) continue;
-          const f32x4 v = ld4bf_(dc + (bh * (Lo + 1) + ((long)to * g.Ho + yo) * g.Wo + xo) * HD + c0);
-          acc += v * *reinterpret_cast<const f32x4*>(ws + ((a * 3 + yy) * 3 + xx) * HD + c0);
+          float v[6];
+          ld6(dc + (bh * (Lo + 1) + ((long)to * g.Ho + yo) * g.Wo + xo) * HD + c0, v);
+          const float* wt = ws + ((a * 3 + yy) * 3 + xx) * HD + c0;
+#pragma unroll
+          for (int e = 0; e < 6; ++e) acc[e] = fmaf(v[e], wt[e], acc[e]);
         }
       }
     }
-    union { bf16x4 h4; u32x2 u; } o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o.h4[e] = (bf16)acc[e];
-    *reinterpret_cast<u32x2*>(dqkv + ((long)b * L + l) * g.ld + g.col0 + h * HD + c0) = o.u;
+    st6(dqkv + ((long)b * L + l) * g.ld + g.col0 + h * HD + c0, acc);
   }
 }
 
@@ -728,7 +722,7 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
                      g, gamma, eps, (bf16*)dc_scratch, (bf16*)dqkv, dgamma, dbeta);
   PVRL_LAUNCH_CHECK();
   const long nin = (long)B * H * T * Hh * Ww;
-  hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin, 8)), dim3(192), 0, s, (const bf16*)dc_scratch, g, w,
+  hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
                      (bf16*)dqkv);
   PVRL_LAUNCH_CHECK();
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
