@@ -42,6 +42,11 @@ __device__ __forceinline__ void glds16_raw(const void* uniform_base, unsigned la
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
                :: "v"(lane_off), "s"(uniform_base), "s"(lds_wave_base) : "memory", "m0");
 }
+// per-lane 64-bit source address form of the same raw LDS-DMA copy
+__device__ __forceinline__ void glds16_raw_v(const void* lane_ptr, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(lane_ptr), "s"(lds_wave_base) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;

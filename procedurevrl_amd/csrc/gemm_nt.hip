@@ -459,6 +459,151 @@ __global__ __launch_bounds__(1024) void gemm_nt_pipe_kernel(GemmNT p) {
   nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256x256 tile with FOUR waves (2 x 2), each owning a 128 x 128 block = 8 x 8 MFMA tiles = 256 accumulator AGPRs (one
+// wave per SIMD, 512-register budget): 16 ds_read_b128 per 64 MFMAs, half the LDS read bytes per FLOP of the 64x64 wave
+// block.  BK = 32 stages (32 KiB) in a 4-deep LDS ring filled by raw-ISA LDS-DMA three stages ahead (counted vmcnt + raw
+// s_barrier, one barrier per 64 MFMAs); the X fragments of step s+1 replace those of step s in place right after their
+// row of MFMAs, the W fragments are double-buffered.  Same [rows][32] LDS image / swizzles as the pipe kernel, same
+// epilogue as every other NT kernel.  MEASURED (same-process A/B, 50k-row shapes): 25-30 % SLOWER than the 16-wave
+// kernel (qkv 702 vs 908, dfc1 762 vs 1032, fc1+GELU 527 vs 682 TFLOP/s): with no transposition work to hide, four
+// waves per SIMD cover LDS / MFMA latencies better than one software-pipelined wave.  Kept behind benchmark knob 6.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, BKS = 32, NS = 4;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BKS * 2, STAGE = 2 * XBYTES;   // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int GM = 8;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: 32 LDS-DMA instructions per stage (16 rows x 64 B each): waves 0,1 bring X (rows 128 w ..), waves 2,3 bring W
+  const char* gsrc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = (wave & 1) * 128 + e * 16 + (lane >> 2);
+    const int pc = lane & 3;
+    if (wave < 2) {
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[e] = reinterpret_cast<const char*>(p.A + (long)grow * p.lda + ((pc ^ swz_x64(row)) << 3));
+    } else {
+      gsrc[e] = reinterpret_cast<const char*>(p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w64<F32OUT>(row)) << 3));
+    }
+  }
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const unsigned dbase = (wave < 2 ? 0 : XBYTES) + (wave & 1) * 128 * 64;
+  auto stage = [&](int kt, int nk) {
+    const int kc = kt < nk ? kt : nk - 1;                       // surplus ring slots re-load the last stage (never read)
+    const unsigned b = smem_base + (kt & (NS - 1)) * STAGE + dbase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) glds16_raw_v(gsrc[e] + kc * (BKS * 2), b + e * 1024);
+  };
+
+  // fragment addresses: X block a (0,1) tile mt -> row wm*128 + a*64 + mt*16 + i ; W block b tile nt -> wn*128 + b*64 + w_row
+  int xoff[8], woff[8];
+  {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int rx = wm * 128 + (t >> 2) * 64 + (t & 3) * 16 + i;
+      xoff[t] = rx * 64 + ((q ^ swz_x64(rx)) << 4);
+      const int rw = wn * 128 + (t >> 2) * 64 + w_row<F32OUT>(t & 3, i);
+      woff[t] = XBYTES + rw * 64 + ((q ^ swz_w64<F32OUT>(rw)) << 4);
+    }
+  }
+
+  f32x4 acc[2][2][4][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 xf[7], xa[1], xb[1], wfa[8], wfb[8];
+  auto rd = [&](const char* b, int off) { return *reinterpret_cast<const bf16x8*>(b + off); };
+  // one K = 32 step: 8 rows (X tile r) of 8 MFMAs; LDS reads of the next stage are issued after rows 0..6 only
+  auto step = [&](const bf16x8* wc, bf16x8* wnx, const bf16x8* xc7, bf16x8* xn7, const char* nb) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const bf16x8 xr = r < 7 ? xf[r] : xc7[0];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        acc[r >> 2][t >> 2][r & 3][t & 3] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xr, acc[r >> 2][t >> 2][r & 3][t & 3], 0, 0, 0);
+      if (r < 4) {
+        wnx[2 * r] = rd(nb, woff[2 * r]);
+        wnx[2 * r + 1] = rd(nb, woff[2 * r + 1]);
+        xf[r] = rd(nb, xoff[r]);
+      } else if (r < 6) {
+        xf[r] = rd(nb, xoff[r]);
+        if (r == 4) xn7[0] = rd(nb, xoff[7]);
+      } else if (r == 6) {
+        xf[6] = rd(nb, xoff[6]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  };
+
+  const int nk = p.K / BKS;     // even (K % 64 == 0)
+  stage(0, nk); stage(1, nk); stage(2, nk);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) xf[t] = rd(smem, xoff[t]);
+    else xa[0] = rd(smem, xoff[t]);
+    wfa[t] = rd(smem, woff[t]);
+  }
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int hb = ((kt >> 1) & 1) * 2;                      // ring slot of stage kt: 0 or 2
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // stage kt+1 landed (this wave's part; kt+2 stays in flight)
+    __builtin_amdgcn_s_barrier();                            // ... everyone's part; slot (kt+3)%4 is free
+    stage(kt + 3, nk);
+    step(wfa, wfb, xa, xb, smem + (hb + 1) * STAGE);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 4, nk);
+    step(wfb, wfa, xb, xa, smem + (hb ^ 2) * STAGE);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) nt_epilogue<EPI>(p, acc[a][b], m0, n0, 2 * wm + a, 2 * wn + b, lane);
+}
+
 // ---------------------------------------------------------------------------
 // Small fp32 GEMM for the projection head / step-logit path, where M is a few
 // dozen rows and the reference keeps fp32 (lib/models/vit.py:299-307):
@@ -557,8 +702,19 @@ int launch_w128(GemmNT p, hipStream_t s) {
 }
 
 template <int EPI>
+int launch_w4(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / 256;
+  p.tiles_m = cdiv(p.M, 256);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_w4_kernel<EPI>), dim3(p.nwg), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   int t = g_force_tile;
+  if (t == 6 && p.N % 256 == 0) return launch_w4<EPI>(p, s);
   if (t == 4 && p.N % 256 == 0) return launch_pipe<EPI>(p, s);
   if (t == 5 && p.N % 256 == 0) return launch_w128<EPI>(p, s);
   if (t == 0) t = (p.M >= 4096 && p.N % 256 == 0) ? 3 : (p.M >= 2048 ? 2 : 1);

@@ -62,7 +62,7 @@ def main():
         gemm_case(f"nt[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
         gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
     for rep in range(2):
-        for tile, tg in ((3, "256 16 waves"), (5, "256 8w 128x64")):
+        for tile, tg in ((3, "256 16 waves"), (6, "256 4w 128x128")):
             L.call("pvrl_debug_set_gemm_tile", tile)
             gemm_case(f"ab[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
@@ -71,6 +71,7 @@ def main():
             gemm_case(f"ab[{tg}] fc2   resid M x768x3072", M, 768, 3072, L.PVRL_EPI_RESID_F32)
             gemm_case(f"ab[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
+            gemm_case(f"ab[{tg}] dfc2  dgelu M x3072x768", M, 3072, 768, L.PVRL_EPI_DGELU)
     L.call("pvrl_debug_set_gemm_tile", 0)
     gemm_case("nt-auto qkv      bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
     gemm_case("nt proj     bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
