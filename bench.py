@@ -150,6 +150,24 @@ def main():
     dt = float(t.item())
     timing = ops.collect_kernel_timing() if not args.no_kernel_timing else None
     ops.KERNEL_TIMING = None
+    # isolated leg (untimed, not part of `value`): the same step with the weight-gradient GEMMs on the main stream, so
+    # that a launch's event-timed duration is the kernel's own and not its share of a GPU it co-runs on with the dgrad
+    # chain (under overlap the TN and NT kernels each see about half the CUs and their durations double)
+    isolated = None
+    if timing and getattr(vt.engine, "overlap_wgrad", False):
+        vt.engine.overlap_wgrad = False
+        step(); barrier()
+        ops.KERNEL_TIMING = []
+        for _ in range(min(args.steps, 3)):
+            step()
+        barrier()
+        iso = ops.collect_kernel_timing()
+        ops.KERNEL_TIMING = None
+        vt.engine.overlap_wgrad = True
+        if iso and timing["roofline"]["kernel"] in iso["summary"]:
+            k = iso["summary"][timing["roofline"]["kernel"]]
+            isolated = {"achieved": k["tflops"], "frac": round(k["tflops"] / 2500.0, 4), "avg_launch_us": k["avg_us"],
+                        "note": "same step, wgrad overlap off (kernel alone on the GPU)"}
 
     if rank == 0:
         clips = B * world * args.steps
@@ -174,6 +192,8 @@ def main():
         if timing:
             out["roofline"] = timing["roofline"]
             out["roofline"]["traffic"] = pmc_traffic(timing["roofline"]["kernel"])
+            if isolated:
+                out["roofline"]["isolated"] = isolated
             out["kernels"] = timing["summary"]
         if not args.no_cpu_baseline:
             try:
