@@ -176,7 +176,7 @@ def main():
         if args.arch == "mvit":
             wtrain = 3 * 128.45e9 * args.frames / 16      # MViTv2-S forward 128.45 GFLOP/clip at 16 frames
         out = {
-            "metric": "training clips/sec (8f x 224^2, ViT-B TimeSformer)" if args.arch == "vit" else
+            "metric": f"training clips/sec ({args.frames}f x 224^2, ViT-B TimeSformer)" if args.arch == "vit" else
                       f"training clips/sec ({args.frames}f x 224^2, MViTv2-S)", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
