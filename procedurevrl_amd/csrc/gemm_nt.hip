@@ -40,17 +40,16 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int swz_x(int row) { return (row >> 1) & 7; }
 // W rows are read in a permuted order so that the lanes of one epilogue store instruction write contiguous bytes:
-//   fp32 outputs: natural order, lane (i = 4q + r) of tile nt holds column 16 nt + i -> the 4 lanes q of a row write
-//                 16 consecutive floats (64 B) per instruction;
-//   bf16 outputs: tile nt = 2c + h holds column 32c + 8q + 4h + r -> a lane packs 8 consecutive bf16 (tiles 2c, 2c+1)
-//                 and the 4 lanes q of a row write 32 consecutive bf16 (64 B) per instruction.
+//   tile nt = 2c + h holds column 32c + 8q + 4h + r -> a lane owns 8 consecutive columns (tiles 2c, 2c+1) and the 4 lanes
+//   q of a row cover 32 consecutive columns: 64 B of bf16 per store instruction, or a whole 128-byte line of fp32 in
+//   two back-to-back 16-byte stores per lane (the earlier natural order for fp32 wrote 64-byte half lines).
 // Each order has its own chunk swizzle making ds_read_b128 conflict-free (rows that a lane group reads together
 // must land on distinct 16-byte slots of the 256-byte bank row).
 template <bool F32OUT> __device__ __forceinline__ int w_row(int nt, int i) {
-  return F32OUT ? 16 * nt + i : 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3);
+  return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3);
 }
 template <bool F32OUT> __device__ __forceinline__ int swz_w(int row) {
-  return F32OUT ? (row >> 1) & 7 : ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+  return ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
 }
 
 template <int EPI>
@@ -60,29 +59,31 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
   const int q = lane >> 4, i = lane & 15;
   const int nw0 = n0 + wn * 64;
   if constexpr (F32OUT) {
-    // lane holds, for tile nt, columns nw0 + 16 nt + 4q + (0..3)
+    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
     f32x4 bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 16 * nt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1))
+                      : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + wm * 64 + mt * 16 + i;
       if (m >= p.M) continue;
       const float rs = p.rowscale ? p.rowscale[m] : 1.f;
-      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 4 * q;
+      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 8 * q;
       const float* r = nullptr;
       if constexpr (EPI == PVRL_EPI_RESID_F32) {
         const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
-        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 4 * q;
+        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 8 * q;
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
+        const int off = 32 * (nt >> 1) + 4 * (nt & 1);
         f32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
-        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 16 * nt);
-        *reinterpret_cast<f32x4*>(o + 16 * nt) = ov;
+        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + off);
+        *reinterpret_cast<f32x4*>(o + off) = ov;
       }
     }
   } else {
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w128_kernel(GemmNT p) {
 // group then touches 16 distinct 16-byte slots.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int g64(int a) { return (4 - a) & 3; }
-template <bool F32OUT> __device__ __forceinline__ int swz_w64(int row) { return g64(F32OUT ? (row >> 2) & 3 : (row >> 3) & 3); }
+template <bool F32OUT> __device__ __forceinline__ int swz_w64(int row) { return g64((row >> 3) & 3); }
 __device__ __forceinline__ int swz_x64(int row) { return g64((row >> 2) & 3); }
 
 template <int EPI>
