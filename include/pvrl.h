@@ -149,6 +149,11 @@ int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float dampening,
                   float weight_decay, int nesterov, int first_step, float gscale, void* stream);
 
+/* softmax over the rows of an fp32 logit matrix: the eval-mode output `self.softmax(x)` (vit.py:355-356, mvit.py:203-204) */
+int pvrl_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, void* stream);
+/* exact-erf GELU on a small fp32 tensor (time_mlp, tfm_model.py:89-94): out = gelu(x), or out = dy * gelu'(x) when dy != 0 */
+int pvrl_gelu_f32(const float* x, const float* dy, float* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * MViTv2 encoder path (reference lib/models/slowfast_mvit/).  Token matrices: rows [0, B*L) patch tokens
  * ordered (b, t, h, w), rows [B*L, B*L + B) the cls tokens; channel widths padded with zero columns to multiples of 128.

@@ -230,6 +230,38 @@ __global__ __launch_bounds__(256) void milnce_grad_kernel(const float* __restric
   }
 }
 
+
+// row softmax over fp32 logits (eval-mode output of the wrappers, lib/models/vit.py:355-356): one workgroup per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                           long ldy, int N) {
+  __shared__ float red[8];
+  const float* xr = x + (long)blockIdx.x * ldx;
+  float* yr = y + (long)blockIdx.x * ldy;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < N; c += 256) mx = fmaxf(mx, xr[c]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sm = 0.f;
+  for (int c = threadIdx.x; c < N; c += 256) sm += __expf(xr[c] - mx);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sm;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = threadIdx.x; c < N; c += 256) yr[c] = __expf(xr[c] - mx) * inv;
+}
+
+// exact-erf GELU on a small fp32 tensor (time_mlp of the order transformer, lib/models/tfm_model.py:89-94) and its derivative
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    out[i] = dy ? dy[i] * (0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v))
+                : 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  }
+}
+
 }  // namespace
 
 extern "C" int pvrl_milnce(const float* x, int64_t n, int64_t C, float grad_scale, float* nom, float* den, float* dx,
@@ -283,6 +315,25 @@ extern "C" int pvrl_mse(const float* a, const float* b, int64_t n, float grad_sc
                         void* stream) {
   if (n <= 0 || !a || !b) return PVRL_EINVAL;
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, grad_scale, loss, da, db);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, void* stream) {
+  if (M <= 0) return PVRL_OK;
+  if (!x || !y || N <= 0) return PVRL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y, (long)ldy,
+                     (int)N);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_gelu_f32(const float* x, const float* dy, float* out, int64_t n, void* stream) {
+  if (n <= 0) return PVRL_OK;
+  if (!x || !out) return PVRL_EINVAL;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, out, (long)n);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -95,6 +95,25 @@ def l2norm(x):
     return L2NormFn.apply(x)
 
 
+class GeluF32Fn(torch.autograd.Function):
+    """nn.GELU() (exact erf) on a small fp32 tensor: the order transformer's time_mlp (tfm_model.py:89-94)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.gelu_f32(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_f32(x, dy.contiguous())
+
+
+def gelu_f32(x):
+    return GeluF32Fn.apply(x)
+
+
 class StepLogitsFn(torch.autograd.Function):
     """x @ label_emb.t() / temp   (vit.py:307); label_emb is a constant (no gradient)."""
 

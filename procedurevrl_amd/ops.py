@@ -402,3 +402,21 @@ def milnce(x, n, C, grad_scale=None):
     L.call("pvrl_milnce", _ptr(x), n, C, float(grad_scale if grad_scale is not None else 0.0), _ptr(nom), _ptr(den),
            _ptr(dx), _stream())
     return nom, den, dx
+
+
+def softmax_rows(x):
+    """fp32 [M, N] -> row softmax (eval-mode probabilities)"""
+    L = lib()
+    _chk2d(x, F32)
+    y = torch.empty_like(x)
+    L.call("pvrl_softmax_rows_f32", _ptr(x), _ld(x), _ptr(y), _ld(y), x.shape[0], x.shape[1], _stream())
+    return y
+
+
+def gelu_f32(x, dy=None):
+    """exact-erf GELU of a contiguous fp32 tensor, or dy * gelu'(x)"""
+    L = lib()
+    assert x.dtype == F32 and x.is_contiguous() and x.is_cuda
+    out = torch.empty_like(x)
+    L.call("pvrl_gelu_f32", _ptr(x), _ptr(dy), _ptr(out), x.numel(), _stream())
+    return out

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .functional import StackFn, linear_f32
+from .functional import StackFn, gelu_f32, linear_f32
 
 
 class QuickGELU(nn.Module):
@@ -108,7 +108,7 @@ class DiffusionTransformer(nn.Module):
     def _time_mlp(self, t):
         e = sinusoidal_embedding(t, self.hidden_size // 4)
         h = linear_f32(e, self.time_mlp[1].weight, self.time_mlp[1].bias)
-        h = torch.nn.functional.gelu(h)
+        h = gelu_f32(h)
         return linear_f32(h, self.time_mlp[3].weight, self.time_mlp[3].bias)
 
     def _ennoise(self, x_start, noise, t_index):  # tfm_model.py:291-302

@@ -14,6 +14,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from . import ops
 from .build import MODEL_REGISTRY
 from .engine import EncoderEngine, GradStore
 from .functional import EncoderFn, kl_topk_loss, l2norm, linear_f32, mse_loss, step_logits
@@ -308,7 +309,7 @@ class VisionTransformer(nn.Module):
             return x, teacher_x, mse
 
         if not self.training:
-            x = torch.softmax(x, dim=1)
+            x = ops.softmax_rows(x.contiguous())
         return x
 
 

@@ -430,6 +430,13 @@ def check_loss():
         out.append((f"milnce loss n={n} C={C}", abs(l.item() - lref.item()) / abs(lref.item()), 1e-5))
         out.append((f"milnce dV n={n} C={C}", rel(vd.grad, vr.grad), 1e-4))
         out.append((f"milnce dT n={n} C={C}", rel(td.grad, tr.grad), 1e-4))
+    lg = torch.randn(7, 9871, generator=g) * 6
+    out.append(("softmax rows (eval probabilities)", rel(ops.softmax_rows(lg.to(dev())), torch.softmax(lg, 1)), 1e-5))
+    xg = (torch.randn(4, 512, generator=g) * 2).requires_grad_(True)
+    dyg = torch.randn(4, 512, generator=g)
+    F.gelu(xg).backward(dyg)
+    out.append(("gelu f32", rel(ops.gelu_f32(xg.detach().to(dev())), F.gelu(xg.detach())), 1e-5))
+    out.append(("gelu f32 backward", rel(ops.gelu_f32(xg.detach().to(dev()), dyg.to(dev())), xg.grad), 1e-5))
     a = torch.randn(8, 512, generator=g); b = torch.randn(8, 512, generator=g)
     ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     lref = F.mse_loss(ar, br); lref.backward()
