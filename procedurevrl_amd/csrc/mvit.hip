@@ -532,13 +532,19 @@ __global__ __launch_bounds__(256) void rel_fwd_kernel(const bf16* __restrict__ Q
     else R = Rt + (long)it[t * g.kt + (j - g.kh - g.kw)] * HD;
     const bf16* qp = Q + (bh * (Lq + 1) + q) * HD;
     float a = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < HD; ++c) a = fmaf((float)qp[c], R[c], a);
+#pragma unroll 4
+    for (int c8 = 0; c8 < HD / 8; ++c8) {                       // 16-byte loads: 8 bf16 of q, 2 x 4 floats of R
+      const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + c8 * 8);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(R + c8 * 8), r1 = *reinterpret_cast<const f32x4*>(R + c8 * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a = fmaf((float)qv[e], r0[e], fmaf((float)qv[4 + e], r1[e], a));
+    }
     rel[idx] = a;
   }
 }
 
 // dQ[bh][q][c] += sum_j drel[bh][q][j] * R_j(q)[c]     (dQ is the bf16 gradient written by the attention backward)
+// one thread per (q, 4 channels)
 __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
                                                         const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                         const float* __restrict__ Rt, const int* __restrict__ ih,
@@ -546,20 +552,23 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
                                                         bf16* __restrict__ dQ) {
   const int J = g.kh + g.kw + g.kt;
   const int Lq = g.qt * g.qh * g.qw;
-  const long total = (long)g.BH * Lq * HD;
+  const long total = (long)g.BH * Lq * (HD / 4);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % HD);
-    const long bq = idx / HD;
+    const int c = (int)(idx % (HD / 4)) * 4;
+    const long bq = idx / (HD / 4);
     const int q = (int)(bq % Lq);
     const long bh = bq / Lq;
     const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
     const float* d = drel + bq * J;
-    float a = 0.f;
-    for (int j = 0; j < g.kh; ++j) a = fmaf(d[j], Rh[(long)ih[y * g.kh + j] * HD + c], a);
-    for (int j = 0; j < g.kw; ++j) a = fmaf(d[g.kh + j], Rw[(long)iw[x * g.kw + j] * HD + c], a);
-    for (int j = 0; j < g.kt; ++j) a = fmaf(d[g.kh + g.kw + j], Rt[(long)it[t * g.kt + j] * HD + c], a);
-    bf16* p = dQ + (bh * (Lq + 1) + q) * HD + c;
-    *p = (bf16)((float)*p + a);
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < g.kh; ++j) a += d[j] * *reinterpret_cast<const f32x4*>(Rh + (long)ih[y * g.kh + j] * HD + c);
+    for (int j = 0; j < g.kw; ++j) a += d[g.kh + j] * *reinterpret_cast<const f32x4*>(Rw + (long)iw[x * g.kw + j] * HD + c);
+    for (int j = 0; j < g.kt; ++j) a += d[g.kh + g.kw + j] * *reinterpret_cast<const f32x4*>(Rt + (long)it[t * g.kt + j] * HD + c);
+    bf16x4* p = reinterpret_cast<bf16x4*>(dQ + (bh * (Lq + 1) + q) * HD + c);
+    bf16x4 v = *p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16)((float)v[e] + a[e]);
+    *p = v;
   }
 }
 
@@ -793,7 +802,7 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
       rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
     return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)BH * qt * qh * qw * HD;
+  const long total = (long)BH * qt * qh * qw * (HD / 4);
   hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
                      (bf16*)dQ);
   PVRL_LAUNCH_CHECK();
