@@ -44,6 +44,7 @@ int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, in
 
 /* Benchmark knob: force the GEMM tile (0 heuristic, 1 128x128, 2 256x128, 3 256x256). Not used by the model. */
 int pvrl_debug_set_gemm_tile(int tile);
+int pvrl_debug_set_gemm_gm(int gm);   /* rasterisation group height (tile rows per XCD panel group), default 2 */
 int pvrl_debug_set_gemm_tn_tile(int tile);
 
 /* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits

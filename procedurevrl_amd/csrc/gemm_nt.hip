@@ -34,6 +34,7 @@ struct GemmNT {
   void* out1; long ld1;
   int tiles_m, tiles_n, nwg;
   int m_off;   // global row of local row 0 (a launch may cover a row range of the logical GEMM)
+  int gm;      // rasterisation group height in tiles
 };
 
 constexpr int BK = 64;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   // contiguous range of M-panels and walks it in groups of GM panels x all N-tiles, panel index fastest, so the
   // ~64 tiles resident on an XCD share GM activation panels and a few weight tiles instead of sweeping the whole
   // weight matrix per panel.
-  constexpr int GM = 8;
+  const int GM = p.gm;   // tile rows per rasterisation group (benchmark knob, default 8)
   int tm, tn;
   {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -680,6 +681,7 @@ int launch_tile(GemmNT p, hipStream_t s) {
   return PVRL_OK;
 }
 
+int g_nt_gm = 2;   // measured on MI355X: 2 tile rows per group is 1-3 % ahead of 8-32 (A rows stay hot while W cycles)
 int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x256 deep pipeline (knob)
 
 template <int EPI>
@@ -744,7 +746,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
-  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0;
+  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = g_nt_gm;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s);
@@ -756,6 +758,12 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     case PVRL_EPI_DQGELU: return launch_nt<PVRL_EPI_DQGELU>(p, s);
     default: return PVRL_EINVAL;
   }
+}
+
+extern "C" int pvrl_debug_set_gemm_gm(int gm) {
+  if (gm < 1) return PVRL_EINVAL;
+  g_nt_gm = gm;
+  return PVRL_OK;
 }
 
 extern "C" int pvrl_debug_set_gemm_tile(int tile) {

@@ -73,6 +73,14 @@ def main():
             gemm_case(f"ab[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] dfc2  dgelu M x3072x768", M, 3072, 768, L.PVRL_EPI_DGELU)
     L.call("pvrl_debug_set_gemm_tile", 0)
+    for rep in range(2):
+        for gm in (1, 2, 3, 4):
+            L.call("pvrl_debug_set_gemm_gm", gm)
+            gemm_case(f"gm[{gm}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
+            gemm_case(f"gm[{gm}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
+            gemm_case(f"gm[{gm}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
+            gemm_case(f"gm[{gm}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
+    L.call("pvrl_debug_set_gemm_gm", 2)
     gemm_case("nt-auto qkv      bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
     gemm_case("nt proj     bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
     gemm_case("nt fc/projs resid M x768x768", R, 768, 768, L.PVRL_EPI_RESID_F32)
