@@ -6,8 +6,3 @@ for c in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_ID
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $c -d $OUT/$n -o pmc --output-format csv -- python $R/tools/bench_kernels.py tn > $OUT/$n.log 2>&1
 done
-python - <<'PY'
-import csv, glob, collections, os
-out = os.environ.get("OUT", "gpurun_out/pmc_tn")
-for f in sorted(glob.glob(os.path.expandvars("$PWD") + "/nonexistent")): pass
-PY
