@@ -167,3 +167,43 @@ def load_pretrained(model, cfg):
             new_state.setdefault(key.replace("norm1", "temporal_norm1"), state[key])
     missing, unexpected = model.load_state_dict(new_state, strict=False)
     print("\nMissing keys: ", missing, "\nUnexpected_keys: ", unexpected)
+
+
+def convert_mvit_image_state(state, model_dict):
+    """Released image MViTv2 checkpoint -> video encoder state (lib/models/helpers.py:124-142): every key gets the
+    `video_encoder.` prefix; pooling / patch-embed conv weights are repeated over the new time axis (not divided by t, as in
+    the reference); relative-position tables are linearly interpolated to the model's length."""
+    new = OrderedDict()
+    for key, v in state.items():
+        tgt = "video_encoder." + key
+        if "pool_" in key or "patch_embed.proj.weight" in key:
+            t = model_dict[tgt].shape[2]
+            new[tgt] = v.unsqueeze(2).repeat(1, 1, t, 1, 1)
+        elif "rel_pos_" in key:
+            n = model_dict[tgt].shape[0]
+            r = F.interpolate(v.reshape(1, v.shape[0], -1).permute(0, 2, 1), size=n, mode="linear")
+            new[tgt] = r.reshape(-1, n).permute(1, 0).squeeze()
+        else:
+            new[tgt] = v
+    return new
+
+
+def load_pretrained_mvit(model, cfg):
+    """Initialise the MViT wrapper (`procedurevrl_amd.mvit.VisionTransformer`) from a LOCAL copy of the checkpoint the
+    reference downloads (lib/models/mvit.py:41, helpers.py:108-142): an image MViTv2 `model_state` is converted, an already
+    converted / video checkpoint (keys prefixed `video_encoder.`) is loaded as is; shape-matched, non-strict."""
+    path = cfg.TIMESFORMER.PRETRAINED_MODEL
+    if not path:
+        raise FileNotFoundError("MODEL.PRETRAINED is True but TIMESFORMER.PRETRAINED_MODEL is empty: give a local copy of "
+                                "MViTv2_S_in1k.pyth (the reference's URL download needs network), or set MODEL.PRETRAINED False")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    state = ck["model_state"] if isinstance(ck, dict) and "model_state" in ck else ck
+    model_dict = model.state_dict()
+    if not any(k.startswith("video_encoder.") for k in state):
+        state = convert_mvit_image_state(state, model_dict)
+    hw = state.get("head.weight")
+    if hw is not None and hw.size() != model.head.weight.size():
+        state.pop("head.weight", None)
+        state.pop("head.bias", None)
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    print("\nMissing keys: ", missing, "\nUnexpected_keys: ", unexpected)

@@ -519,9 +519,10 @@ class MViT(nn.Module):
                                        text_model=cfg.MODEL.TEXT_MODEL, num_seg=cfg.MODEL.NUM_SEG, cfg=cfg)
         self.attention_type = cfg.TIMESFORMER.ATTENTION_TYPE
         if self.pretrained:
-            raise FileNotFoundError("MODEL.PRETRAINED for MViT needs the released MViTv2_S_in1k.pyth (lib/models/mvit.py:41); "
-                                    "there is no network here -- load a local checkpoint with checkpoint.load_checkpoint")
-        print("not loading any pretrained weights!")
+            from .checkpoint import load_pretrained_mvit
+            load_pretrained_mvit(self.model, cfg)
+        else:
+            print("not loading any pretrained weights!")
 
     def forward(self, x, rng=None):
         return self.model(x) if rng is None else self.model(x, rng=rng)

@@ -323,6 +323,47 @@ def make_lr_table(defaults, out):
     out["lr_table"] = tab
 
 
+def imagenet_vit_shapes(depth, num_patches=196, dim=768, classes=1000):
+    """state_dict layout of timm's jx_vit_base_p16_224 (the URL checkpoint of lib/models/vit.py:36-39), `depth` blocks"""
+    sh = {"cls_token": (1, 1, dim), "pos_embed": (1, num_patches + 1, dim), "patch_embed.proj.weight": (dim, 3, 16, 16),
+          "patch_embed.proj.bias": (dim,), "norm.weight": (dim,), "norm.bias": (dim,), "head.weight": (classes, dim),
+          "head.bias": (classes,)}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sh[p + n + ".weight"] = (dim,); sh[p + n + ".bias"] = (dim,)
+        sh[p + "attn.qkv.weight"] = (3 * dim, dim); sh[p + "attn.qkv.bias"] = (3 * dim,)
+        sh[p + "attn.proj.weight"] = (dim, dim); sh[p + "attn.proj.bias"] = (dim,)
+        sh[p + "mlp.fc1.weight"] = (4 * dim, dim); sh[p + "mlp.fc1.bias"] = (4 * dim,)
+        sh[p + "mlp.fc2.weight"] = (dim, 4 * dim); sh[p + "mlp.fc2.bias"] = (dim,)
+    return sh
+
+
+def tensor_stats(t):
+    t = t.double().flatten()
+    return [float(t.sum()), float(t.abs().sum()), float((t * torch.arange(1, t.numel() + 1, dtype=torch.float64)).sum() / t.numel())]
+
+
+def make_pretrained(defaults, vit, tfm, out, tmpdir):
+    """lib/models/helpers.py:load_pretrained on the reference TimeSformer wrapper with an ImageNet-ViT-shaped checkpoint
+    (the URL download is replaced by a synthetic state dict): head dropped, pos_embed resized 196 -> 49 patches,
+    attn / norm1 cloned into temporal_attn / temporal_norm1.  Stored: per-key statistics of the resulting state_dict."""
+    helpers = importlib.import_module("lib.models.helpers")
+    cfg, model, _ = build_ref_model(defaults, vit, tfm, depth=1, crop=112, K=32, text_layers=1, tmpdir=tmpdir)
+    fake = orc.seeded_state(imagenet_vit_shapes(1), 91)
+    helpers.model_zoo.load_url = lambda *a, **k: {k2: v.clone() for k2, v in fake.items()}
+    inner = model.model
+    inner.default_cfg = dict(url="https://synthetic/jx_vit_base_p16_224.pth", num_classes=1000, first_conv="patch_embed.proj",
+                             classifier="head")
+    before = {k: v.clone() for k, v in inner.state_dict().items()}
+    helpers.load_pretrained(inner, num_classes=inner.num_classes, in_chans=3, filter_fn=None, img_size=112, num_patches=49,
+                            attention_type="divided_space_time", pretrained_model="", num_frames=8, pre_num=0)
+    after = inner.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    out["pretrained"] = dict(seed=91, depth=1, crop=112, K=32, changed=changed,
+                             stats={k: tensor_stats(after[k]) for k in changed})
+
+
 MVIT_SMALL = dict(frames=4, crop=64, depth=4, dim_mul=[[1, 2.0], [3, 2.0]], head_mul=[[1, 2.0], [3, 2.0]],
                   pool_q=[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]], kv_adaptive=[1, 4, 4])
 
@@ -339,6 +380,63 @@ def mvit_cfg(defaults, frames, crop, small=None):
         cfg.MVIT.POOL_Q_STRIDE = small["pool_q"]
         cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE = small["kv_adaptive"]
     return cfg
+
+
+def mvit_image_state_shapes(enc_shapes):
+    """A 2-D (image) MViTv2 checkpoint for a video encoder with parameter shapes `enc_shapes`: conv weights without the
+    time axis, no rel_pos_t, spatial rel-pos tables 4 rows longer (forces the linear interpolation), a 1000-way head."""
+    sh = {}
+    for k, v in enc_shapes.items():
+        if "rel_pos_t" in k:
+            continue
+        if "pool_" in k or k == "patch_embed.proj.weight":
+            sh[k] = (v[0], v[1], v[3], v[4])
+        elif "rel_pos_" in k:
+            sh[k] = (v[0] + 4, v[1])
+        else:
+            sh[k] = tuple(v)
+    last = enc_shapes["norm.weight"][0]
+    sh["head.projection.weight"] = (1000, last)
+    sh["head.projection.bias"] = (1000,)
+    return sh
+
+
+def make_mvit_pretrained(defaults, out, tmpdir):
+    """lib/models/helpers.py:load_pretrained on the reference MViT wrapper with an image-MViTv2-shaped checkpoint (URL
+    download replaced by a synthetic dict): conv weights repeated over time, rel-pos tables interpolated, `video_encoder.`
+    prefix added (helpers.py:124-142).  Stored: per-key statistics of the tensors that changed."""
+    from oracle import mvit_oracle as mo
+    helpers = importlib.import_module("lib.models.helpers")
+    mvit_mod = importlib.import_module("lib.models.mvit")
+    sm = MVIT_SMALL
+    cfg = mvit_cfg(defaults, sm["frames"], sm["crop"], sm)
+    cfg.MODEL.MODEL_NAME = "MViT"
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NUM_CLASSES = 32
+    cfg.MODEL.TEXT_MODEL = ""
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.DEV.ORDER_PRETRAIN_ENABLED = False
+    cfg.NUM_GPUS = 0
+    label = torch.randn(32, 512, generator=torch.Generator().manual_seed(5))
+    path = os.path.join(tmpdir, "label_emb_mvit.pth")
+    torch.save(label, path)
+    cfg.TRAIN.LABEL_EMB = path
+    torch.manual_seed(0)
+    model = mvit_mod.MViT(cfg)
+    inner = model.model
+    enc_shapes = mo.encoder_shapes(dict(cfg.MVIT), sm["frames"], sm["crop"])
+    fake = orc.seeded_state(mvit_image_state_shapes(enc_shapes), 93)
+    helpers.model_zoo.load_url = lambda *a, **k: {"model_state": {k2: v.clone() for k2, v in fake.items()}}
+    inner.default_cfg = dict(url="https://synthetic/mvit/MViTv2_S_in1k.pyth", num_classes=1000, first_conv="patch_embed.proj",
+                             classifier="head")
+    os.makedirs("exps", exist_ok=True)
+    before = {k: v.clone() for k, v in inner.state_dict().items()}
+    helpers.load_pretrained(inner, num_classes=inner.num_classes, in_chans=3, filter_fn=None, img_size=sm["crop"],
+                            num_patches=16, attention_type="", pretrained_model="", num_frames=sm["frames"], pre_num=0)
+    after = inner.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    out["mvit_pretrained"] = dict(seed=93, cfg=sm, mvit={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in dict(cfg.MVIT).items()},
+                                  changed=changed, stats={k: tensor_stats(after[k]) for k in changed})
 
 
 def make_mvit(defaults, out):
@@ -422,6 +520,26 @@ def make_input_pipeline(out):
 
 def main():
     import tempfile
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "pretrained":
+        defaults, vit, tfm, dist_mod, losses = import_reference()
+        out = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            cwd = os.getcwd(); os.chdir(tmp)
+            try:
+                make_pretrained(defaults, vit, tfm, out, tmp)
+            finally:
+                os.chdir(cwd)
+        torch.save(out["pretrained"], os.path.join(HERE, "pretrained.pt"))
+        print("wrote pretrained", os.path.getsize(os.path.join(HERE, "pretrained.pt")) // 1024, "KiB", len(out["pretrained"]["changed"]))
+        with tempfile.TemporaryDirectory() as tmp:
+            cwd = os.getcwd(); os.chdir(tmp)
+            try:
+                make_mvit_pretrained(defaults, out, tmp)
+            finally:
+                os.chdir(cwd)
+        torch.save(out["mvit_pretrained"], os.path.join(HERE, "mvit_pretrained.pt"))
+        print("wrote mvit_pretrained", len(out["mvit_pretrained"]["changed"]))
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit":
         _install_stubs()
         defaults = importlib.import_module("lib.config.defaults")
@@ -445,6 +563,7 @@ def main():
         make_block(vit, out)
         make_e2e(defaults, vit, tfm, out, tmp)
         make_forecast(defaults, vit, tfm, out, tmp)
+        make_pretrained(defaults, vit, tfm, out, tmp)
     make_small_ops(vit, losses, out)
     make_lr_table(defaults, out)
     make_allgather(dist_mod, out)

@@ -201,3 +201,74 @@ def test_mvit_unsupported_settings_raise():
     cfg.MVIT.DROPPATH_RATE = 0.2
     with pytest.raises(NotImplementedError):
         mvit.MViT(cfg)
+
+
+def test_load_pretrained_matches_reference_loader(tmp_path):
+    """checkpoint.load_pretrained vs the reference's lib/models/helpers.py:load_pretrained (tests/golden/pretrained.pt: the
+    reference loader run on the reference model with an ImageNet-ViT-shaped checkpoint): the same 24 tensors change and
+    end up with the same contents -- classifier dropped (1000 != 512 rows), pos_embed resized 196 -> 49 patches
+    (nearest), attn / norm1 cloned into temporal_attn / temporal_norm1."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import imagenet_vit_shapes, tensor_stats
+    from oracle import timesformer_oracle as orc
+    from procedurevrl_amd.build import MODEL_REGISTRY
+    from procedurevrl_amd import vit  # noqa: F401
+    from procedurevrl_amd.config import get_cfg
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "pretrained.pt"), weights_only=False)
+    ck = tmp_path / "jx_vit_base_p16_224.pth"
+    torch.save(orc.seeded_state(imagenet_vit_shapes(g["depth"]), g["seed"]), ck)
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "vit_base_patch16_224_develop"
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NUM_CLASSES = g["K"]
+    cfg.TIMESFORMER.DEPTH = g["depth"]
+    cfg.DATA.TRAIN_CROP_SIZE = g["crop"]
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.NUM_GPUS = 0
+    cfg.TRAIN.LABEL_EMB = synthetic_label_emb(g["K"], 512, seed=1)
+    model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    inner = model.model
+    before = {k: v.clone() for k, v in inner.state_dict().items()}
+    cfg.TIMESFORMER.PRETRAINED_MODEL = str(ck)
+    from procedurevrl_amd.checkpoint import load_pretrained
+    load_pretrained(inner, cfg)
+    after = inner.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    assert changed == g["changed"]
+    for k in changed:
+        got, ref = tensor_stats(after[k]), g["stats"][k]
+        assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(got, ref)), (k, got, ref)
+
+
+def test_mvit_image_checkpoint_conversion_matches_reference_loader(tmp_path):
+    """checkpoint.load_pretrained_mvit vs the reference's helpers.load_pretrained on its MViT wrapper with an image-MViTv2
+    shaped checkpoint (tests/golden/mvit_pretrained.pt): conv weights repeated over time, rel-pos tables interpolated,
+    `video_encoder.` prefix -- the same 101 tensors change and end up with the same contents."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import mvit_image_state_shapes, tensor_stats
+    from oracle import mvit_oracle as mo
+    from oracle import timesformer_oracle as orc
+    from procedurevrl_amd import mvit
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "mvit_pretrained.pt"), weights_only=False)
+    c = g["cfg"]
+    cfg, _ = _mvit_cfg_from_golden("mvit_small", c["frames"], c["crop"])
+    model = mvit.MViT(cfg)
+    inner = model.model
+    fake = orc.seeded_state(mvit_image_state_shapes(mo.encoder_shapes(g["mvit"], c["frames"], c["crop"])), g["seed"])
+    ck = tmp_path / "MViTv2_S_in1k.pyth"
+    torch.save({"model_state": fake}, ck)
+    before = {k: v.clone() for k, v in inner.state_dict().items()}
+    cfg.TIMESFORMER.PRETRAINED_MODEL = str(ck)
+    from procedurevrl_amd.checkpoint import load_pretrained_mvit
+    load_pretrained_mvit(inner, cfg)
+    after = inner.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    assert changed == g["changed"]
+    for k in changed:
+        got, ref = tensor_stats(after[k]), g["stats"][k]
+        assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(got, ref)), (k, got, ref)
