@@ -320,12 +320,13 @@ def vit_forward_forecast_eval(sd, x, label_emb, temp, depth, num_seg, max_len=9,
 
 
 def vit_forward_train(sd, inputs, meta, label_emb, temp, depth, max_len, order_layers, text_layers, rng,
-                      order_recog_batch=9, droppath=None):
+                      order_recog_batch=9, droppath=None, encoder=None):
     """VisionTransformer.forward in pre-training mode, vit.py:283-352 (ORDER_PRETRAIN_ENABLED, MATCH_LANG_EMB,
-    text model present, training)."""
+    text model present, training).  `encoder(x) -> features` replaces the TimeSformer encoder for the MViT wrapper
+    (lib/models/mvit.py:109-229 is the same code around `self.video_encoder`)."""
     batch_size = inputs.shape[0]
     x = rearrange(inputs, "b m c t h w -> (b m) c t h w", m=max_len)
-    feat = forward_features(sd, x, depth, droppath=droppath)
+    feat = encoder(x) if encoder is not None else forward_features(sd, x, depth, droppath=droppath)
     video_emb, logits = head_logits(sd, feat, label_emb, temp)
     teacher_x = pseudo_labels(sd, meta["clip_text_ids"], meta["clip_vis_feat"], label_emb, temp, text_layers)
     pred_emb, mask_inds, mse, inter = order_tfm_pretrain(sd, "order_tfm.", video_emb, max_len, order_layers, 8,

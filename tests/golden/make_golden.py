@@ -439,6 +439,101 @@ def make_mvit_pretrained(defaults, out, tmpdir):
                                   changed=changed, stats={k: tensor_stats(after[k]) for k in changed})
 
 
+def make_mvit_e2e(defaults, tfm, out, tmpdir):
+    """The reference's registered `MViT` model (lib/models/mvit.py) in train mode on one video of 9 clips at the reduced
+    geometry: (pred, teacher, mse), KL + MSE losses and parameter gradients, all RNG draws captured -- the MViT twin of
+    make_e2e."""
+    from oracle import mvit_oracle as mo
+    mvit_mod = importlib.import_module("lib.models.mvit")
+    sm = MVIT_SMALL
+    K, text_layers = 40, 2
+    cfg = mvit_cfg(defaults, sm["frames"], sm["crop"], sm)
+    cfg.MODEL.MODEL_NAME = "MViT"
+    cfg.MODEL.PRETRAINED = False
+    cfg.MODEL.NUM_CLASSES = K
+    cfg.MODEL.TEXT_MODEL = "clip_vit_b_16"
+    cfg.MODEL.LOSS_FUNC = "kldiv"
+    cfg.DEV.MATCH_LANG_EMB = True
+    cfg.DEV.ORDER_PRETRAIN_ENABLED = True
+    cfg.NUM_GPUS = 0
+    cfg.TRAIN.TEXT = "synthetic"
+    g = torch.Generator().manual_seed(79)
+    label = torch.randn(K, 512, generator=g) * 0.38
+    label = label / label.norm(dim=1, keepdim=True)
+    path = os.path.join(tmpdir, "label_emb_mvit_e2e.pth")
+    torch.save(label, path)
+    cfg.TRAIN.LABEL_EMB = path
+
+    class RefClipText(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            mask = torch.empty(77, 77).fill_(float("-inf")).triu_(1)
+            self.token_embedding = torch.nn.Embedding(49408, 512)
+            self.positional_embedding = torch.nn.Parameter(torch.zeros(77, 512))
+            self.transformer = tfm.TemporalModelling(width=512, layers=text_layers, heads=8, dropout=0.0, attn_mask=mask)
+            self.ln_final = tfm.LayerNorm(512)
+            self.text_projection = torch.nn.Parameter(torch.zeros(512, 512))
+            self.logit_scale = torch.nn.Parameter(torch.ones([]))
+            self.visual = torch.nn.Identity()
+
+        def encode_text(self, text):
+            x = self.token_embedding(text) + self.positional_embedding
+            x = self.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+            x = self.ln_final(x)
+            return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.text_projection
+
+    sys.modules["clip"].load = lambda *a, **k: (RefClipText(), None)
+    mvit_mod.clip.load = sys.modules["clip"].load
+    torch.manual_seed(0)
+    model = mvit_mod.MViT(cfg)
+    sd = load_seeded(model, 61)
+    model.train()
+    model.model.text_model.eval()
+    b = 1
+    inputs = torch.randn(b, 9, 3, sm["frames"], sm["crop"], sm["crop"], generator=g)
+    from procedurevrl_amd.datasets import synthetic_text_ids
+    ids = synthetic_text_ids(b * 9, g)
+    vis = torch.randn(b * 9, 512, generator=g) * 0.4
+    meta = {"clip_text_ids": ids.view(b * 9, 1, 77), "clip_vis_feat": vis}
+    with CaptureRNG() as cap:
+        pred, teacher, mse = model([inputs, meta])
+    draws = cap.log
+    mask_inds = draws[0][1]
+    k = 1
+    pad_start = []
+    for i in range(b):
+        if int(mask_inds[i]) + 1 == 9:
+            pad_start.append(9)
+        else:
+            assert draws[k][0] == "randint"
+            pad_start.append(int(draws[k][1]))
+            k += 1
+    noises = [d[1] for d in draws[k:k + 4]]
+    assert all(d[0] == "randn_like" for d in draws[k:k + 4])
+    rand_inds = draws[k + 4][1]
+    assert draws[k + 4][0] == "randperm"
+    import torch.nn.functional as F
+    with torch.no_grad():
+        tp = F.softmax(teacher, 1)
+        tp = (tp.unsqueeze(1) * (tp.unsqueeze(1) == tp.topk(k=5, dim=1)[0].unsqueeze(2)).float()).sum(1)
+        tp = tp / tp.sum(1, keepdim=True)
+    loss1 = torch.nn.KLDivLoss(reduction="batchmean")(F.log_softmax(pred, dim=1), tp)
+    loss2 = torch.nn.MSELoss(reduction="mean")(mse[0], mse[1])
+    (loss1 + loss2).backward()
+    named = dict(model.named_parameters())
+    keep = ["model.video_encoder.cls_token", "model.video_encoder.blocks.0.attn.rel_pos_h", "model.video_encoder.blocks.1.proj.bias",
+            "model.video_encoder.blocks.2.attn.pool_k.weight", "model.video_encoder.blocks.3.mlp.fc2.bias", "model.head.weight",
+            "model.order_tfm.pad_embedding.weight", "model.order_tfm.time_mlp.3.bias", "model.video_encoder.norm.weight"]
+    out["mvit_e2e"] = dict(seed=61, cfg=sm, mvit={k2: (list(v) if isinstance(v, (list, tuple)) else v) for k2, v in dict(cfg.MVIT).items()},
+                           K=K, text_layers=text_layers, wsum=checksum(sd), inputs=inputs, clip_text_ids=ids, clip_vis_feat=vis,
+                           label_emb=label,
+                           rng=dict(mask_inds=mask_inds, pad_start=torch.tensor(pad_start), noises=noises, rand_inds=rand_inds),
+                           pred=pred.detach(), teacher=teacher.detach(), mse0=mse[0].detach(), mse1=mse[1].detach(),
+                           loss1=float(loss1), loss2=float(loss2), grads={k2: named[k2].grad.clone() for k2 in keep},
+                           grad_sums={k2: float(p.grad.double().abs().sum()) for k2, p in named.items() if p.grad is not None},
+                           state_keys=sorted(model.state_dict().keys()))
+
+
 def make_mvit(defaults, out):
     """The reference MViT_encoder (lib/models/slowfast_mvit/mvit.py) on a reduced geometry that still has every block
     flavour of MViTv2-S (plain, q-strided stage transition with max-pool skip + channel projection, rel-pos with
@@ -540,6 +635,14 @@ def main():
         torch.save(out["mvit_pretrained"], os.path.join(HERE, "mvit_pretrained.pt"))
         print("wrote mvit_pretrained", len(out["mvit_pretrained"]["changed"]))
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit_e2e":
+        defaults, vit, tfm, dist_mod, losses = import_reference()
+        out = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            make_mvit_e2e(defaults, tfm, out, tmp)
+        torch.save(out["mvit_e2e"], os.path.join(HERE, "mvit_e2e.pt"))
+        print("wrote mvit_e2e", os.path.getsize(os.path.join(HERE, "mvit_e2e.pt")) // 1024, "KiB")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit":
         _install_stubs()
         defaults = importlib.import_module("lib.config.defaults")
@@ -564,11 +667,18 @@ def main():
         make_e2e(defaults, vit, tfm, out, tmp)
         make_forecast(defaults, vit, tfm, out, tmp)
         make_pretrained(defaults, vit, tfm, out, tmp)
+        make_mvit_e2e(defaults, tfm, out, tmp)
     make_small_ops(vit, losses, out)
     make_lr_table(defaults, out)
     make_allgather(dist_mod, out)
     make_input_pipeline(out)
     make_mvit(defaults, out)
+    with tempfile.TemporaryDirectory() as tmp:       # the reference's MViT conversion writes ./exps/...converted.pyth
+        cwd = os.getcwd(); os.chdir(tmp)
+        try:
+            make_mvit_pretrained(defaults, out, tmp)
+        finally:
+            os.chdir(cwd)
     for k, v in out.items():
         torch.save(v, os.path.join(HERE, k + ".pt"))
         print("wrote", k, os.path.getsize(os.path.join(HERE, k + ".pt")) // 1024, "KiB")

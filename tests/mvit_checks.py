@@ -274,6 +274,52 @@ def check_mvit_encoder_small_golden():
     return out
 
 
+def check_mvit_e2e_golden():
+    """The registered `MViT` model end to end vs the REFERENCE's (tests/golden/mvit_e2e.pt): full pre-training forward
+    (encoder + CLIP-text teacher + order transformer + output assembly) with the reference's RNG draws pinned, KL + MSE
+    losses and parameter gradients."""
+    import test_oracle_golden as tg
+    from procedurevrl_amd.build import build_model
+    from procedurevrl_amd.vit import pretrain_loss
+    from oracle import timesformer_oracle as orc
+    f = _load("mvit_e2e")
+    c = f["cfg"]
+    cfg = _mvit_cfg(f["mvit"], c["frames"], c["crop"], f["K"])
+    cfg.MODEL.TEXT_MODEL = "clip_vit_b_16"
+    cfg.SYNTHETIC.TEXT_LAYERS = f["text_layers"]
+    cfg.DEV.ORDER_PRETRAIN_ENABLED = True
+    cfg.TRAIN.LABEL_EMB = f["label_emb"].clone()
+    model = build_model(cfg, gpu_id=0)
+    sh = {"video_encoder." + k: v for k, v in mo.encoder_shapes(f["mvit"], c["frames"], c["crop"]).items()}
+    last = sh["video_encoder.norm.weight"][0]
+    sh.update({"head.weight": (512, last), "head.bias": (512,)})
+    sh.update(tg.orc_order_shapes())
+    sh.update(tg.orc_text_shapes(f["text_layers"]))
+    full = orc.seeded_state({"model." + k: v for k, v in sh.items()}, f["seed"])
+    out = [("mvit e2e state_dict keys == reference", float(sorted(full.keys()) != f["state_keys"]), 0.0)]
+    model.load_state_dict(full, strict=True)
+    model.to(DEV).train()
+    meta = {"clip_text_ids": f["clip_text_ids"].to(DEV), "clip_vis_feat": f["clip_vis_feat"].to(DEV)}
+    rng = dict(order=dict(mask_inds=f["rng"]["mask_inds"].to(DEV), pad_start=f["rng"]["pad_start"].to(DEV),
+                          noises=[n.to(DEV) for n in f["rng"]["noises"]]), rand_inds=f["rng"]["rand_inds"].to(DEV))
+    pred, teacher, mse = model([f["inputs"].to(DEV), meta], rng=rng)
+    out += [("mvit e2e pred logits vs reference", rel(pred, f["pred"]), 1.5e-2),
+            ("mvit e2e teacher logits vs reference", rel(teacher, f["teacher"]), 1e-2),
+            ("mvit e2e mse target vs reference", rel(mse[0], f["mse0"]), 1e-2),
+            ("mvit e2e mse pred vs reference", rel(mse[1], f["mse1"]), 1e-2)]
+    loss, l1, l2 = pretrain_loss(pred, teacher, mse, cfg)
+    out.append(("mvit e2e loss1 (KL)", abs(float(l1.detach()) - f["loss1"]) / abs(f["loss1"]), 2e-2))
+    out.append(("mvit e2e loss2 (MSE)", abs(float(l2.detach()) - f["loss2"]) / abs(f["loss2"]), 2e-2))
+    for p in model.parameters():
+        p.grad = None
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k, g in f["grads"].items():
+        tol = 6e-2 if "rel_pos" in k else 4e-2
+        out.append((f"mvit e2e grad {k[6:]}", rel(named[k].grad, g), tol))
+    return out
+
+
 def check_mvit_s_features():
     """MViTv2-S geometry (16 x 224^2, 16 blocks, 34 M parameters): one clip's features vs the reference's."""
     g = _load("mvit_s")
@@ -327,4 +373,4 @@ def check_mvit_pretrain_steps():
             ("mvit pretraining: loss after 5 steps / first loss", losses[-1] / losses[0], 0.999)]
 
 
-ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
+ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]

@@ -234,3 +234,31 @@ def test_mvit_oracle_full_size_features():
     with torch.no_grad():
         feat = mo.forward_features(sd, x, g["mvit"])
     assert torch.allclose(feat, g["feat"], atol=5e-5, rtol=5e-5), (feat - g["feat"]).abs().max()
+
+
+def test_mvit_wrapper_e2e_train_forward_loss_grads():
+    """The reference's registered MViT model (tests/golden/mvit_e2e.pt): the oracle's wrapper restatement around the
+    MViT encoder restatement reproduces (pred, teacher, mse), both losses and the stored gradients."""
+    from oracle import mvit_oracle as mo
+    f = load("mvit_e2e")
+    c = f["cfg"]
+    sh = {"video_encoder." + k: v for k, v in mo.encoder_shapes(f["mvit"], c["frames"], c["crop"]).items()}
+    last = sh["video_encoder.norm.weight"][0]
+    sh.update({"head.weight": (512, last), "head.bias": (512,)})
+    sh.update(orc_order_shapes())
+    sh.update(orc_text_shapes(f["text_layers"]))
+    full = orc.seeded_state({"model." + k: v for k, v in sh.items()}, f["seed"])
+    assert sorted(full.keys()) == f["state_keys"]
+    assert abs(checksum(full) - f["wsum"]) < 1e-6 * f["wsum"]
+    sd = {k[len("model."):]: v.requires_grad_(not k.startswith("model.text_model")) for k, v in full.items()}
+    enc = {k[len("video_encoder."):]: v for k, v in sd.items() if k.startswith("video_encoder.")}
+    meta = {"clip_text_ids": f["clip_text_ids"], "clip_vis_feat": f["clip_vis_feat"]}
+    pred, teacher, mse = orc.vit_forward_train(sd, f["inputs"], meta, f["label_emb"], 0.02, None, 9, 4, f["text_layers"], f["rng"],
+                                               encoder=lambda x: mo.forward_features(enc, x, f["mvit"]))
+    assert rel(pred, f["pred"]) < 1e-4 and rel(teacher, f["teacher"]) < 1e-4
+    assert rel(mse[0], f["mse0"]) < 1e-4 and rel(mse[1], f["mse1"]) < 1e-4
+    loss, l1, l2 = orc.pretrain_loss(pred, teacher, mse, 5)
+    assert abs(float(l1) - f["loss1"]) < 1e-4 * abs(f["loss1"]) and abs(float(l2) - f["loss2"]) < 1e-4 * abs(f["loss2"])
+    loss.backward()
+    for k, g in f["grads"].items():
+        assert rel(sd[k[len("model."):]].grad, g) < 2e-3, k
