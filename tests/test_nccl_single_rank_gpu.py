@@ -1,0 +1,59 @@
+"""RCCL (backend "nccl") API usage on one GPU: a world_size-1 process group exercises the same calls the N > 1 path makes
+-- communicator creation with device_id, the per-block async all-reduce launched from the engine's backward hook on the
+weight-gradient side stream, AllGather forward / backward, the scalar all-reduce and barrier.  (The multi-rank semantics are
+covered by the gloo world_size-2 tests on CPU; an 8-GPU node is only available to the driver.)"""
+import os
+import socket
+
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_nccl_world1_training_step_matches_no_dist_step():
+    import torch.distributed as dist
+    import e2e_checks as ec
+    from procedurevrl_amd import distributed as du
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    from procedurevrl_amd.losses import MILNCELoss
+
+    def run(with_dist):
+        torch.manual_seed(0)
+        cfg = ec.make_cfg(2, 32, 64)
+        model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1)).to("cuda:0").train()
+        vt = model.model
+        with torch.no_grad():
+            for blk in vt.blocks:
+                torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+        reducer = du.GradReducer(vt, enabled=with_dist)
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        x = torch.randn(4, 3, 8, 32, 32, device="cuda:0", generator=g)
+        teacher = torch.randn(4, 64, device="cuda:0", generator=g) * 3
+        text = torch.nn.functional.normalize(torch.randn(4, 512, device="cuda:0", generator=g), dim=1)
+        pred = model(x)
+        loss = kl_topk_loss(pred, teacher, 5)
+        v = vt.last_video_emb
+        v_all, t_all = (du.AllGather.apply(v), du.AllGather.apply(text)) if with_dist else (v, text)
+        loss = loss + MILNCELoss()(v_all * 3.0, t_all * 3.0)
+        loss.backward()
+        reducer.finish()
+        vt.adopt_grads()
+        stats = du.all_reduce_scalars([loss.detach()]) if with_dist else torch.stack([loss.detach()])
+        return float(stats[0]), vt.grad_store().flat.clone()
+
+    l0, g0 = run(False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l1, g1 = run(True)
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    # two executions of the same step are not bit-identical (fp32 atomics in the split-K head / logits GEMMs change the last
+    # bit of d feat, which flips a few bf16 roundings downstream): observed 7e-4 between ANY two runs, with or without RCCL
+    assert float((g1 - g0).norm() / g0.norm()) < 5e-3
