@@ -48,9 +48,13 @@ int pvrl_debug_set_gemm_gm(int gm);   /* rasterisation group height (tile rows p
 int pvrl_debug_set_gemm_tn_tile(int tile);
 
 /* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits
- * `x @ label_emb.t() / temp` vit.py:307,334,340,432). */
+ * `x @ label_emb.t() / temp` vit.py:307,334,340,432).  Long reductions with few output tiles are split over K into fp32
+ * partials (workspace >= pvrl_gemm_nt_f32_small_workspace_bytes, may be 0 / null when that returns 0) summed in a fixed
+ * order: deterministic. */
+int64_t pvrl_gemm_nt_f32_small_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float alpha,
-                           float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+                           float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* Weight gradient dW[N,K] = beta*dW + P[M,N]^T . Q[M,K]; dbias[N] = beta*dbias + colsum(P) (optional).
  * Backward of nn.Linear / the patch-embed conv (loss.backward(), tools/train_net.py:176-181).

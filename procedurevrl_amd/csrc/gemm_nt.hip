@@ -614,13 +614,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmNT p) {
 // rows of B once, coalesced, against up to 64 rows of A held in LDS.
 // ---------------------------------------------------------------------------
 // 64x64 output tile, 32-deep K chunks, 4x4 outputs per thread from k-major LDS tiles (float4 reads); optional split-K
-// over grid.z with fp32 atomics (the logits backward has M = 32, N = 512, K = 9871: 8 output tiles only).
+// over grid.z (the logits backward has M = 32, N = 512, K = 9871: 8 output tiles only) into fp32 partials that a second
+// kernel sums in a fixed order -- no atomics, so two runs of a training step are bit-identical.
 constexpr int SG_T = 64, SG_K = 32, SG_LD = 68;
 __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __restrict__ A, long lda,
                                                              const float* __restrict__ B, long ldb,
                                                              const float* __restrict__ bias, float alpha,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
-                                                             int kchunk) {
+                                                             int kchunk, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float sa[SG_K][SG_LD];
   __shared__ __attribute__((aligned(16))) float sb[SG_K][SG_LD];
   const int tid = threadIdx.x;
@@ -664,11 +665,36 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + tx * 4 + j;
       if (n >= N) continue;
-      float v = alpha * acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
-      if (split) atomicAdd(&C[(long)m * ldc + n], v);
-      else C[(long)m * ldc + n] = v;
+      if (split) part[((long)blockIdx.z * M + m) * N + n] = acc[i][j];      // deterministic: partials + ordered reduce
+      else C[(long)m * ldc + n] = alpha * acc[i][j] + (bias ? bias[n] : 0.f);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void f32_small_reduce_kernel(const float* __restrict__ part, int splits, long MN, int N,
+                                                               const float* __restrict__ bias, float alpha,
+                                                               float* __restrict__ C, long ldc) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
+    float a = 0.f;
+    for (int z = 0; z < splits; ++z) a += part[(long)z * MN + i];
+    const long m = i / N;
+    const int n = (int)(i - m * N);
+    C[m * ldc + n] = alpha * a + (bias ? bias[n] : 0.f);
+  }
+}
+
+static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
+  const int tiles = cdiv(N, SG_T) * cdiv(M, SG_T);
+  int splits = 1;
+  if (tiles < 128 && K >= 512) {           // few output tiles and a long reduction: split K over grid.z
+    splits = 256 / tiles;
+    const int maxs = (int)(K / 128);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  const int kchunk = cdiv(cdiv(K, splits), SG_K) * SG_K;
+  if (kchunk_out) *kchunk_out = kchunk;
+  return cdiv(K, kchunk);
 }
 
 template <int EPI, int WM, int WN>
@@ -771,28 +797,29 @@ extern "C" int pvrl_debug_set_gemm_tile(int tile) {
   return PVRL_OK;
 }
 
+extern "C" int64_t pvrl_gemm_nt_f32_small_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int splits = f32_small_plan(M, N, K, nullptr);
+  return splits > 1 ? (int64_t)splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                                       float alpha, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                      void* stream) {
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0) return PVRL_OK;
   if (!A || !B || !C || K <= 0) return PVRL_EINVAL;
-  const int tiles = cdiv(N, SG_T) * cdiv(M, SG_T);
-  int splits = 1;
-  if (tiles < 128 && K >= 512) {           // few output tiles and a long reduction: split K over grid.z
-    splits = 256 / tiles;
-    const int maxs = (int)(K / 128);
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
-  }
-  int kchunk = cdiv(cdiv(K, splits), SG_K) * SG_K;
-  splits = cdiv(K, kchunk);
-  if (splits > 1) {
-    if (ldc != N) return PVRL_EINVAL;       // split-K accumulates into a zero-filled contiguous C
-    if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return PVRL_EHIP;
-  }
+  int kchunk;
+  const int splits = f32_small_plan(M, N, K, &kchunk);
+  if (splits > 1 && (!workspace || workspace_bytes < pvrl_gemm_nt_f32_small_workspace_bytes(M, N, K))) return PVRL_EINVAL;
   dim3 grid(cdiv(N, SG_T), cdiv(M, SG_T), splits);
   hipLaunchKernelGGL(gemm_f32_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (long)lda, B, (long)ldb,
-                     bias, alpha, C, (long)ldc, (int)M, (int)N, (int)K, kchunk);
+                     bias, alpha, C, (long)ldc, (int)M, (int)N, (int)K, kchunk, (float*)workspace);
   PVRL_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long MN = (long)M * N;
+    hipLaunchKernelGGL(f32_small_reduce_kernel, dim3((unsigned)cdiv(MN, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, splits, MN, (int)N, bias, alpha, C, (long)ldc);
+    PVRL_LAUNCH_CHECK();
+  }
   return PVRL_OK;
 }

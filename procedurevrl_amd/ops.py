@@ -104,8 +104,10 @@ def gemm_nt_f32(A, B, bias=None, alpha=1.0, out=None):
     N = B.shape[0]
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=F32)
+    nbytes = L.call("pvrl_gemm_nt_f32_small_workspace_bytes", M, N, K)
+    ws = workspace(nbytes, A.device, "f32_small") if nbytes else None
     L.call("pvrl_gemm_nt_f32_small", _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(bias), float(alpha), _ptr(out), _ld(out),
-           M, N, K, _stream())
+           M, N, K, _ptr(ws), nbytes, _stream())
     return out
 
 

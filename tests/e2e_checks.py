@@ -319,5 +319,31 @@ def check_decoded_clips_train_step():
             ("decoded-clips d blocks.0.attn.qkv.weight", rel(res[1][2], res[0][2]), 1e-2)]
 
 
-ALL_CHECKS = [check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
+def check_step_is_bit_reproducible():
+    """Two executions of the same training step (same weights, same batch, DropPath draws pinned by the seed) give
+    bit-identical logits and gradients: every reduction on the TimeSformer path has a fixed order (split-K / split-M
+    partials summed by a second kernel; no floating-point atomics)."""
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    cfg = make_cfg(2, 48, 200, drop_path=0.1)
+    model = build(cfg, synthetic_label_emb(200, 512, seed=1)).to(DEV).train()
+    with torch.no_grad():
+        for blk in model.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 3, 8, 48, 48, generator=g).to(DEV)
+    teacher = (torch.randn(5, 200, generator=g) * 3).to(DEV)
+    res = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        model.zero_grad(set_to_none=True)
+        pred = model(x)
+        kl_topk_loss(pred, teacher, 5).backward()
+        gs = model.model.adopt_grads()
+        res.append((pred.detach().clone(), gs.flat.clone()))
+    return [("logits differ between two runs (count)", float((res[0][0] != res[1][0]).sum()), 0.0),
+            ("gradients differ between two runs (count)", float((res[0][1] != res[1][1]).sum()), 0.0)]
+
+
+ALL_CHECKS = [check_step_is_bit_reproducible, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
               check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_full_size]

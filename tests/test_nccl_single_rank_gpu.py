@@ -54,6 +54,6 @@ def test_nccl_world1_training_step_matches_no_dist_step():
     finally:
         dist.destroy_process_group()
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
-    # two executions of the same step are not bit-identical (fp32 atomics in the split-K head / logits GEMMs change the last
-    # bit of d feat, which flips a few bf16 roundings downstream): observed 7e-4 between ANY two runs, with or without RCCL
-    assert float((g1 - g0).norm() / g0.norm()) < 5e-3
+    # the step is bit-reproducible (e2e_checks.check_step_is_bit_reproducible) and a 1-rank all-reduce / all-gather is
+    # the identity: the two gradient buffers must agree exactly
+    assert torch.equal(g1, g0)
