@@ -272,3 +272,49 @@ def test_mvit_image_checkpoint_conversion_matches_reference_loader(tmp_path):
     for k in changed:
         got, ref = tensor_stats(after[k]), g["stats"][k]
         assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(got, ref)), (k, got, ref)
+
+
+def test_spatial_sampling_params_properties():
+    """The host mirror of utils.spatial_sampling: for arbitrary frame sizes the crop window lies inside the rescaled
+    frame, the short side equals the drawn size, test-mode crops are the three uniform positions."""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from procedurevrl_amd.transform import spatial_sampling_params
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(120, 720), st.integers(120, 720), st.integers(0, 2 ** 31 - 1), st.sampled_from([-1, 0, 1, 2]), st.booleans())
+    def prop(h, w, seed, sidx, inv):
+        np.random.seed(seed)
+        mn, mx, crop = (256, 320, 224) if sidx == -1 else (224, 224, 224)
+        nh, nw, yo, xo, flip = spatial_sampling_params(h, w, sidx, mn, mx, crop, True, inv)
+        assert min(nh, nw) >= crop and mn <= min(nh, nw) <= mx
+        assert 0 <= yo <= nh - crop and 0 <= xo <= nw - crop
+        assert flip in (0, 1) and (sidx == -1 or flip == 0)
+        if sidx != -1:
+            if nh > nw:
+                assert yo == {0: 0, 1: int(np.ceil((nh - crop) / 2)), 2: nh - crop}[sidx]
+            else:
+                assert xo == {0: 0, 1: int(np.ceil((nw - crop) / 2)), 2: nw - crop}[sidx]
+    prop()
+
+
+def test_tn_split_plan_properties():
+    """pvrl_gemm_tn_plan_splits (a pure host function of the C ABI, callable without a GPU): one round of <= 256 workgroups for
+    the 256x256 kernel, a multiple of 8 slices for the 128x128 kernel, never more slices than 64-row blocks."""
+    from hypothesis import given, settings, strategies as st
+    from procedurevrl_amd._lib import lib
+    L = lib()
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 200000), st.integers(1, 24), st.integers(1, 24))
+    def prop(M, n, k):
+        N, K = 128 * n, 128 * k
+        s = L.call("pvrl_gemm_tn_plan_splits", M, N, K)
+        assert s >= 1
+        if N % 256 == 0 and K % 256 == 0:
+            tiles = (N // 256) * (K // 256)
+            assert s == 1 or (s * tiles <= 256 and s <= max(1, M // 64))
+        else:
+            assert s % 8 == 0 and (s == 8 or M // s >= 256)
+        assert L.call("pvrl_gemm_tn_workspace_bytes", N, K, s) == s * (N * K + N) * 4 + 256
+    prop()
