@@ -462,6 +462,120 @@ __global__ __launch_bounds__(1024) void gemm_nt_pipe_kernel(GemmNT p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Generalised BK = 32 ring kernel: tile (64 WM) x (64 WN), WM*WN waves, NS LDS stages, LDS-DMA NS-1 stages ahead with
+// counted vmcnt.  Smaller tiles / fewer stages leave room for TWO workgroups per CU (e.g. 256x128, 3 stages = 72 KiB), so
+// one workgroup's barrier / DMA wait is covered by the other's MFMAs.  MEASURED (same-process A/B, 50k-row shapes):
+// 256x128 / 3 stages reaches 87-90 % of the 16-wave 256x256 kernel (qkv 819 vs 943, dfc1 915 vs 1022 TFLOP/s), 256x128 /
+// 2 stages 81 %, 128x128 / 4 stages 71-74 %: the smaller tiles' extra L2 traffic and halved MFMAs per barrier cost more
+// than the second workgroup hides.  Benchmark knobs 7-9.
+// ---------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N == 0, "add the immediate");
+}
+
+template <int EPI, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_nt_ring_kernel(GemmNT p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, BKS = 32;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BKS * 2, WBYTES = BN * BKS * 2, STAGE = XBYTES + WBYTES;
+  constexpr int PER = (BM + BN) / 16 / NW;
+  static_assert((BM + BN) / 16 % NW == 0, "staging must divide over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int GM = p.gm;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16* gsrc[PER];
+  int gdst[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int it = wave * PER + e;
+    const int pc = lane & 3;
+    if (it < BM / 16) {
+      const int row = it * 16 + (lane >> 2);
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[e] = p.A + (long)grow * p.lda + ((pc ^ swz_x64(row)) << 3);
+      gdst[e] = it * 1024;
+    } else {
+      const int row = (it - BM / 16) * 16 + (lane >> 2);
+      gsrc[e] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w64<F32OUT>(row)) << 3);
+      gdst[e] = XBYTES + (it - BM / 16) * 1024;
+    }
+  }
+  auto stage = [&](int kt) {
+    char* b = smem + (kt % NS) * STAGE;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) glds16(gsrc[e] + kt * BKS, b + gdst[e]);
+  };
+
+  int xoff[4], woff[4];
+  {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rx = wm * 64 + t * 16 + i;
+      xoff[t] = rx * 64 + ((q ^ swz_x64(rx)) << 4);
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = XBYTES + rw * 64 + ((q ^ swz_w64<F32OUT>(rw)) << 4);
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BKS;
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) stage(st);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stages issued so far: .. min(kt + NS - 2, nk - 1); those after kt may stay in flight
+    const int ahead = min(kt + NS - 2, nk - 1) - kt;
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * PER>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);
+    const char* b = smem + (kt % NS) * STAGE;
+    bf16x8 xf[4], wf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wf[t] = *reinterpret_cast<const bf16x8*>(b + woff[t]);
+      xf[t] = *reinterpret_cast<const bf16x8*>(b + xoff[t]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+  }
+  nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 256x256 tile with FOUR waves (2 x 2), each owning a 128 x 128 block = 8 x 8 MFMA tiles = 256 accumulator AGPRs (one
 // wave per SIMD, 512-register budget): 16 ds_read_b128 per 64 MFMAs, half the LDS read bytes per FLOP of the 64x64 wave
 // block.  BK = 32 stages (32 KiB) in a 4-deep LDS ring filled by raw-ISA LDS-DMA three stages ahead (counted vmcnt + raw
@@ -740,9 +854,22 @@ int launch_w4(GemmNT p, hipStream_t s) {
   return PVRL_OK;
 }
 
+template <int EPI, int WM, int WN, int NS>
+int launch_ring(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / (64 * WN);
+  p.tiles_m = cdiv(p.M, 64 * WM);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, WM, WN, NS>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   int t = g_force_tile;
+  if (t == 7) return launch_ring<EPI, 4, 2, 2>(p, s);      // 256x128, 2 stages (48 KiB): 2-3 workgroups / CU
+  if (t == 8) return launch_ring<EPI, 4, 2, 3>(p, s);      // 256x128, 3 stages (72 KiB): 2 workgroups / CU
+  if (t == 9) return launch_ring<EPI, 2, 2, 4>(p, s);      // 128x128, 4 stages (64 KiB): 2 workgroups / CU
   if (t == 6 && p.N % 256 == 0) return launch_w4<EPI>(p, s);
   if (t == 4 && p.N % 256 == 0) return launch_pipe<EPI>(p, s);
   if (t == 5 && p.N % 256 == 0) return launch_w128<EPI>(p, s);
