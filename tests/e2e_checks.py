@@ -237,6 +237,20 @@ def check_train_step_t32():
     return _hip_vs_oracle(1, 32, 64, 1, frames=32, seed=9, tag="T=32: ")
 
 
+def check_embed_resize_golden():
+    """Frame count / patch grid different from the model's: nearest-neighbour pos/time-embed resize (vit.py:374-386,
+    398-402) through the HIP path vs the reference's features (tests/golden/embed_interp.pt)."""
+    import test_oracle_golden as tg
+    f = load("embed_interp")
+    cfg = make_cfg(f["depth"], f["crop"], f["K"], text=True, text_layers=f["text_layers"], order=True)
+    model = build(cfg, torch.randn(f["K"], 512))
+    model.load_state_dict(orc.seeded_state(tg.e2e_state(f), f["seed"]), strict=True)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        feat = model.model.forward_features(f["x"].to(DEV))
+    return [("features with resized pos/time embeddings vs reference", rel(feat, f["feat"]), TOL_ACT)]
+
+
 def check_forecast_eval_golden():
     """Eval-mode zero-shot step forecasting (NUM_SEG = 8, order transformer's diffusion_signal_forecast) against the
     reference's output probabilities (tests/golden/forecast.pt)."""
@@ -346,4 +360,4 @@ def check_step_is_bit_reproducible():
 
 
 ALL_CHECKS = [check_step_is_bit_reproducible, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
-              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_full_size]
+              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size]

@@ -247,6 +247,18 @@ def make_e2e(defaults, vit, tfm, out, tmpdir):
     out["features"] = dict(seed=31, x=inputs[0, :2].clone(), feat=feat)
 
 
+def make_embed_interp(defaults, vit, tfm, out, tmpdir):
+    """forward_features on an input whose frame count and patch grid differ from the model's (built for 8 frames, 2x2
+    patches; fed 4 frames, 3x3 patches): the nearest-neighbour resize of pos_embed / time_embed, vit.py:374-386,398-402."""
+    cfg, model, _ = build_ref_model(defaults, vit, tfm, depth=1, crop=32, K=16, text_layers=1, tmpdir=tmpdir)
+    sd = load_seeded(model, 71)
+    model.eval()
+    x = torch.randn(2, 3, 4, 48, 48, generator=torch.Generator().manual_seed(72))
+    with torch.no_grad():
+        feat = model.model.forward_features(x)
+    out["embed_interp"] = dict(seed=71, depth=1, crop=32, K=16, text_layers=1, wsum=checksum(sd), x=x, feat=feat.clone())
+
+
 def make_forecast(defaults, vit, tfm, out, tmpdir):
     """Zero-shot step forecasting in eval mode (vit.py:292-293, 302-307, 355-356 -> tfm_model.py:206-249): NUM_SEG = 8
     observed clips per video, the 9th is denoised by the order transformer; output = softmax probabilities."""
@@ -635,6 +647,14 @@ def main():
         torch.save(out["mvit_pretrained"], os.path.join(HERE, "mvit_pretrained.pt"))
         print("wrote mvit_pretrained", len(out["mvit_pretrained"]["changed"]))
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "embed_interp":
+        defaults, vit, tfm, dist_mod, losses = import_reference()
+        out = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            make_embed_interp(defaults, vit, tfm, out, tmp)
+        torch.save(out["embed_interp"], os.path.join(HERE, "embed_interp.pt"))
+        print("wrote embed_interp")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit_e2e":
         defaults, vit, tfm, dist_mod, losses = import_reference()
         out = {}
@@ -666,6 +686,7 @@ def main():
         make_block(vit, out)
         make_e2e(defaults, vit, tfm, out, tmp)
         make_forecast(defaults, vit, tfm, out, tmp)
+        make_embed_interp(defaults, vit, tfm, out, tmp)
         make_pretrained(defaults, vit, tfm, out, tmp)
         make_mvit_e2e(defaults, tfm, out, tmp)
     make_small_ops(vit, losses, out)

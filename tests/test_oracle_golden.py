@@ -262,3 +262,15 @@ def test_mvit_wrapper_e2e_train_forward_loss_grads():
     loss.backward()
     for k, g in f["grads"].items():
         assert rel(sd[k[len("model."):]].grad, g) < 2e-3, k
+
+
+def test_pos_time_embed_resize():
+    """Input with another frame count / patch grid than the model was built for (tests/golden/embed_interp.pt): the
+    nearest-neighbour resize of pos_embed and time_embed (vit.py:374-386,398-402)."""
+    f = load("embed_interp")
+    full = orc.seeded_state(e2e_state(f), f["seed"])
+    assert abs(checksum(full) - f["wsum"]) < 1e-6 * f["wsum"]
+    sd = {k[len("model."):]: v for k, v in full.items()}
+    with torch.no_grad():
+        feat = orc.forward_features(sd, f["x"], f["depth"])
+    assert rel(feat, f["feat"]) < 1e-5
