@@ -7,7 +7,7 @@ tests/test_oracle_golden.py holds this file to them (forward features, per-block
 
 Scope = the configuration every shipped MViT yaml uses (configs/HowTo100M/procedurevrl_mvitv2_*.yaml):
 MODE conv, CLS_EMBED_ON, no absolute position embedding, REL_POS_SPATIAL + REL_POS_TEMPORAL, RESIDUAL_POOLING,
-DIM_MUL_IN_ATT, POOL_KVQ_KERNEL (3,3,3), adaptive KV stride, DROPPATH 0, DROPOUT 0.
+DIM_MUL_IN_ATT, POOL_KVQ_KERNEL (3,3,3), adaptive KV stride, DROPOUT 0; DropPath (DROPPATH_RATE, per clip) is supported with pinned draws.
 """
 import math
 
@@ -144,27 +144,34 @@ def msa(sd, pre, x, blk, taps=None):
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), q_thw
 
 
-def block(sd, pre, x, blk, taps=None):
-    """MultiScaleBlock.forward (attention.py:545-568) with dim_mul_in_att, drop_path 0, no layer scale."""
+def block(sd, pre, x, blk, taps=None, dp=None):
+    """MultiScaleBlock.forward (attention.py:545-568) with dim_mul_in_att, no layer scale.  dp = (s_attn, s_mlp): the
+    per-clip DropPath factors floor(keep + U) / keep of common.py:38-52 (None = identity)."""
     xn = ln(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
     xb, thw_new = msa(sd, pre + "attn.", xn, blk, taps)
     if blk["dim"] != blk["dim_out"]:
         x = F.linear(xn, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    if dp is not None:
+        xb = xb * dp[0][:, None, None]
     x = pool_skip(x, blk["stride_q"], blk["in_thw"]) + xb
     xn = ln(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
     h = F.gelu(F.linear(xn, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
-    return x + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    y = F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if dp is not None:
+        y = y * dp[1][:, None, None]
+    return x + y
 
 
-def forward_features(sd, x, mv, block_outputs=None):
-    """MViT_encoder.forward (mvit.py:346-407): x fp32 [B, 3, T, H, W] -> [B, C_last] = norm(tokens)[:, 0]."""
+def forward_features(sd, x, mv, block_outputs=None, droppath=None):
+    """MViT_encoder.forward (mvit.py:346-407): x fp32 [B, 3, T, H, W] -> [B, C_last] = norm(tokens)[:, 0].
+    droppath: list over blocks of (s_attn [B], s_mlp [B]) or None per block."""
     _, blocks = plan(mv, x.shape[2], x.shape[3])
     t = F.conv3d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=tuple(mv["PATCH_STRIDE"]),
                  padding=tuple(mv["PATCH_PADDING"]))
     t = t.flatten(2).transpose(1, 2)                                             # stem_helper.py:319-321
     t = torch.cat((sd["cls_token"].expand(t.shape[0], -1, -1), t), dim=1)
     for i, blk in enumerate(blocks):
-        t = block(sd, f"blocks.{i}.", t, blk)
+        t = block(sd, f"blocks.{i}.", t, blk, dp=None if droppath is None else droppath[i])
         if block_outputs is not None:
             block_outputs.append(t)
     t = ln(t, sd["norm.weight"], sd["norm.bias"])

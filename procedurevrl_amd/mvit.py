@@ -9,7 +9,7 @@ The sub-modules own parameters only; the arithmetic is `MViTEngine`'s kernel sch
 
 Built for the configuration every shipped MViT yaml uses (configs/HowTo100M/procedurevrl_mvitv2_*.yaml): MODE conv,
 CLS_EMBED_ON, no absolute position embedding, REL_POS_SPATIAL + REL_POS_TEMPORAL, RESIDUAL_POOLING, DIM_MUL_IN_ATT,
-POOL_KVQ_KERNEL (3,3,3), head_dim 96, DROPPATH_RATE 0, DROPOUT_RATE 0; other settings raise NotImplementedError.
+POOL_KVQ_KERNEL (3,3,3), head_dim 96, DROPOUT_RATE 0 (DROPPATH_RATE: any); other settings raise NotImplementedError.
 """
 from functools import partial
 
@@ -100,7 +100,6 @@ def _check_cfg(cfg):
     if not mv.DIM_MUL_IN_ATT: bad.append("DIM_MUL_IN_ATT off")
     if mv.SEPARATE_QKV: bad.append("SEPARATE_QKV")
     if mv.POOL_KVQ_KERNEL is None or list(mv.POOL_KVQ_KERNEL) != [3, 3, 3]: bad.append("POOL_KVQ_KERNEL != [3,3,3]")
-    if float(mv.DROPPATH_RATE) != 0.0: bad.append("DROPPATH_RATE > 0")
     if float(mv.DROPOUT_RATE) != 0.0: bad.append("DROPOUT_RATE > 0")
     if float(mv.LAYER_SCALE_INIT_VALUE) != 0.0: bad.append("LAYER_SCALE_INIT_VALUE > 0")
     if mv.NORM_STEM or mv.USE_MEAN_POOLING or mv.PATCH_2D or mv.NORM != "layernorm": bad.append("NORM_STEM/USE_MEAN_POOLING/PATCH_2D/NORM")
@@ -188,6 +187,7 @@ class MViT_encoder(nn.Module):
             MultiScaleBlock(b["dim"], b["dim_out"], b["heads"], b["in_thw"], float(mv.MLP_RATIO), b["stride_q"],
                             b["stride_kv"], norm_layer) for b in self.plan])
         self.norm = norm_layer(self.plan[-1]["dim_out"])
+        self.drop_path_rates = [x.item() for x in torch.linspace(0, float(mv.DROPPATH_RATE), int(mv.DEPTH))]   # mvit.py:104-106
         trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
 
@@ -281,7 +281,19 @@ class MViTEngine:
         return g
 
     # -------------------------------------------------------------- forward
-    def forward(self, frames, training, save=True):
+    def draw_droppath(self, B, device, training):
+        """Per block (s_attn, s_mlp), each [B] = floor(keep + U[0,1)) / keep (slowfast_mvit/common.py:38-52: one draw per
+        DropPath call, per sample), or None where the block's rate is 0 / in eval mode."""
+        out = []
+        for rate in self.enc.drop_path_rates:
+            if not training or rate == 0.0:
+                out.append(None)
+            else:
+                keep = 1.0 - rate
+                out.append(tuple(torch.floor(keep + torch.rand(B, device=device)) / keep for _ in range(2)))
+        return out
+
+    def forward(self, frames, training, save=True, droppath=None):
         L = lib()
         enc = self.enc
         mv = enc.cfg.MVIT
@@ -300,8 +312,10 @@ class MViTEngine:
         x[R:].zero_()
         x[R:, :e0] = enc.cls_token.detach()[0, 0]
         sv = dict(B=B, a_pe=a_pe if save else None, blocks=[])
+        if droppath is None:
+            droppath = self.draw_droppath(B, dev, training)
         for i, (blk, pl) in enumerate(zip(enc.blocks, enc.plan)):
-            x = self._block_fwd(i, blk, pl, x, B, sv, save)
+            x = self._block_fwd(i, blk, pl, x, B, sv, save, droppath[i])
         Cl = enc.plan[-1]["dim_out"]
         Rl = x.shape[0] - B
         feat, mean, rstd = om.ln_fwd(x[Rl:], Cl, enc.norm.weight.detach(), enc.norm.bias.detach(), eps, out_dtype=F32)
@@ -310,7 +324,7 @@ class MViTEngine:
             self.saved = sv
         return feat
 
-    def _block_fwd(self, i, blk, pl, x, B, sv, save):
+    def _block_fwd(self, i, blk, pl, x, B, sv, save, dp=None):
         L = lib()
         eps = self.enc.ln_eps
         dim, dout, H = pl["dim"], pl["dim_out"], pl["heads"]
@@ -341,17 +355,22 @@ class MViTEngine:
             xres = om.maxpool_fwd(xs, B, thw, sq[1], dout)
         else:
             xres = xs
+        # DropPath: one factor per clip, expanded to the output rows (patch tokens (b, l) then the cls rows)
+        rs_a = rs_m = None
+        if dp is not None:
+            rs_a = torch.cat((dp[0].float().repeat_interleave(Lq), dp[0].float())).contiguous()
+            rs_m = torch.cat((dp[1].float().repeat_interleave(Lq), dp[1].float())).contiguous()
         wproj = self._wpad(a.proj.weight, a.proj.bias)
-        x1 = ops.gemm_nt(o, wproj.w, L.PVRL_EPI_RESID_F32, bias=wproj.b, aux=xres)
+        x1 = ops.gemm_nt(o, wproj.w, L.PVRL_EPI_RESID_F32, bias=wproj.b, rowscale=rs_a, aux=xres)
         xn2, mean2, rstd2 = om.ln_fwd(x1, dout, P(blk.norm2.weight), P(blk.norm2.bias), eps, Cpad=Cpo)
         w1 = self._wpad(blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         u, g = ops.gemm_nt(xn2, w1.w, L.PVRL_EPI_GELU, bias=w1.b)
         w2 = self._wpad(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        x2 = ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, aux=x1)
+        x2 = ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, rowscale=rs_m, aux=x1)
         if save:
             sv["blocks"].append(dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, q=q, k=k, v=v, cq=cq, ck=ck, cv=cv,
                                      rel=rel, o=o, lse=lse, xs=xs if pooled else None, x1=x1, xn2=xn2, mean2=mean2,
-                                     rstd2=rstd2, u=u, g=g, q_thw=q_thw, k_thw=k_thw, pooled=pooled))
+                                     rstd2=rstd2, u=u, g=g, q_thw=q_thw, k_thw=k_thw, pooled=pooled, rs_a=rs_a, rs_m=rs_m))
         return x2
 
     # -------------------------------------------------------------- backward
@@ -396,7 +415,7 @@ class MViTEngine:
         # ---- MLP
         w1 = self._wpad(blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         w2 = self._wpad(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        dyb = ops.cast_scale(dx2)
+        dyb = ops.cast_scale(dx2, rowscale=s["rs_m"])
         self._wgrad(dyb, s["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias, w2)
         du = ops.gemm_nt(dyb, w2.t, L.PVRL_EPI_DGELU, aux=s["u"])
         self._wgrad(du, s["xn2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias, w1)
@@ -405,7 +424,7 @@ class MViTEngine:
                         self._acc_target(blk.norm2.bias), dres=dx2, Cpad=Cpo)
         # ---- attention output projection
         wproj = self._wpad(a.proj.weight, a.proj.bias)
-        dx1b = ops.cast_scale(dx1)
+        dx1b = ops.cast_scale(dx1, rowscale=s["rs_a"])
         self._wgrad(dx1b, s["o"], a.proj.weight, a.proj.bias, wproj)
         d_o = ops.gemm_nt(dx1b, wproj.t, L.PVRL_EPI_BF16)
         # ---- pooling attention, rel-pos terms, pooling convs
@@ -444,16 +463,16 @@ class MViTFn(torch.autograd.Function):
     """frames -> norm(tokens)[:, 0] through the MViT encoder (MViTEngine)."""
 
     @staticmethod
-    def forward(ctx, anchor, frames, owner):
+    def forward(ctx, anchor, frames, owner, droppath=None):
         need = bool(ctx.needs_input_grad[0])
-        feat = owner.engine.forward(frames, training=owner.training, save=need)
+        feat = owner.engine.forward(frames, training=owner.training, save=need, droppath=droppath)
         ctx.owner = owner
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         ctx.owner.engine.backward(dfeat)
-        return None, None, None
+        return None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ wrapper (lib/models/mvit.py)
@@ -505,7 +524,7 @@ class VisionTransformer(_StepMatchingModel):
                                       "give the MViT stem the fp32 clip tensor")
         if self.training and torch.is_grad_enabled():
             self.grad_store()
-        return MViTFn.apply(self.video_encoder.cls_token, x.float(), self)
+        return MViTFn.apply(self.video_encoder.cls_token, x.float(), self, droppath)
 
 
 @MODEL_REGISTRY.register()

@@ -83,6 +83,7 @@ class CaptureRNG:
 
     def __enter__(self):
         self._o = (torch.randint, torch.randn_like, torch.randperm)
+        self._rand = torch.rand
         def wrap(name, fn):
             def w(*a, **k):
                 r = fn(*a, **k)
@@ -92,10 +93,12 @@ class CaptureRNG:
         torch.randint = wrap("randint", self._o[0])
         torch.randn_like = wrap("randn_like", self._o[1])
         torch.randperm = wrap("randperm", self._o[2])
+        torch.rand = wrap("rand", self._rand)
         return self
 
     def __exit__(self, *exc):
         torch.randint, torch.randn_like, torch.randperm = self._o
+        torch.rand = self._rand
 
 
 def checksum(sd):
@@ -451,6 +454,33 @@ def make_mvit_pretrained(defaults, out, tmpdir):
                                   changed=changed, stats={k: tensor_stats(after[k]) for k in changed})
 
 
+def make_mvit_droppath(defaults, out):
+    """The reference MViT_encoder in train mode with DROPPATH_RATE 0.2 on the reduced geometry: every torch.rand draw of
+    common.py:drop_path captured (two per block with a non-zero rate: attention branch, MLP branch), features and a few
+    parameter gradients."""
+    mvit = importlib.import_module("lib.models.slowfast_mvit.mvit")
+    sm = MVIT_SMALL
+    cfg = mvit_cfg(defaults, sm["frames"], sm["crop"], sm)
+    cfg.MVIT.DROPPATH_RATE = 0.2
+    torch.manual_seed(0)
+    net = mvit.MViT_encoder(cfg)
+    sd = load_seeded(net, 45)
+    g = torch.Generator().manual_seed(46)
+    x = torch.randn(6, 3, sm["frames"], sm["crop"], sm["crop"], generator=g)
+    net.train()
+    torch.manual_seed(7)
+    with CaptureRNG() as cap:
+        feat = net(x)
+    draws = [d[1].reshape(-1).clone() for d in cap.log if d[0] == "rand"]
+    gout = torch.randn(feat.shape, generator=g)
+    (feat * gout).sum().backward()
+    params = dict(net.named_parameters())
+    names = ["cls_token", "blocks.1.attn.qkv.weight", "blocks.2.mlp.fc2.bias", "blocks.3.attn.proj.weight", "blocks.3.norm2.weight"]
+    out["mvit_droppath"] = dict(cfg=sm, rate=0.2, mvit={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in dict(cfg.MVIT).items()},
+                                seed=45, checksum=checksum(sd), x=x, gout=gout, feat=feat.detach().clone(), rand=draws,
+                                grads={n: (params[n].grad[:64] if params[n].grad.dim() == 2 else params[n].grad).clone() for n in names})
+
+
 def make_mvit_e2e(defaults, tfm, out, tmpdir):
     """The reference's registered `MViT` model (lib/models/mvit.py) in train mode on one video of 9 clips at the reduced
     geometry: (pred, teacher, mse), KL + MSE losses and parameter gradients, all RNG draws captured -- the MViT twin of
@@ -647,6 +677,14 @@ def main():
         torch.save(out["mvit_pretrained"], os.path.join(HERE, "mvit_pretrained.pt"))
         print("wrote mvit_pretrained", len(out["mvit_pretrained"]["changed"]))
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "mvit_droppath":
+        _install_stubs()
+        defaults = importlib.import_module("lib.config.defaults")
+        out = {}
+        make_mvit_droppath(defaults, out)
+        torch.save(out["mvit_droppath"], os.path.join(HERE, "mvit_droppath.pt"))
+        print("wrote mvit_droppath", len(out["mvit_droppath"]["rand"]), "draws")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "embed_interp":
         defaults, vit, tfm, dist_mod, losses = import_reference()
         out = {}
@@ -694,6 +732,7 @@ def main():
     make_allgather(dist_mod, out)
     make_input_pipeline(out)
     make_mvit(defaults, out)
+    make_mvit_droppath(defaults, out)
     with tempfile.TemporaryDirectory() as tmp:       # the reference's MViT conversion writes ./exps/...converted.pyth
         cwd = os.getcwd(); os.chdir(tmp)
         try:

@@ -320,6 +320,27 @@ def check_mvit_e2e_golden():
     return out
 
 
+def check_mvit_droppath_golden():
+    """DROPPATH_RATE 0.2 in train mode with the reference's draws pinned (tests/golden/mvit_droppath.pt): features and
+    gradients of the HIP encoder vs the reference."""
+    import test_oracle_golden as tg
+    g = _load("mvit_droppath")
+    c = g["cfg"]
+    model, sd = _build_mvit(g, c["frames"], c["crop"])
+    vt = model.model
+    model.train()
+    dp = [None if d is None else (d[0].to(DEV), d[1].to(DEV)) for d in tg.mvit_droppath_scales(g)]
+    feat = vt.forward_features(g["x"].to(DEV), droppath=dp)
+    out = [("mvit droppath features vs reference", rel(feat, g["feat"]), 1e-2)]
+    (feat * g["gout"].to(DEV)).sum().backward()
+    params = dict(vt.video_encoder.named_parameters())
+    for n, ref in g["grads"].items():
+        got = params[n].grad
+        got = got[:64] if got.dim() == 2 else got
+        out.append((f"mvit droppath d {n}", rel(got, ref), 3e-2))
+    return out
+
+
 def check_mvit_s_features():
     """MViTv2-S geometry (16 x 224^2, 16 blocks, 34 M parameters): one clip's features vs the reference's."""
     g = _load("mvit_s")
@@ -373,4 +394,4 @@ def check_mvit_pretrain_steps():
             ("mvit pretraining: loss after 5 steps / first loss", losses[-1] / losses[0], 0.999)]
 
 
-ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
+ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]

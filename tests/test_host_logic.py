@@ -198,7 +198,7 @@ def test_mvit_unsupported_settings_raise():
     with pytest.raises(NotImplementedError):
         mvit.MViT(cfg)
     cfg, _ = _mvit_cfg_from_golden("mvit_small", 4, 64)
-    cfg.MVIT.DROPPATH_RATE = 0.2
+    cfg.MVIT.RESIDUAL_POOLING = False
     with pytest.raises(NotImplementedError):
         mvit.MViT(cfg)
 

@@ -274,3 +274,34 @@ def test_pos_time_embed_resize():
     with torch.no_grad():
         feat = orc.forward_features(sd, f["x"], f["depth"])
     assert rel(feat, f["feat"]) < 1e-5
+
+
+def mvit_droppath_scales(g):
+    """the reference's captured torch.rand draws -> per-block (s_attn, s_mlp) = floor(keep + u) / keep (common.py:38-52)"""
+    depth = g["cfg"]["depth"]
+    rates = [x.item() for x in torch.linspace(0, g["rate"], depth)]
+    draws = list(g["rand"])
+    dp = []
+    for r in rates:
+        if r == 0.0:
+            dp.append(None)
+        else:
+            keep = 1.0 - r
+            dp.append((torch.floor(keep + draws.pop(0)) / keep, torch.floor(keep + draws.pop(0)) / keep))
+    assert not draws
+    return dp
+
+
+def test_mvit_oracle_droppath():
+    """Reference MViT_encoder in train mode with DROPPATH_RATE 0.2 (tests/golden/mvit_droppath.pt, rand draws captured)."""
+    from oracle import mvit_oracle as mo
+    g = load("mvit_droppath")
+    c = g["cfg"]
+    sd = _mvit_state(g, c["frames"], c["crop"])
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    feat = mo.forward_features(p, g["x"], g["mvit"], droppath=mvit_droppath_scales(g))
+    assert torch.allclose(feat, g["feat"], atol=2e-5, rtol=2e-5)
+    (feat * g["gout"]).sum().backward()
+    for n, ref in g["grads"].items():
+        got = p[n].grad[:64] if p[n].grad.dim() == 2 else p[n].grad
+        assert (got - ref).norm() < 2e-4 * ref.norm() + 1e-6 * ref.numel() ** 0.5, n
