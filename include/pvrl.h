@@ -113,6 +113,9 @@ int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t HI, int64_t
 int pvrl_frames_u8_patchify(const void* frames, const int32_t* params, int64_t B, int64_t T, int64_t H0, int64_t W0,
                             int64_t crop, const float* mean3, const float* std3, void* out, int64_t ldo,
                             void* stream);
+/* The same input pipeline producing the fp32 clip tensor [B,3,T,crop,crop] of the reference's loader (MViT stem input). */
+int pvrl_frames_u8_to_f32(const void* frames, const int32_t* params, int64_t B, int64_t T, int64_t H0, int64_t W0,
+                          int64_t crop, const float* mean3, const float* std3, float* out, void* stream);
 /* E[n*T+t] = bias + pos_embed[1+n] + time_embed[t]  (vit.py:370-407), and its batch-summed gradient. */
 int pvrl_embed_table(const float* pos, const float* time, const float* bias, float* E, int64_t N, int64_t T, int64_t C,
                      void* stream);

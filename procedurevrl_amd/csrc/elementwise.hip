@@ -89,6 +89,47 @@ __global__ __launch_bounds__(256) void frames_u8_patchify_kernel(const unsigned 
   }
 }
 
+// Same input pipeline, producing the fp32 clip tensor [B][3][T][crop][crop] the reference's loader would have shipped
+// (for consumers that do their own im2col, e.g. the MViT stem).  One thread = 4 consecutive output pixels of one channel row.
+__global__ __launch_bounds__(256) void frames_u8_to_f32_kernel(const unsigned char* __restrict__ frames,
+                                                               const int* __restrict__ prm, float* __restrict__ out, int B,
+                                                               int T, int H0, int W0, int crop, float m0, float m1,
+                                                               float m2, float s0, float s1, float s2) {
+  const int xg = crop >> 2;
+  const long total = (long)B * 3 * T * crop * xg;
+  const float mean[3] = {m0, m1, m2}, istd[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    long r = idx;
+    const int x4 = (int)(r % xg); r /= xg;
+    const int y = (int)(r % crop); r /= crop;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % 3);
+    const int b = (int)(r / 3);
+    const int* q = prm + b * 5;
+    const int nh = q[0], nw = q[1], yo = q[2], xo = q[3], flip = q[4];
+    const float sy = (float)H0 / (float)nh, sx = (float)W0 / (float)nw;
+    float fy = sy * ((float)(y + yo) + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H0 - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const unsigned char* f0 = frames + (((long)b * T + t) * H0 + y0) * W0 * 3 + c;
+    const unsigned char* f1 = frames + (((long)b * T + t) * H0 + y1) * W0 * 3 + c;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = x4 * 4 + e;
+      const int X = (flip ? crop - 1 - x : x) + xo;
+      float fx = sx * ((float)X + 0.5f) - 0.5f;
+      fx = fx < 0.f ? 0.f : fx;
+      const int x0 = (int)fx, x1 = x0 + (x0 < W0 - 1 ? 1 : 0);
+      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+      const float v = ly0 * (lx0 * (float)f0[x0 * 3] + lx1 * (float)f0[x1 * 3]) + ly1 * (lx0 * (float)f1[x0 * 3] + lx1 * (float)f1[x1 * 3]);
+      o[e] = (v / 255.0f - mean[c]) * istd[c];
+    }
+    *reinterpret_cast<f32x4*>(out + idx * 4) = o;
+  }
+}
+
 // E[n*T + t][c] = bias[c] + pos[1 + n][c] + time[t][c]
 __global__ __launch_bounds__(256) void embed_table_kernel(const float* __restrict__ pos, const float* __restrict__ time,
                                                           const float* __restrict__ bias, float* __restrict__ E, int N,
@@ -245,6 +286,19 @@ extern "C" int pvrl_frames_u8_patchify(const void* frames, const int32_t* params
   hipLaunchKernelGGL(frames_u8_patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned char*)frames, (const int*)params, (bf16*)out, (int)B, (int)T, (int)H0, (int)W0,
                      (int)crop, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (long)ldo);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_frames_u8_to_f32(const void* frames, const int32_t* params, int64_t B, int64_t T, int64_t H0, int64_t W0,
+                                     int64_t crop, const float* mean3, const float* std3, float* out, void* stream) {
+  if (B <= 0) return PVRL_OK;
+  if (!frames || !params || !mean3 || !std3 || !out || crop <= 0 || (crop % 4) || H0 <= 0 || W0 <= 0) return PVRL_EINVAL;
+  if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return PVRL_EINVAL;
+  const long total = B * 3 * T * crop * (crop >> 2);
+  hipLaunchKernelGGL(frames_u8_to_f32_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)frames, (const int*)params, out, (int)B, (int)T, (int)H0, (int)W0, (int)crop,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

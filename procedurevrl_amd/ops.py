@@ -274,6 +274,24 @@ def frames_u8_patchify(clips, out=None):
     return out
 
 
+def frames_u8_to_f32(clips):
+    """transform.DecodedClips -> fp32 [B, 3, T, crop, crop]: the tensor the reference's CPU workers would have produced"""
+    import ctypes
+    L = lib()
+    fr = clips.frames
+    B, T, H0, W0, _ = fr.shape
+    crop = clips.crop
+    ph = clips.params_host
+    if bool(((ph[:, 0] - ph[:, 2]) < crop).any()) or bool(((ph[:, 1] - ph[:, 3]) < crop).any()) or bool((ph[:, 2:4] < 0).any()):
+        raise ValueError("crop window leaves the rescaled frame")
+    out = torch.empty((B, 3, T, crop, crop), device=fr.device, dtype=F32)
+    mean = (ctypes.c_float * 3)(*clips.mean)
+    std = (ctypes.c_float * 3)(*clips.std)
+    L.call("pvrl_frames_u8_to_f32", _ptr(fr), _ptr(clips.params), B, T, H0, W0, crop, ctypes.cast(mean, ctypes.c_void_p),
+           ctypes.cast(std, ctypes.c_void_p), _ptr(out), _stream())
+    return out
+
+
 def embed_table(pos, time, bias, N, T):
     L = lib()
     C = pos.shape[-1]

@@ -481,6 +481,8 @@ def check_input_pipeline():
     ref = torch.stack([orc.input_pipeline(fr[b], prms[b], [0.45, 0.40, 0.5], [0.225, 0.25, 0.2], crop) for b in range(B)])
     got = ops.frames_u8_patchify(DecodedClips(fr.to(dev()), prms, [0.45, 0.40, 0.5], [0.225, 0.25, 0.2], crop))
     cmp("u8 pipeline vs oracle, batch of 5", got, orc.patch_rows(ref))
+    f32 = ops.frames_u8_to_f32(DecodedClips(fr.to(dev()), prms, [0.45, 0.40, 0.5], [0.225, 0.25, 0.2], crop))
+    out.append(("u8 pipeline -> fp32 clip tensor vs oracle", rel(f32, ref), 1e-6))
     return out
 
 
