@@ -394,4 +394,36 @@ def check_mvit_pretrain_steps():
             ("mvit pretraining: loss after 5 steps / first loss", losses[-1] / losses[0], 0.999)]
 
 
-ALL_CHECKS = [check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
+def check_mvit_s_full_size_step_vs_oracle():
+    """MViTv2-S at BASELINE config-5 size (16 x 224^2, 16 blocks): one clip's features AND parameter gradients of the HIP
+    path against the CPU oracle (pinned to the reference by the golden tests) -- the 25,089-query / 1,569-key attention
+    shapes, every stage transition and the 34 M-parameter backward at real size."""
+    from oracle import timesformer_oracle as orc
+    g = _load("mvit_s")
+    model, sd = _build_mvit(g, 16, 224)
+    vt = model.model
+    model.train()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 3, 16, 224, 224, generator=gen)
+    gout = torch.randn(1, 768, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = mo.forward_features(p, x, g["mvit"])
+    (ref * gout).sum().backward()
+    feat = vt.forward_features(x.to(DEV))
+    out = [("mvit-S full-size features vs oracle", rel(feat, ref), 1.5e-2)]
+    (feat * gout.to(DEV)).sum().backward()
+    params = dict(vt.video_encoder.named_parameters())
+    for n in ("patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.pool_q.weight", "blocks.1.proj.weight",
+              "blocks.1.attn.rel_pos_t", "blocks.3.attn.pool_k.weight", "blocks.7.mlp.fc1.weight", "blocks.14.attn.qkv.bias",
+              "blocks.15.mlp.fc2.weight", "norm.weight", "cls_token"):
+        r = p[n].grad
+        err = float((params[n].grad.detach().float().cpu() - r).norm())
+        # the stem's gradient has passed through all 16 blocks of bf16 activations / gradients: observed 5.9e-2 relative
+        # (2.1e-2 after 4 blocks in the reduced geometry); every later parameter is below 3e-2
+        tol = 8e-2 if n.startswith("patch_embed") else 5e-2
+        out.append((f"mvit-S full-size d {n} (abs err / allowed)", err / (tol * float(r.norm()) + 1e-5 * r.numel() ** 0.5), 1.0))
+    return out
+
+
+ALL_CHECKS = [check_mvit_s_full_size_step_vs_oracle, check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
