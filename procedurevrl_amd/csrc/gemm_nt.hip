@@ -720,6 +720,196 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmNT p) {
     for (int b = 0; b < 2; ++b) nt_epilogue<EPI>(p, acc[a][b], m0, n0, 2 * wm + a, 2 * wn + b, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The 4-wave 128x128-per-wave kernel with v_mfma_f32_32x32x16_bf16: 32-cycle MFMAs leave a one-wave-per-SIMD kernel
+// twice the issue slots per MFMA for its LDS reads / DMA issue (the 16x16x32 form above loses 25-30 % to the 16-wave
+// kernel; for the TN kernel the same switch was worth 13-23 %).  Wave block = 4 x 4 blocks of 32 x 32; the W row feeding
+// MFMA row rho of a block is n = 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3), so that lane (m = lane % 32, kg = lane / 32) ends up
+// with the 16 consecutive output columns 16 kg .. 16 kg + 15 of the block: 32-byte (bf16) / 64-byte (fp32) pieces per lane,
+// two lanes = one 128-byte line of fp32.  Natural-order LDS swizzle for both operands.  MEASURED: no better than the
+// 16x16x32 form (qkv 689, dfc1 782 TFLOP/s vs 963 / 1036 for the 16-wave kernel): for NT the one-wave-per-SIMD structure
+// itself loses (three 1024-cycle stages of DMA look-ahead, every stall exposed), not the MFMA shape.  Benchmark knob 10.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epi_row16(const GemmNT& p, const f32x16& a, int m, int n) {
+  // 16 consecutive output columns n .. n+15 of output row m (m < M)
+  const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = a[e] + (p.bias ? p.bias[n + e] : 0.f);
+  if constexpr (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32) {
+    float* o = (float*)p.out0 + (long)m * p.ld0 + n;
+    const float* r = nullptr;
+    if constexpr (EPI == PVRL_EPI_RESID_F32) {
+      const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
+      r = (const float*)p.aux + (long)mr * p.aux_ld + n;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 ov = (f32x4){rs * v[4 * c], rs * v[4 * c + 1], rs * v[4 * c + 2], rs * v[4 * c + 3]};
+      if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 4 * c);
+      *reinterpret_cast<f32x4*>(o + 4 * c) = ov;
+    }
+  } else if constexpr (EPI == PVRL_EPI_BF16) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 o0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o0[e] = (bf16)(rs * v[8 * c + e]);
+      *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + n + 8 * c) = o0;
+    }
+  } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 u0, g0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        u0[e] = (bf16)v[8 * c + e];
+        g0[e] = (bf16)(EPI == PVRL_EPI_GELU ? gelu_erf(v[8 * c + e]) : quick_gelu(v[8 * c + e]));
+      }
+      *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + n + 8 * c) = u0;
+      *reinterpret_cast<bf16x8*>((bf16*)p.out1 + (long)m * p.ld1 + n + 8 * c) = g0;
+    }
+  } else {   // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8 ua = *reinterpret_cast<const bf16x8*>((const bf16*)p.aux + (long)m * p.aux_ld + n + 8 * c);
+      bf16x8 o0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
+        o0[e] = (bf16)(rs * v[8 * c + e] * d);
+      }
+      *reinterpret_cast<bf16x8*>((bf16*)p.out0 + (long)m * p.ld0 + n + 8 * c) = o0;
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4x32_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, BKS = 32, NS = 4;
+  constexpr int XBYTES = BM * BKS * 2, STAGE = 2 * XBYTES;   // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int GM = p.gm;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: waves 0,1 bring X rows 128 w .., waves 2,3 W rows; 8 LDS-DMA instructions (16 rows x 64 B) per wave and stage
+  const char* gsrc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = (wave & 1) * 128 + e * 16 + (lane >> 2);
+    const int pc = lane & 3;
+    if (wave < 2) {
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[e] = reinterpret_cast<const char*>(p.A + (long)grow * p.lda + ((pc ^ swz_x64(row)) << 3));
+    } else {
+      gsrc[e] = reinterpret_cast<const char*>(p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_x64(row)) << 3));
+    }
+  }
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const unsigned dbase = (wave < 2 ? 0 : XBYTES) + (wave & 1) * 128 * 64;
+  auto stage = [&](int kt, int nk) {
+    const int kc = kt < nk ? kt : nk - 1;
+    const unsigned b = smem_base + (kt & (NS - 1)) * STAGE + dbase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) glds16_raw_v(gsrc[e] + kc * (BKS * 2), b + e * 1024);
+  };
+
+  // fragment addresses of block b, K = 16 sub-step u: row r, 16-byte chunk 2u + kg
+  const int i32 = lane & 31, kg = lane >> 5;
+  int xoff[4], woff[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int rx = wm * 128 + b * 32 + i32;
+    xoff[b] = rx * 64 + ((kg ^ swz_x64(rx)) << 4);
+    const int rw = wn * 128 + b * 32 + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
+    woff[b] = XBYTES + rw * 64 + ((kg ^ swz_x64(rw)) << 4);
+  }
+  // chunk 2u + kg: (2u + kg) ^ s = (kg ^ s) ^ 2u  -> sub-step 1 is the address ^ 32
+  auto rd = [&](const char* b, int off, int u) { return *reinterpret_cast<const bf16x8*>(b + (off ^ (u << 5))); };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  bf16x8 xa[4], wa[4], xb[4], wb[4];
+  auto mma = [&](const bf16x8* xf, const bf16x8* wf) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+  };
+  auto step = [&](const char* nb) {            // one K = 32 stage; fragments of the next stage replace the set just used
+    mma(xa, wa);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { xa[t] = rd(nb, xoff[t], 0); wa[t] = rd(nb, woff[t], 0); }
+    mma(xb, wb);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { xb[t] = rd(nb, xoff[t], 1); wb[t] = rd(nb, woff[t], 1); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+  };
+
+  const int nk = p.K / BKS;     // even (K % 64 == 0)
+  stage(0, nk); stage(1, nk); stage(2, nk);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xa[t] = rd(smem, xoff[t], 0); wa[t] = rd(smem, woff[t], 0);
+    xb[t] = rd(smem, xoff[t], 1); wb[t] = rd(smem, woff[t], 1);
+  }
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int hb = ((kt >> 1) & 1) * 2;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 3, nk);
+    step(smem + (hb + 1) * STAGE);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 4, nk);
+    step(smem + (hb ^ 2) * STAGE);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // D layout: lane (col m = lane % 32, kg): register e <-> MFMA row rho = (e/4)*8 + kg*4 + e%4 <-> column 16 kg + e
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wm * 128 + mb * 32 + i32;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) epi_row16<EPI>(p, acc[mb][nb], m, n0 + wn * 128 + nb * 32 + 16 * kg);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Small fp32 GEMM for the projection head / step-logit path, where M is a few
 // dozen rows and the reference keeps fp32 (lib/models/vit.py:299-307):
@@ -865,8 +1055,19 @@ int launch_ring(GemmNT p, hipStream_t s) {
 }
 
 template <int EPI>
+int launch_w4x32(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / 256;
+  p.tiles_m = cdiv(p.M, 256);
+  p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_w4x32_kernel<EPI>), dim3(p.nwg), dim3(256), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   int t = g_force_tile;
+  if (t == 10 && p.N % 256 == 0) return launch_w4x32<EPI>(p, s);
   if (t == 7) return launch_ring<EPI, 4, 2, 2>(p, s);      // 256x128, 2 stages (48 KiB): 2-3 workgroups / CU
   if (t == 8) return launch_ring<EPI, 4, 2, 3>(p, s);      // 256x128, 3 stages (72 KiB): 2 workgroups / CU
   if (t == 9) return launch_ring<EPI, 2, 2, 4>(p, s);      // 128x128, 4 stages (64 KiB): 2 workgroups / CU

@@ -810,6 +810,202 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt_kernel(GemmTN p) {
   }
 }
 
+__global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
+  constexpr int TS = 32;
+  constexpr int OPB = 4 * 256 * 16;                        // 16 KiB per operand and stage
+  constexpr int STAGE = 2 * OPB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  int s, rem;
+  {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int pair = xcd * p.Ms_pairs + jj;                // (slice, tile) pairs in slice-major order, one chunk per XCD
+    if (jj >= p.Ms_pairs || pair >= p.npairs) return;
+    s = pair / p.tiles_nk;
+    rem = pair - s * p.tiles_nk;
+  }
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int rows = mend - mbeg;
+  const int nsteps = (((rows + TS - 1) / TS) + 1) & ~1;    // stages, rounded up to even (the surplus one is all zeros)
+  if (rows <= 0) {                                         // empty slice: its partial tile must still be zero
+    float* part = p.part + (long)s * p.N * p.K;
+    const int q = lane >> 4, i = lane & 15;
+    for (int nt = 0; nt < 8; ++nt)
+      for (int kt = 0; kt < 8; ++kt)
+        *reinterpret_cast<f32x4*>(part + (long)(n0 + wn * 128 + nt * 16 + i) * p.K + k0 + wk * 128 + kt * 16 + 4 * q) =
+            (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.cpart && tk == 0 && wk == 0 && q == 0)
+      for (int t = 0; t < 8; ++t) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = 0.f;
+    return;
+  }
+
+  // staging role: waves 0,1 bring P rows [16 w, 16 w + 16) of the stage, waves 2,3 the same rows of Q
+  const bool isq = wave >= 2;
+  const long ld2 = (isq ? p.ldq : p.ldp) * 2;              // row pitch in bytes
+  const int rg = lane >> 5, cg = lane & 31;
+  const int g = 2 * (wave & 1) + rg;                       // 8-row block of the stage
+  const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + (long)mbeg * ld2;
+  const unsigned loff = (unsigned)(8 * g * ld2 + cg * 16);
+  const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
+  auto gload = [&](u32x4* r, int st) {
+    if ((st + 1) * TS <= rows) {                           // whole stage (uniform branch; every stage but the last)
+      const char* b = ubase + (long)st * TS * ld2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const u32x4*>(b + e * ld2 + loff);
+    } else {                                               // ragged or surplus stage: clamp the row, zero what is outside
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = st * TS + 8 * g + e;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (long)min(row, rows - 1) * ld2 + cg * 16);
+        const unsigned keep = row < rows ? 0xffffffffu : 0u;   // mask, not a branch: keeps the loads unconditional
+        r[e] = v & (u32x4){keep, keep, keep, keep};
+      }
+    }
+  };
+  auto twrite = [&](const u32x4* r, int j, char* slot) {   // column j of the lane's 8: gather its 8 m, store 16 B
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      o[d] = __builtin_amdgcn_perm(r[2 * d + 1][j >> 1], r[2 * d][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+    *reinterpret_cast<u32x4*>(slot + (wr ^ (j << 4))) = o;
+  };
+
+  // v_mfma_f32_32x32x16_bf16: 32-cycle MFMAs leave twice the issue slots per MFMA for the fragment reads, perms, LDS
+  // writes and global loads that one wave per SIMD has to interleave.  MEASURED (same-process A/B): 204 vs 250 us (wqkv,
+  // 873 TFLOP/s), 263 vs 299 (wfc1, 902), 80 vs 94 (wproj) against the 16x16x32 form of the same kernel -> default.  Wave block 128 x 128 = 4 x 4 blocks of 32 x 32.
+  // A / B fragment of a block for K = 16 sub-step u: lane (i = lane % 32, kg = lane / 32) holds the 8 m of m-block 2u + kg
+  // for column 32 b + i  -> one ds_read_b128 from the same [m/8][col] LDS image (conflict-free: see the layout note above).
+  const int i32 = lane & 31, kg = lane >> 5;
+  int prd[4], qrd[4];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    const int slot = (i32 & 8) | ((i32 & 7) ^ ((4 * bb + (i32 >> 3)) & 7));
+    const int win = bb * 2 + (i32 >> 4);
+    prd[bb] = (wn * 8 + win) * 256 + kg * 4096 + (slot << 4);
+    qrd[bb] = OPB + (wk * 8 + win) * 256 + kg * 4096 + (slot << 4);
+  }
+  auto rfrag = [&](const char* slot, int off, int u) { return *reinterpret_cast<const bf16x8*>(slot + off + u * 8192); };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a2 = 0; a2 < 4; ++a2)
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a2][b2][e] = 0.f;
+  float cacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+  bf16x2 ones2;
+  ones2[0] = (bf16)1.0f; ones2[1] = (bf16)1.0f;
+
+  // fragments of the two K = 16 sub-steps of a stage: set A (sub-step 0) and set B (sub-step 1); while sub-step 0 of stage
+  // s computes, sub-step 1's fragments are already in registers and the reads of stage s+1 refill the set that just finished
+  bf16x8 pa[4], qa[4], pb[4], qb[4];
+  u32x4 ra[8], rb[8];
+  auto mma = [&](const bf16x8* pf, const bf16x8* qf) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], pf[nb], acc[nb][kb], 0, 0, 0);
+  };
+  auto colsum = [&](const bf16x8* pf) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        cacc[nb] = __builtin_amdgcn_fdot2_f32_bf16((bf16x2){pf[nb][2 * d], pf[nb][2 * d + 1]}, ones2, cacc[nb], false);
+  };
+  // one stage: 32 MFMAs | 16 fragment reads of the NEXT stage from `rs` | transpose registers r -> slot `ws`
+  auto step = [&](const char* rs, const u32x4* r, char* ws) {
+    if (do_csum) { colsum(pa); colsum(pb); }
+    mma(pa, qa);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { pa[t] = rfrag(rs, prd[t], 0); qa[t] = rfrag(rs, qrd[t], 0); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) twrite(r, j, ws);
+    mma(pb, qb);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { pb[t] = rfrag(rs, prd[t], 1); qb[t] = rfrag(rs, qrd[t], 1); }
+#pragma unroll
+    for (int j = 4; j < 8; ++j) twrite(r, j, ws);
+    // 16 MFMAs each half; per MFMA: <= 1 LDS read / 1 perm-group; the LDS writes go with the later MFMAs of a half
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  char* slot0 = smem;
+  char* slot1 = smem + STAGE;
+  gload(ra, 0);
+  gload(rb, 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) twrite(ra, j, slot0);
+  gload(ra, 2);
+  lds_barrier();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    pa[t] = rfrag(slot0, prd[t], 0); qa[t] = rfrag(slot0, qrd[t], 0);
+    pb[t] = rfrag(slot0, prd[t], 1); qb[t] = rfrag(slot0, qrd[t], 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) twrite(rb, j, slot1);
+  gload(rb, 3);
+  for (int st = 0; st < nsteps; st += 2) {
+    lds_barrier();
+    step(slot1, ra, slot0);
+    gload(ra, st + 4);
+    lds_barrier();
+    step(slot0, rb, slot1);
+    gload(rb, st + 5);
+  }
+
+  // D layout of 32x32x16: lane (col n = lane % 32, kg): register e holds row k = (e / 4) * 8 + kg * 4 + e % 4
+  float* part = p.part + (long)s * p.N * p.K;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = n0 + wn * 128 + nb * 32 + i32;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int k = k0 + wk * 128 + kb * 32 + e4 * 8 + kg * 4;
+        *reinterpret_cast<f32x4*>(part + (long)n * p.K + k) =
+            (f32x4){acc[nb][kb][4 * e4], acc[nb][kb][4 * e4 + 1], acc[nb][kb][4 * e4 + 2], acc[nb][kb][4 * e4 + 3]};
+      }
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      float v = cacc[nb];
+      v += __shfl_xor(v, 32, 64);
+      if (kg == 0) p.cpart[(long)s * p.N + n0 + wn * 128 + nb * 32 + i32] = v;
+    }
+  }
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -835,11 +1031,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 // 0 = heuristic (register-transposed 256x256 kernel when N and K are multiples of 256, else 128x128 register-staged),
 // 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 / 16 waves, 4 = 256x256 / 8 waves,
-// 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed (benchmark / test knob)
+// 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed with 16x16x32 MFMAs, 7 = the same with 32x32x16 MFMAs
+// (= what the heuristic picks; benchmark / test knob)
 int g_tn_tile = 0;
 
 bool tn_use_rt(int64_t N, int64_t K) {
-  return (g_tn_tile == 0 || g_tn_tile == 6) && (N % 256 == 0) && (K % 256 == 0);
+  return (g_tn_tile == 0 || g_tn_tile == 6 || g_tn_tile == 7) && (N % 256 == 0) && (K % 256 == 0);
 }
 
 }  // namespace
@@ -897,7 +1094,8 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
     p.tiles_nk = (int)(N / 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = cdiv(p.npairs, 8);
-    hipLaunchKernelGGL(gemm_tn_rt_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
+    if (g_tn_tile != 6) hipLaunchKernelGGL(gemm_tn_rt32_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_tn_rt_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
   } else if (g_tn_tile == 5 && (N % 256 == 0) && (K % 256 == 0) && (M % 64 == 0)) {
     p.tiles_k = (int)(K / 256);
     p.tiles_nk = (int)(N / 256) * p.tiles_k;

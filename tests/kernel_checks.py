@@ -115,7 +115,7 @@ def check_gemm_nt_tiles():
             bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
             ref = bf(A) @ bf(W).t()
             Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
-            for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+            for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                 L.call("pvrl_debug_set_gemm_tile", knob)
                 o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_BF16, bias=bias.to(dev()))
                 out.append((f"gemm_nt tile{knob} bf16 {M}x{N}x{K}", rel(o, ref + bias), TOL_BF16))
@@ -177,10 +177,10 @@ def check_gemm_tn_variants():
             out.append((f"gemm_tn[{name}] dW", rel(dW, ref), 1e-4))
             out.append((f"gemm_tn[{name}] dbias", rel(db, bf(P).sum(0)), 1e-4))
         # the 4-wave 256x256 kernels need M % 64 == 0; slices of 2, 4, ... stages and empty slices
-        for knob, name in ((5, "ring"), (6, "rt")):
+        for knob, name in ((5, "ring"), (6, "rt"), (7, "rt32")):
             L.call("pvrl_debug_set_gemm_tn_tile", knob)
             for (M2, N2, K2, sp) in [(1152, 512, 256, 8), (4160, 256, 768, 16), (128, 256, 256, 8), (6400, 768, 768, 32),
-                                     (3200, 768, 256, 9 if knob == 6 else 8)] + ([(1111, 512, 256, 5), (1569, 256, 256, 3), (40, 256, 512, 4)] if knob == 6 else []):
+                                     (3200, 768, 256, 9 if knob >= 6 else 8)] + ([(1111, 512, 256, 5), (1569, 256, 256, 3), (40, 256, 512, 4)] if knob >= 6 else []):
                 P2 = torch.randn(M2, N2, generator=g); Q2 = torch.randn(M2, K2, generator=g)
                 ref2 = bf(P2).t() @ bf(Q2)
                 dW = torch.zeros(N2, K2, device=dev()); db = torch.zeros(N2, device=dev())

@@ -62,7 +62,7 @@ def main():
         gemm_case(f"nt[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
         gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
     for rep in range(2):
-        for tile, tg in ((3, "256 16 waves"), (7, "256x128 ring2"), (8, "256x128 ring3"), (9, "128x128 ring4")):
+        for tile, tg in ((3, "256 16 waves"), (10, "256 4w 32x32x16")):
             L.call("pvrl_debug_set_gemm_tile", tile)
             gemm_case(f"ab[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
@@ -101,9 +101,9 @@ def main():
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    for tile in (1, 0, 1, 0):
+    for tile in (6, 7, 6, 7):
         L.call("pvrl_debug_set_gemm_tn_tile", tile)
-        tg = {1: "128x128 tr-read", 0: "default"}[tile]
+        tg = {1: "128x128 tr-read", 0: "default", 6: "rt 16x16x32", 7: "rt 32x32x16"}[tile]
         tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
         tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
         tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
