@@ -854,9 +854,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
   const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
   auto gload = [&](u32x4* r, int st) {
     if ((st + 1) * TS <= rows) {                           // whole stage (uniform branch; every stage but the last)
+      // raw ISA loads: the compiler's own wait for a compiler-visible load here is s_waitcnt vmcnt(6..0) in front of the
+      // first perms of the NEXT step, which also drains the set issued one step later (no look-ahead left); issued as
+      // asm the two register sets are ordered by `wait_set` below with vmcnt(8): a true two-step look-ahead
       const char* b = ubase + (long)st * TS * ld2;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const u32x4*>(b + e * ld2 + loff);
+      for (int e = 0; e < 8; ++e)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[e]) : "v"(b + e * ld2 + loff) : "memory");
     } else {                                               // ragged or surplus stage: clamp the row, zero what is outside
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -951,6 +955,12 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
   };
+  // all 8 registers of the OLDER set have landed (the 8 loads of the newer set may stay in flight); the "+v" operands tie
+  // the perms that consume the set to this wait
+  auto wait_set = [&](u32x4* r) {
+    asm volatile("s_waitcnt vmcnt(8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+  };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -961,6 +971,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
   char* slot1 = smem + STAGE;
   gload(ra, 0);
   gload(rb, 1);
+  wait_set(ra);
 #pragma unroll
   for (int j = 0; j < 8; ++j) twrite(ra, j, slot0);
   gload(ra, 2);
@@ -970,17 +981,21 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
     pa[t] = rfrag(slot0, prd[t], 0); qa[t] = rfrag(slot0, qrd[t], 0);
     pb[t] = rfrag(slot0, prd[t], 1); qb[t] = rfrag(slot0, qrd[t], 1);
   }
+  wait_set(rb);
 #pragma unroll
   for (int j = 0; j < 8; ++j) twrite(rb, j, slot1);
   gload(rb, 3);
   for (int st = 0; st < nsteps; st += 2) {
     lds_barrier();
+    wait_set(ra);
     step(slot1, ra, slot0);
     gload(ra, st + 4);
     lds_barrier();
+    wait_set(rb);
     step(slot0, rb, slot1);
     gload(rb, st + 5);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // D layout of 32x32x16: lane (col n = lane % 32, kg): register e holds row k = (e / 4) * 8 + kg * 4 + e % 4
   float* part = p.part + (long)s * p.N * p.K;
