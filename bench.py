@@ -208,8 +208,8 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_e_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
-    path = os.path.join(ROOT, "profiles", "r1_e_traffic.json")
+    (profiles/r1_f_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r1_f_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
