@@ -63,28 +63,34 @@ __device__ __forceinline__ unsigned long long pad_bits_q(const AttnArgs& p, int 
   return bits;
 }
 
+// Cooperative load of one head slice [S rows][64] of a packed activation into the blocked LDS image, in two halves so a
+// kernel can put EVERY global load it needs (both tiles + its waves' own fragments) in flight before the first wait.
 template <int NT>
-__device__ __forceinline__ void load_tile(const bf16* base, long ld, int col0, const SeqRows& sr, int S, const bf16* src0,
-                                          char* rm, int rm_rows, char* bl, int bl_rows, int tid) {
+struct TileRegs { u32x4 v[(ATT_ROWS_PAD * 8 + NT - 1) / NT]; };
+
+template <int NT>
+__device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const bf16* base, long ld, int col0, const SeqRows& sr, int S,
+                                           const bf16* src0, int rows, int tid) {
   constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
-  const int maxrows = rm_rows > bl_rows ? rm_rows : bl_rows;
-  u32x4 v[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + NT * it;
     const int row = idx >> 3, c = idx & 7;
-    v[it] = (u32x4){0u, 0u, 0u, 0u};
-    if (row < S && row < maxrows) {
+    t.v[it] = (u32x4){0u, 0u, 0u, 0u};
+    if (row < S && row < rows) {
       const bf16* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
-      v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
+      t.v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
     }
   }
+}
+template <int NT>
+__device__ __forceinline__ void tile_commit(const TileRegs<NT>& t, char* bl, int rows, int tid) {
+  constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + NT * it;
     const int row = idx >> 3, c = idx & 7;
-    if (rm && row < rm_rows) *reinterpret_cast<u32x4*>(rm + rm_off(row, c)) = v[it];
-    if (bl && row < bl_rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = v[it];
+    if (row < rows) *reinterpret_cast<u32x4*>(bl + bl_off(row, c * 8)) = t.v[it];
   }
 }
 
@@ -92,7 +98,7 @@ __device__ __forceinline__ void load_tile(const bf16* base, long ld, int col0, c
 // forward
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * BL];
@@ -100,23 +106,43 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   char* Vb = smem + BL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  // workgroups are dealt round-robin to the 8 XCDs: keep the H heads of a sequence on ONE XCD, back to back, so the
+  // 128-byte head slices of a token row are fetched together (same DRAM pages, same L2)
+  const int xj = blockIdx.x >> 3;
+  const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
+  if (seq >= p.nseq) return;
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, nullptr, 0, Kb, NKS2 * 32, tid);
-  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, NKS2 * 32, tid);
-  __syncthreads();
-
+  constexpr int MAXT = (NKT + NW - 1) / NW;   // query tiles per wave
   const int q4 = lane >> 4, i = lane & 15;
-  const unsigned long long pbits = pad_bits_q<NKT, GEN>(p, seq, q4);
   const int nqt = (S + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += NW) {
-    const int query = qt * 16 + i;
+  // every global load of the workgroup goes out before the first wait: this wave's query fragments, then K and V
+  bf16x8 qf[MAXT][2];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int query = (wave + t * NW) * 16 + i;
     const int qrow = query < S ? query : S - 1;
     const bf16* qp = p.qkv + row_of(sr, qrow) * p.ld + h * 64 + q4 * 8;
-    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
-    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    qf[t][0] = *reinterpret_cast<const bf16x8*>(qp);
+    qf[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+  }
+  {
+    TileRegs<64 * NW> kr, vr;
+    tile_issue<64 * NW>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_issue<64 * NW>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_commit<64 * NW>(kr, Kb, NKS2 * 32, tid);
+    tile_commit<64 * NW>(vr, Vb, NKS2 * 32, tid);
+  }
+  __syncthreads();
+
+  const unsigned long long pbits = pad_bits_q<NKT, GEN>(p, seq, q4);
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int qt = wave + t * NW;
+    if (qt >= nqt) break;
+    const int query = qt * 16 + i;
+    const bf16x8 qf0 = qf[t][0], qf1 = qf[t][1];
 
     f32x4 sc[NKT];
 #pragma unroll
@@ -127,6 +153,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
       sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+      if (NKT > 5 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the fragment look-ahead (and VGPRs) bounded
     }
     // softmax over the lane's 4*NKT keys.  exp(scale*s - max) is evaluated as exp2(fma(s, c, -max*c)) with
     // c = scale*log2(e) (one FMA + one v_exp per element); P stays un-normalised (<= 1) and the 16 output values are
@@ -179,6 +206,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
         const bf16x8 vf = bl_frag(Vb, ks2, dt, lane);
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
       }
+      if (NKT > 5) __builtin_amdgcn_sched_barrier(0);
     }
     if (query < S) {
       bf16* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, sr, seq, query) + h * 64 + 4 * q4;
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 // backward, pass 1: dQ (and D = rowsum(dO * O)); waves own query tiles exactly as in the forward.
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * BL];
@@ -206,67 +234,68 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
   char* Vb = smem + BL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  // workgroups are dealt round-robin to the 8 XCDs: keep the H heads of a sequence on ONE XCD, back to back, so the
+  // 128-byte head slices of a token row are fetched together (same DRAM pages, same L2)
+  const int xj = blockIdx.x >> 3;
+  const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
+  if (seq >= p.nseq) return;
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, HD + h * 64, sr, S, nullptr, nullptr, 0, Kb, NKS2 * 32, tid);
-  load_tile<64 * NW>(p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, nullptr, 0, Vb, NKS2 * 32, tid);
+  constexpr int MAXT = (NKT + NW - 1) / NW;   // query tiles per wave
+  const int q4 = lane >> 4, i = lane & 15;
+  const int nqt = (S + 15) >> 4;
+  const float c = p.scale * 1.4426950408889634f;
+  // every global load of the workgroup goes out before the first wait: q / dO / O / lse of this wave's query tiles,
+  // then the K and V head slices
+  bf16x8 qf[MAXT][2], df[MAXT][2];
+  float lse2[MAXT], dss[MAXT];
+  {
+    bf16x8 of[MAXT][2];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int query = (wave + t * NW) * 16 + i;
+      const int qj = query < S ? query : S - 1;
+      const bf16* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
+      qf[t][0] = *reinterpret_cast<const bf16x8*>(qp);
+      qf[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+      const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
+      df[t][0] = *reinterpret_cast<const bf16x8*>(dop);
+      df[t][1] = *reinterpret_cast<const bf16x8*>(dop + 32);
+      const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
+      of[t][0] = *reinterpret_cast<const bf16x8*>(ofp);
+      of[t][1] = *reinterpret_cast<const bf16x8*>(ofp + 32);
+      lse2[t] = p.lse[((long)seq * p.H + h) * S + qj] * 1.4426950408889634f;
+    }
+    TileRegs<64 * NW> kr, vr;
+    tile_issue<64 * NW>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_issue<64 * NW>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)df[t][0][e] * (float)of[t][0][e] + (float)df[t][1][e] * (float)of[t][1][e];
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);
+      dss[t] = dsum * p.scale;
+      const int query = (wave + t * NW) * 16 + i;
+      if (q4 == 0 && query < S) p.dvec[((long)seq * p.H + h) * S + query] = dsum;
+    }
+    tile_commit<64 * NW>(kr, Kb, NKS2 * 32, tid);
+    tile_commit<64 * NW>(vr, Vb, NKS2 * 32, tid);
+  }
   __syncthreads();
 
-  const int q4 = lane >> 4, i = lane & 15;
   const unsigned long long pbits = pad_bits_q<NKT, GEN>(p, seq, q4);
-  const int nqt = (S + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += NW) {
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int qt = wave + t * NW;
+    if (qt >= nqt) break;
     const int query = qt * 16 + i;
-    const int qj = query < S ? query : S - 1;
-    const bf16* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
-    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
-    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
-    const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
-    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop);
-    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32);
-    const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
-    const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(ofp);
-    const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(ofp + 32);
-    float dsum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dsum += (float)df0[e] * (float)of0[e] + (float)df1[e] * (float)of1[e];
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    const long stat = ((long)seq * p.H + h) * S + qj;
-    const float c = p.scale * 1.4426950408889634f;
-    const float lse2 = p.lse[stat] * 1.4426950408889634f;
-    const float dss = dsum * p.scale;
-    if (q4 == 0 && query < S) p.dvec[stat] = dsum;
+    const bf16x8 qf0 = qf[t][0], qf1 = qf[t][1], df0 = df[t][0], df1 = df[t][1];
+    const float lse2_t = lse2[t], dss_t = dss[t];
 
-    f32x4 ds[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int krow = kt * 16 + i;
-      const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
-      const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
-      const bf16x8 v0 = bl_row_frag(Vb, krow, q4);
-      const bf16x8 v1 = bl_row_frag(Vb, krow, 4 + q4);
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
-      f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * q4 + r;
-        float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
-        if (GEN || kt * 16 + 15 >= S || qt * 16 + 15 >= S) {
-          bool msk = key >= S || query >= S;
-          if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
-          if (msk) pr = 0.f;
-        }
-        s[r] = pr * fmaf(dp[r], p.scale, -dss);
-      }
-      ds[kt] = s;
-    }
+    // dS for two 16-key tiles at a time, consumed at once by the dQ MFMAs: nothing but dq[] lives across iterations
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -274,16 +303,42 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
     for (int ks2 = 0; ks2 < NKS2; ++ks2) {
       bf16x8 sf;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sf[r] = (bf16)ds[2 * ks2][r];
-        if (2 * ks2 + 1 < NKT) sf[4 + r] = (bf16)ds[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r];
-        else sf[4 + r] = (bf16)0.f;
+      for (int half = 0; half < 2; ++half) {
+        const int kt = 2 * ks2 + half;
+        if (kt >= NKT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sf[4 * half + r] = (bf16)0.f;
+          continue;
+        }
+        const int krow = kt * 16 + i;
+        const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
+        const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
+        const bf16x8 v0 = bl_row_frag(Vb, krow, q4);
+        const bf16x8 v1 = bl_row_frag(Vb, krow, 4 + q4);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
+        f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * q4 + r;
+          float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2_t));
+          if (GEN || kt * 16 + 15 >= S || qt * 16 + 15 >= S) {
+            bool msk = key >= S || query >= S;
+            if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
+            if (msk) pr = 0.f;
+          }
+          sf[4 * half + r] = (bf16)(pr * fmaf(dp[r], p.scale, -dss_t));
+        }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 kf = bl_frag(Kb, ks2, dt, lane);
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, dq[dt], 0, 0, 0);
       }
+      if (NKT > 5) __builtin_amdgcn_sched_barrier(0);
     }
     if (query < S) {
       bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, query) + h * 64 + 4 * q4;
@@ -303,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs p) {
 // Needs lse and dvec from the forward / pass 1.
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int ROWS = NKS2 * 32;
   constexpr int T = ROWS * 128;
@@ -314,33 +369,52 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs p) {
   float* dv_s = lse_s + ROWS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int seq = blockIdx.x / p.H, h = blockIdx.x - seq * p.H;
+  // workgroups are dealt round-robin to the 8 XCDs: keep the H heads of a sequence on ONE XCD, back to back, so the
+  // 128-byte head slices of a token row are fetched together (same DRAM pages, same L2)
+  const int xj = blockIdx.x >> 3;
+  const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
+  if (seq >= p.nseq) return;
   const int S = p.mp.S;
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
-  load_tile<64 * NW>(p.qkv, p.ld, h * 64, sr, S, nullptr, nullptr, 0, Qb, ROWS, tid);
+  constexpr int MAXT = (NKT + NW - 1) / NW;   // key tiles per wave
+  const int q4 = lane >> 4, i = lane & 15;
+  const float c = p.scale * 1.4426950408889634f;
+  const int nkt_rt = (S + 15) >> 4;
+  // every global load of the workgroup goes out before the first wait: this wave's K / V fragments, then Q and dO
+  bf16x8 kf[MAXT][2], vf[MAXT][2];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int key = (wave + t * NW) * 16 + i;
+    const int kj = key < S ? key : S - 1;
+    const bf16* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
+    kf[t][0] = *reinterpret_cast<const bf16x8*>(kp);
+    kf[t][1] = *reinterpret_cast<const bf16x8*>(kp + 32);
+    vf[t][0] = *reinterpret_cast<const bf16x8*>(kp + HD);
+    vf[t][1] = *reinterpret_cast<const bf16x8*>(kp + HD + 32);
+  }
   {
     const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
-    load_tile<64 * NW>(p.d_o, p.ldo, h * 64, sr, S, src0, nullptr, 0, Db, ROWS, tid);
+    TileRegs<64 * NW> qr, dr;
+    tile_issue<64 * NW>(qr, p.qkv, p.ld, h * 64, sr, S, nullptr, ROWS, tid);
+    tile_issue<64 * NW>(dr, p.d_o, p.ldo, h * 64, sr, S, src0, ROWS, tid);
     for (int idx = tid; idx < ROWS; idx += 64 * NW) {
       const long stat = ((long)seq * p.H + h) * S + idx;
       lse_s[idx] = idx < S ? p.lse[stat] * 1.4426950408889634f : 0.f;
       dv_s[idx] = idx < S ? p.dvec[stat] * p.scale : 0.f;
     }
+    tile_commit<64 * NW>(qr, Qb, ROWS, tid);
+    tile_commit<64 * NW>(dr, Db, ROWS, tid);
   }
   __syncthreads();
 
-  const int q4 = lane >> 4, i = lane & 15;
-  const float c = p.scale * 1.4426950408889634f;
-  const int nkt_rt = (S + 15) >> 4;
-  for (int kt = wave; kt < nkt_rt; kt += NW) {
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int kt = wave + t * NW;
+    if (kt >= nkt_rt) break;
     const int key = kt * 16 + i;
     const int kj = key < S ? key : S - 1;
-    const bf16* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
-    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp);
-    const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
-    const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(kp + HD);
-    const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(kp + HD + 32);
+    const bf16x8 kf0 = kf[t][0], kf1 = kf[t][1], vf0 = vf[t][0], vf1 = vf[t][1];
     bool kbad = key >= S;
     if constexpr (GEN) kbad = kbad || (p.kpm ? (p.kpm[(long)seq * S + kj] != 0) : false);
 
@@ -409,7 +483,7 @@ int check_common(const AttnArgs& p) {
 
 template <int NKT, int NW>
 int launch_fwd(const AttnArgs& p, hipStream_t s) {
-  const dim3 grid((unsigned)(p.nseq * p.H)), blk(64 * NW);
+  const dim3 grid((unsigned)(8 * ((p.nseq + 7) / 8) * p.H)), blk(64 * NW);
   if (p.causal || p.kpm) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true, NW>), grid, blk, 0, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, NW>), grid, blk, 0, s, p);
   PVRL_LAUNCH_CHECK();
@@ -418,7 +492,7 @@ int launch_fwd(const AttnArgs& p, hipStream_t s) {
 
 template <int NKT, int NW>
 int launch_bwd(const AttnArgs& p, hipStream_t s) {
-  const dim3 grid((unsigned)(p.nseq * p.H)), blk(64 * NW);
+  const dim3 grid((unsigned)(8 * ((p.nseq + 7) / 8) * p.H)), blk(64 * NW);
   if (p.causal || p.kpm) {
     hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, true, NW>), grid, blk, 0, s, p);
     PVRL_LAUNCH_CHECK();
