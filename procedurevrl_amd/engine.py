@@ -133,16 +133,24 @@ class EncoderEngine:
             torch.cuda.current_stream().wait_stream(self._side)
 
     # ------------------------------------------------------------------ drop path
-    def _droppath(self, i, B, N, T, device, training):
-        rate = self.m.drop_path_rates[i]
-        if not training or rate == 0.0:
-            return None
-        keep = 1.0 - rate
-        # lib/models/vit_utils.py:140-155: floor(keep + U[0,1)) / keep per dim-0 row of each branch
-        s1 = torch.floor(keep + torch.rand(B * N, device=device)) / keep          # temporal: per (b h w)
-        s2 = torch.floor(keep + torch.rand(B * T, device=device)) / keep          # spatial: per (b t)
-        s3 = torch.floor(keep + torch.rand(B, device=device)) / keep              # mlp: per b
-        return self.expand_droppath(s1, s2, s3, B, N, T)
+    def _droppath_all(self, B, N, T, device, training):
+        """DropPath row scales of every block, lib/models/vit_utils.py:140-155: floor(keep + U[0,1)) / keep per dim-0 row
+        of each branch (temporal: per (b h w); spatial: per (b t); mlp: per b).  All blocks are drawn and expanded to
+        token rows with ONE set of launches (a per-block version costs ~20 tiny kernels x depth on the critical path)."""
+        rates = [float(r) for r in self.m.drop_path_rates]
+        nb = len(rates)
+        if not training or all(r == 0.0 for r in rates):
+            return [None] * nb
+        keep = torch.tensor([1.0 - r for r in rates], device=device, dtype=F32).view(nb, 1)
+        n1, n2, n3 = B * N, B * T, B
+        sc = torch.floor(keep + torch.rand((nb, n1 + n2 + n3), device=device)) / keep
+        s1, s2, s3 = sc[:, :n1], sc[:, n1:n1 + n2], sc[:, n1 + n2:]
+        s1_tok = s1.repeat_interleave(T, dim=1)                                       # [nb, B*N*T]
+        s2_seq = s2.contiguous()
+        s2_tok = s2.reshape(nb, B, 1, T).expand(nb, B, N, T).reshape(nb, -1)          # [nb, B*N*T]
+        s3_all = torch.cat([s3.repeat_interleave(N * T, dim=1), s3], 1)               # [nb, B*N*T + B]
+        return [None if rates[i] == 0.0 else dict(s1_tok=s1_tok[i], s2_seq=s2_seq[i], s2_tok=s2_tok[i], s3_all=s3_all[i])
+                for i in range(nb)]
 
     @staticmethod
     def expand_droppath(s1, s2, s3, B, N, T):
@@ -194,9 +202,10 @@ class EncoderEngine:
         x[R:] = (m.cls_token.detach()[0, 0] + pos[0]).unsqueeze(0)
         sv["a_pe"] = a_pe if save else None
 
+        if droppath is None:
+            droppath = self._droppath_all(B, N, T, dev, training)
         for i, blk in enumerate(m.blocks):
-            dp = droppath[i] if droppath is not None else self._droppath(i, B, N, T, dev, training)
-            x = self._block_fwd(blk, x, sv, dp, save)
+            x = self._block_fwd(blk, x, sv, droppath[i], save)
 
         feat, mean, rstd = ops.layernorm_fwd(x[R:], m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
                                              out_dtype=F32)
