@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--classes", type=int, default=9871)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--host-profile", action="store_true", help="cProfile the host side of the timed steps (stderr)")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
+    ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient instead of one per block")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
     args = ap.parse_args()
@@ -105,6 +107,8 @@ def main():
     model.train()
     if args.no_wgrad_overlap:
         vt.engine.overlap_wgrad = False
+    if args.no_wgrad_group and hasattr(vt.engine, "group_wgrad"):
+        vt.engine.group_wgrad = False
     optimizer = construct_optimizer(model, cfg)
     set_lr(optimizer, cfg.SOLVER.BASE_LR)
     optimizer.grad_scale = 1.0 / world
@@ -139,9 +143,19 @@ def main():
     barrier()
     if not args.no_kernel_timing:
         ops.KERNEL_TIMING = []
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+    t_enq = time.perf_counter() - t0      # host time to enqueue the K steps (informational: launch-bound if ~ dt)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -184,7 +198,7 @@ def main():
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "loss": float(loss.item()),
+            "loss": float(loss.item()), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
             "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),
                            "frac_of_bf16_peak": round(value / world * wtrain / 2.5e15, 4),
                            "w_train_gflop_per_clip": round(wtrain / 1e9, 2)},

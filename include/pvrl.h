@@ -69,6 +69,25 @@ int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, in
                       int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,
                       void* stream);
 
+/* Several weight gradients of the same backward pass in ONE launch (a transformer block's seven nn.Linear dW,
+ * loss.backward(), tools/train_net.py:176-181): the (row slice, 256x256 tile) work items of all problems share the 256 CUs,
+ * so every problem is cut into the same small number of slices (pvrl_gemm_tn_grouped_plan_splits) instead of the 7-28 a
+ * lone dW needs -- longer reduction loops, less fp32 partial traffic.  1 <= nprob <= 8, every N and K a multiple of
+ * 256, M >= 1 (else PVRL_EINVAL: use pvrl_gemm_tn_bf16 per problem).  Semantics per problem as pvrl_gemm_tn_bf16;
+ * deterministic.  workspace >= pvrl_gemm_tn_grouped_workspace_bytes(nprob, problems, splits). */
+typedef struct pvrl_tn_problem {
+  const void* P; int64_t ldp;     /* bf16 [M, N] */
+  const void* Q; int64_t ldq;     /* bf16 [M, K] */
+  int64_t M, N, K;
+  float beta;
+  float* dW;                      /* fp32 [N, K] */
+  float* dbias;                   /* fp32 [N] or null */
+} pvrl_tn_problem;
+int64_t pvrl_gemm_tn_grouped_plan_splits(int nprob, const pvrl_tn_problem* problems);
+int64_t pvrl_gemm_tn_grouped_workspace_bytes(int nprob, const pvrl_tn_problem* problems, int64_t splits);
+int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* problems, int64_t splits, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 /* LayerNorm over fp32 rows, C in {512, 768} (vit.py:104,109,116,228 eps 1e-6; tfm_model.py:18-24 eps 1e-5).
  * fwd: y = (x - mean) * rstd * gamma + beta  -> bf16 (GEMM operand) or fp32.
  * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows; optionally also writes
@@ -187,14 +206,17 @@ int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const floa
 /* attention_pool (attention.py:14-48) for mode "conv": depthwise Conv3d(96 ch, kernel 3x3x3, padding 1, stride st,sh,sw, no
  * bias; weight fp32 [96][27]) + LayerNorm(96) on one of q / k / v taken in place from the packed qkv activation (bf16
  * [B*T*Hh*Ww + B][ld], columns col0 + h*96 ..); the cls token skips the conv.  y / conv_out: [B*H][To*Ho*Wo + 1][96] bf16.
- * Backward writes this tensor's slice of dqkv and ACCUMULATES dw [96][27], dgamma, dbeta; dc_scratch: bf16, size of y. */
+ * Backward writes this tensor's slice of dqkv and ACCUMULATES dw [96][27], dgamma, dbeta; dc_scratch: bf16, size of y;
+ * workspace >= pvrl_mvit_pool_bwd_workspace_bytes() holds per-workgroup fp32 partials of dw that a second kernel sums in a
+ * fixed order (same-address fp32 atomics from 8 XCDs cost ~0.5 us each and made every call ~200 us). */
 int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww,
                        int64_t st, int64_t sh, int64_t sw, const float* w, const float* gamma, const float* beta,
                        float eps, void* y, void* conv_out, void* stream);
+int64_t pvrl_mvit_pool_bwd_workspace_bytes(void);
 int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const void* qkv, void* dqkv, int64_t ld, int64_t col0,
                        int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st, int64_t sh, int64_t sw,
                        const float* w, const float* gamma, float eps, void* dc_scratch, float* dw, float* dgamma,
-                       float* dbeta, void* stream);
+                       float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* MaxPool3d skip of MultiScaleBlock (attention.py:537-552): kernel (1,s+1,s+1), stride (1,s,s), padding (0,(s+1)/2,..),
  * fp32 token matrix in / out, cls rows copied.  Backward routes to the first maximum (torch semantics). */
@@ -205,14 +227,18 @@ int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* dy, int64_t 
 
 /* Decomposed relative-position terms (attention.py:67-159): rel[bh][q][j] = Q[bh][q] . R_j(q), j over kh heights, kw
  * widths, kt times; R_j(q) = rel_pos_h[idx_h[qh(q)][j]] ... with the int32 index tables of attention.py:80-98,130-137.
- * Backward: dQ += drel . R (in place on the bf16 dQ of the attention backward), dR* ACCUMULATED. */
+ * Backward: dQ += drel . R (in place on the bf16 dQ of the attention backward), dR* ([nrows_*][96]) ACCUMULATED from
+ * per-workgroup partials in the workspace (>= pvrl_mvit_rel_bwd_workspace_bytes) summed in a fixed order. */
 int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw,
                       const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h, const int32_t* idx_w,
                       const int32_t* idx_t, float* rel, void* stream);
+int64_t pvrl_mvit_rel_bwd_workspace_bytes(int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
+                                          int64_t kw);
 int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh, int64_t qw,
                       int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw, const float* Rt,
-                      const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* dRh, float* dRw,
-                      float* dRt, void* stream);
+                      const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, int64_t nrows_h, int64_t nrows_w,
+                      int64_t nrows_t, float* dRh, float* dRw, float* dRt, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* Pooling attention (attention.py:404-442): softmax(scale q k^T + rel bias) v (+ q, residual pooling) for head_dim 96;
  * q [B*H][Lq+1][96], k / v [B*H][kt*kh*kw+1][96]; o / d_o token-major [B*Lq + B][ldo] with column h*96 + d.

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so")
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
+    "const pvrl_tn_problem*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -31,6 +32,8 @@ def parse_header(path=HEADER):
         parsed = []
         for a in args.split(","):
             a = " ".join(a.split())
+            if a in ("void", ""):
+                continue
             mm = re.match(r"(.*?)(\w+)$", a)
             ty = mm.group(1).strip().replace(" *", "*")
             parsed.append((ty, mm.group(2)))
@@ -41,6 +44,13 @@ def parse_header(path=HEADER):
 def header_constants(path=HEADER):
     txt = open(path).read()
     return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(PVRL_\w+)\s+(-?\d+)", txt)}
+
+
+class TnProblem(ctypes.Structure):
+    """`pvrl_tn_problem` of include/pvrl.h"""
+    _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_int64), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+                ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("beta", ctypes.c_float),
+                ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
 
 
 class PvrlError(RuntimeError):

@@ -1014,6 +1014,110 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8x32_kernel(GemmNT p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The default 16-wave 256x256 tile with v_mfma_f32_32x32x16_bf16 (wave block 64 x 64 = 2 x 2 blocks): the same LDS bytes
+// per FLOP, half the MFMA instructions and half the operand-register reads per FLOP.  Benchmark knob 12.  MEASURED
+// (MI355X, M=50208): 12-20 % slower than the 16x16x32 form on every shape (qkv 228 vs 191 us, dfc1 264 vs 228 us): with
+// only 2 x 2 accumulator blocks a wave has 4 independent 64-cycle MFMAs in flight instead of 16 32-cycle ones.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_nt_w16x32_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, NW = 16;
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int PER = (BM + BN) / 8 / NW;   // 8
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 4 x 4 waves of 64 x 64
+  const int GM = p.gm;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16* gsrc[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int it = wave * PER + j;
+    const int pc = lane & 7;
+    if (it < BM / 8) {
+      const int row = it * 8 + (lane >> 3);
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+    } else {
+      const int row = (it - BM / 8) * 8 + (lane >> 3);
+      gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_x(row)) << 3);
+    }
+  }
+  auto stage = [&](int buf, int k0) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);
+  };
+
+  // fragment of block b for K = 16 sub-step u (0..3): row r, 16-byte chunk 2u + kg of the 128-byte row
+  const int i32 = lane & 31, kg = lane >> 5;
+  int xoff[2], woff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int rx = wm * 64 + b * 32 + i32;
+    xoff[b] = rx * 128 + ((kg ^ swz_x(rx)) << 4);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int rw = wn * 64 + b * 32 + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
+    woff[b] = XBYTES + rw * 128 + ((kg ^ swz_x(rw)) << 4);
+  }
+  auto rd = [&](const char* b, int off, int u) { return *reinterpret_cast<const bf16x8*>(b + (off ^ (u << 5))); };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* b = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bf16x8 xf[2], wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[t] = rd(b, woff[t], u);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) xf[t] = rd(b, xoff[t], u);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = m0 + wm * 64 + mb * 32 + i32;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) epi_row16<EPI>(p, acc[mb][nb], m, n0 + wn * 64 + nb * 32 + 16 * kg);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Small fp32 GEMM for the projection head / step-logit path, where M is a few
 // dozen rows and the reference keeps fp32 (lib/models/vit.py:299-307):
@@ -1178,6 +1282,15 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
     q.tiles_m = cdiv(q.M, 256);
     q.nwg = 8 * cdiv(q.tiles_m, 8) * q.tiles_n;
     hipLaunchKernelGGL((gemm_nt_w8x32_kernel<EPI>), dim3(q.nwg), dim3(512), 0, s, q);
+    PVRL_LAUNCH_CHECK();
+    return PVRL_OK;
+  }
+  if (t == 12 && p.N % 256 == 0) {
+    GemmNT q = p;
+    q.tiles_n = q.N / 256;
+    q.tiles_m = cdiv(q.M, 256);
+    q.nwg = 8 * cdiv(q.tiles_m, 8) * q.tiles_n;
+    hipLaunchKernelGGL((gemm_nt_w16x32_kernel<EPI>), dim3(q.nwg), dim3(1024), 0, s, q);
     PVRL_LAUNCH_CHECK();
     return PVRL_OK;
   }

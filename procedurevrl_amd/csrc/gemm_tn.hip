@@ -810,22 +810,18 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt_kernel(GemmTN p) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
-  constexpr int TS = 32;
-  constexpr int OPB = 4 * 256 * 16;                        // 16 KiB per operand and stage
-  constexpr int STAGE = 2 * OPB;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+constexpr int RT32_TS = 32;
+constexpr int RT32_OPB = 4 * 256 * 16;                     // 16 KiB per operand and stage
+constexpr int RT32_STAGE = 2 * RT32_OPB;
+
+// One (slice, tile) pair of problem `p`: the body shared by the single-problem and the grouped kernel.
+__device__ __forceinline__ void tn_rt32_pair(const GemmTN& p, const int pair, char* smem) {
+  constexpr int TS = RT32_TS, OPB = RT32_OPB, STAGE = RT32_STAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wk = wave >> 1;
-  int s, rem;
-  {
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int pair = xcd * p.Ms_pairs + jj;                // (slice, tile) pairs in slice-major order, one chunk per XCD
-    if (jj >= p.Ms_pairs || pair >= p.npairs) return;
-    s = pair / p.tiles_nk;
-    rem = pair - s * p.tiles_nk;
-  }
+  const int s = pair / p.tiles_nk;
+  const int rem = pair - s * p.tiles_nk;
   const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   const int mbeg = s * p.Ms;
@@ -1021,6 +1017,38 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
   }
 }
 
+__global__ __launch_bounds__(256, 1) void gemm_tn_rt32_kernel(GemmTN p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT32_STAGE];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int pair = xcd * p.Ms_pairs + jj;                  // (slice, tile) pairs in slice-major order, one chunk per XCD
+  if (jj >= p.Ms_pairs || pair >= p.npairs) return;
+  tn_rt32_pair(p, pair, smem);
+}
+
+// Several weight gradients in ONE launch: the (slice, tile) pairs of up to 8 problems are laid end to end and dealt to the
+// XCDs in contiguous chunks.  A Linear's dW has 9-36 tiles of 256x256; alone, each needs 7-28 row slices to fill 256 CUs
+// (short reduction loops, 67 MB of fp32 partials per call); a transformer block's seven dW together have 153 tiles, so 5
+// slices give 765 equal work items = 2.99 rounds of 256, with 5x longer loops and 2.3x less partial traffic.
+constexpr int TN_GROUP_MAX = 8;
+struct TnGroup {
+  int nprob, total, per_xcd;
+  int first[TN_GROUP_MAX + 1];     // first global pair index of each problem
+  GemmTN prob[TN_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256, 1) void gemm_tn_rt32_grouped_kernel(TnGroup g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT32_STAGE];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int gp = xcd * g.per_xcd + jj;
+  if (jj >= g.per_xcd || gp >= g.total) return;
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < TN_GROUP_MAX; ++t)
+    if (t < g.nprob && gp >= g.first[t]) q = t;
+  const GemmTN p = g.prob[q];
+  tn_rt32_pair(p, gp - g.first[q], smem);
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -1141,5 +1169,92 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
                      (int)splits, NK, (int)N, beta, dW, dbias);
   PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// grouped weight gradients
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+bool tn_group_ok(int nprob, const pvrl_tn_problem* pr) {
+  if (nprob < 1 || nprob > TN_GROUP_MAX || !pr) return false;
+  for (int i = 0; i < nprob; ++i) {
+    const pvrl_tn_problem& q = pr[i];
+    if (!q.P || !q.Q || !q.dW || q.M < 1 || q.N <= 0 || q.K <= 0 || (q.N % 256) || (q.K % 256)) return false;
+    if ((q.ldp % 8) || (q.ldq % 8) || ((uintptr_t)q.P % 16) || ((uintptr_t)q.Q % 16)) return false;
+  }
+  return true;
+}
+int64_t tn_group_tiles(int nprob, const pvrl_tn_problem* pr) {
+  int64_t t = 0;
+  for (int i = 0; i < nprob; ++i) t += (pr[i].N / 256) * (pr[i].K / 256);
+  return t;
+}
+}  // namespace
+
+extern "C" int64_t pvrl_gemm_tn_grouped_plan_splits(int nprob, const pvrl_tn_problem* problems) {
+  if (!tn_group_ok(nprob, problems)) return PVRL_EINVAL;
+  const int64_t T = tn_group_tiles(nprob, problems);
+  int64_t smax = 32;
+  for (int i = 0; i < nprob; ++i) smax = std::min<int64_t>(smax, std::max<int64_t>(1, problems[i].M / 64));
+  // the smallest slice count whose T*s equal work items fill whole rounds of the 256 CUs to >= 97 %, else the best one
+  int64_t best = 1;
+  double best_eff = 0.0;
+  for (int64_t s = 1; s <= smax; ++s) {
+    const int64_t items = T * s;
+    const double eff = (double)items / (double)(256 * cdiv(items, 256));
+    if (eff >= 0.97) return s;
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+  }
+  return best;
+}
+
+extern "C" int64_t pvrl_gemm_tn_grouped_workspace_bytes(int nprob, const pvrl_tn_problem* problems, int64_t splits) {
+  if (!tn_group_ok(nprob, problems) || splits < 1) return PVRL_EINVAL;
+  int64_t b = 0;
+  for (int i = 0; i < nprob; ++i) b += splits * (problems[i].N * problems[i].K + problems[i].N) * (int64_t)sizeof(float);
+  return b;
+}
+
+extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* problems, int64_t splits, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  if (!tn_group_ok(nprob, problems) || splits < 1 || !workspace) return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_gemm_tn_grouped_workspace_bytes(nprob, problems, splits)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  TnGroup g = {};
+  g.nprob = nprob;
+  float* w = (float*)workspace;
+  int first = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const pvrl_tn_problem& q = problems[i];
+    GemmTN& p = g.prob[i];
+    p.P = (const bf16*)q.P; p.ldp = q.ldp; p.Q = (const bf16*)q.Q; p.ldq = q.ldq;
+    p.M = (int)q.M; p.N = (int)q.N; p.K = (int)q.K;
+    p.Ms = cdiv(cdiv(q.M, splits), TM) * TM;
+    p.part = w;
+    w += splits * q.N * q.K;
+    p.cpart = q.dbias ? w : nullptr;
+    w += splits * q.N;
+    p.zero_page = nullptr;
+    p.tiles_k = (int)(q.K / 256);
+    p.tiles_nk = (int)(q.N / 256) * p.tiles_k;
+    p.npairs = (int)splits * p.tiles_nk;
+    p.Ms_pairs = 0;
+    g.first[i] = first;
+    first += p.npairs;
+  }
+  g.first[nprob] = first;
+  g.total = first;
+  g.per_xcd = cdiv(first, 8);
+  hipLaunchKernelGGL(gemm_tn_rt32_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(256), 0, s, g);
+  PVRL_LAUNCH_CHECK();
+  for (int i = 0; i < nprob; ++i) {
+    const pvrl_tn_problem& q = problems[i];
+    const long NK = q.N * q.K;
+    const long nthreads = (NK >> 2) + (q.dbias ? q.N : 0);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, g.prob[i].part,
+                       g.prob[i].cpart, (int)splits, NK, (int)q.N, q.beta, q.dW, q.dbias);
+    PVRL_LAUNCH_CHECK();
+  }
   return PVRL_OK;
 }

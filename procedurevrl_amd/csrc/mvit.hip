@@ -386,7 +386,7 @@ __device__ __forceinline__ f32x4 ld4bf(const bf16* p) {
 }
 __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16* __restrict__ dc,
                                                                       const bf16* __restrict__ qkv, PoolGeom g,
-                                                                      float* __restrict__ dw) {
+                                                                      float* __restrict__ part) {
   __shared__ float red[27][HD];
   const int cq = threadIdx.x % PW_CQ, tl = threadIdx.x / PW_CQ, c0 = cq * 4;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
@@ -429,7 +429,34 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicAdd(&red[t][c0 + e], acc[t][e]);      // LDS: 8 lanes per address
   __syncthreads();
-  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) atomicAdd(dw + (i % HD) * 27 + i / HD, red[i / HD][i % HD]);
+  float* mine = part + (long)blockIdx.x * (27 * HD);
+  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) mine[i] = red[i / HD][i % HD];
+}
+
+// dw[c][tap] += sum over workgroups of part[wg][tap][c] in a fixed order (deterministic): 16 outputs x 16 slices of
+// the workgroup list per block, slices combined through LDS
+constexpr int PW_MAX_WG = 2048;
+__global__ __launch_bounds__(256) void pool_wgrad_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ dw) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + o;            // 27 * 96 = 2592 = 162 * 16
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = sl;
+  for (; b + 48 < nwg; b += 64) {
+    a0 += part[(long)b * (27 * HD) + i];
+    a1 += part[(long)(b + 16) * (27 * HD) + i];
+    a2 += part[(long)(b + 32) * (27 * HD) + i];
+    a3 += part[(long)(b + 48) * (27 * HD) + i];
+  }
+  for (; b < nwg; b += 16) a0 += part[(long)b * (27 * HD) + i];
+  red[sl][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a += red[t][threadIdx.x];
+    dw[(i % HD) * 27 + i / HD] += a;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- max-pool skip
@@ -576,8 +603,7 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
 // grid (q_n, chunks of the (bh, other) range); block = 96 channels x 2 slices; a thread keeps all k_n <= 16 sums of its channel.
 constexpr int REL_KMAX = 16;
 __global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const bf16* __restrict__ Q,
-                                                            RelGeom g, int axis, const int* __restrict__ idx,
-                                                            float* __restrict__ dR) {
+                                                            RelGeom g, int axis, float* __restrict__ part) {
   __shared__ float red[REL_KMAX][HD];
   const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
   const int coord = blockIdx.x;
@@ -611,11 +637,34 @@ __global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restr
     for (int j = 0; j < REL_KMAX; ++j) red[j][c] = a[j];
   }
   __syncthreads();
-  if (sl == 0) {
+  if (sl == 0) {                                   // part[chunk][coord][j][c]
+    float* mine = part + ((long)blockIdx.y * gridDim.x + coord) * kn * HD;
 #pragma unroll
     for (int j = 0; j < REL_KMAX; ++j)
-      if (j < kn) atomicAdd(dR + (long)idx[coord * kn + j] * HD + c, a[j] + red[j][c]);
+      if (j < kn) mine[j * HD + c] = a[j] + red[j][c];
   }
+}
+
+// p2[coord][j][c] = sum over chunks of part[chunk][coord][j][c], in chunk order
+__global__ __launch_bounds__(256) void rel_table_reduce1_kernel(const float* __restrict__ part, int nchunks, long n,
+                                                                float* __restrict__ p2) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f;
+  int b = 0;
+  for (; b + 2 <= nchunks; b += 2) { a0 += part[(long)b * n + i]; a1 += part[(long)(b + 1) * n + i]; }
+  if (b < nchunks) a0 += part[(long)b * n + i];
+  p2[i] = a0 + a1;
+}
+// dR[r][c] += sum of p2[coord][j][c] over the (coord, j) whose table index is r, in (coord, j) order (deterministic; the
+// same-address fp32 atomics this replaces cost ~100 us per call).  One block of 96 threads per table row.
+__global__ __launch_bounds__(HD) void rel_table_reduce2_kernel(const float* __restrict__ p2, const int* __restrict__ idx,
+                                                               int npairs, float* __restrict__ dR) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  float a = 0.f;
+  for (int e = 0; e < npairs; ++e)
+    if (idx[e] == r) a += p2[(long)e * HD + c];
+  dR[(long)r * HD + c] += a;
 }
 
 // ------------------------------------------------------------------------------------------------- misc
@@ -714,13 +763,16 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   return PVRL_OK;
 }
 
+extern "C" int64_t pvrl_mvit_pool_bwd_workspace_bytes(void) { return (int64_t)PW_MAX_WG * 27 * HD * sizeof(float); }
+
 extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const void* qkv, void* dqkv, int64_t ld,
                                   int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st,
                                   int64_t sh, int64_t sw, const float* w, const float* gamma, float eps, void* dc_scratch,
-                                  float* dw, float* dgamma, float* dbeta, void* stream) {
+                                  float* dw, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
   PoolGeom g;
-  if (!dy || !conv_out || !qkv || !dqkv || !w || !gamma || !dc_scratch || !dw || !dgamma || !dbeta ||
-      pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0))
+  if (!dy || !conv_out || !qkv || !dqkv || !w || !gamma || !dc_scratch || !dw || !dgamma || !dbeta || !workspace ||
+      workspace_bytes < pvrl_mvit_pool_bwd_workspace_bytes() || pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0))
     return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long Lo = (long)g.To * g.Ho * g.Wo;
@@ -735,10 +787,13 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
                      (bf16*)dqkv);
   PVRL_LAUNCH_CHECK();
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
-  if (wb > 1024) wb = 1024;
+  if (wb > PW_MAX_WG) wb = PW_MAX_WG;
   if (wb < 1) wb = 1;
   hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const bf16*)dc_scratch,
-                     (const bf16*)qkv, g, dw);
+                     (const bf16*)qkv, g, (float*)workspace);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pool_wgrad_reduce_kernel, dim3(27 * HD / 16), dim3(256), 0, s, (const float*)workspace,
+                     (int)wb, dw);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -793,31 +848,54 @@ extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t 
   return PVRL_OK;
 }
 
+namespace {
+unsigned rel_chunks(int64_t BH, int64_t qn, int64_t n_other) {     // ~2048 blocks per axis, at least 64 (bh, other) pairs each
+  int64_t c = 2048 / qn, m = (BH * n_other + 63) / 64;
+  if (c > m) c = m;
+  return (unsigned)(c < 1 ? 1 : c);
+}
+}  // namespace
+
+extern "C" int64_t pvrl_mvit_rel_bwd_workspace_bytes(int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
+                                                     int64_t kw) {
+  if (BH <= 0 || qt <= 0 || qh <= 0 || qw <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return PVRL_EINVAL;
+  const int64_t eh = (rel_chunks(BH, qh, qt * qw) + 1) * qh * kh, ew = (rel_chunks(BH, qw, qt * qh) + 1) * qw * kw,
+                et = (rel_chunks(BH, qt, qh * qw) + 1) * qt * kt;
+  return (eh + ew + et) * HD * (int64_t)sizeof(float);
+}
+
 extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh,
                                  int64_t qw, int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw,
                                  const float* Rt, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
-                                 float* dRh, float* dRw, float* dRt, void* stream) {
+                                 int64_t nrows_h, int64_t nrows_w, int64_t nrows_t, float* dRh, float* dRw, float* dRt,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
   RelGeom g;
-  if (!drel || !Q || !dQ || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !dRh || !dRw || !dRt ||
-      rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
+  if (!drel || !Q || !dQ || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !dRh || !dRw || !dRt || !workspace ||
+      nrows_h <= 0 || nrows_w <= 0 || nrows_t <= 0 || rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
     return PVRL_EINVAL;
+  if (kh > REL_KMAX || kw > REL_KMAX || kt > REL_KMAX) return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_mvit_rel_bwd_workspace_bytes(BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)BH * qt * qh * qw * (HD / 4);
   hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
                      (bf16*)dQ);
   PVRL_LAUNCH_CHECK();
-  if (kh > REL_KMAX || kw > REL_KMAX || kt > REL_KMAX) return PVRL_EINVAL;
-  auto chunks = [&](int64_t qn, int64_t n_other) {     // ~2048 blocks per axis, at least 64 (bh, other) pairs each
-    int64_t c = 2048 / qn, m = (BH * n_other + 63) / 64;
-    if (c > m) c = m;
-    return (unsigned)(c < 1 ? 1 : c);
+  float* w = (float*)workspace;
+  auto axis = [&](int ax, int64_t qn, int64_t kn, int64_t n_other, const int32_t* idx, int64_t nrows, float* dR) {
+    const unsigned ch = rel_chunks(BH, qn, n_other);
+    const long n = (long)qn * kn * HD;
+    float* part = w;
+    float* p2 = w + (long)ch * n;
+    w = p2 + n;
+    hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qn, ch), dim3(192), 0, s, drel, (const bf16*)Q, g, ax, part);
+    hipLaunchKernelGGL(rel_table_reduce1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                       (int)ch, n, p2);
+    hipLaunchKernelGGL(rel_table_reduce2_kernel, dim3((unsigned)nrows), dim3(HD), 0, s, (const float*)p2, idx,
+                       (int)(qn * kn), dR);
   };
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qh, chunks(qh, qt * qw)), dim3(192), 0, s, drel, (const bf16*)Q,
-                     g, 0, idx_h, dRh);
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qw, chunks(qw, qt * qh)), dim3(192), 0, s, drel, (const bf16*)Q,
-                     g, 1, idx_w, dRw);
-  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qt, chunks(qt, qh * qw)), dim3(192), 0, s, drel, (const bf16*)Q,
-                     g, 2, idx_t, dRt);
+  axis(0, qh, kh, qt * qw, idx_h, nrows_h, dRh);
+  axis(1, qw, kw, qt * qh, idx_w, nrows_w, dRw);
+  axis(2, qt, kt, qh * qw, idx_t, nrows_t, dRt);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

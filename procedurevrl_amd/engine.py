@@ -82,6 +82,9 @@ class EncoderEngine:
         self.grad_hook = None
         self.overlap_wgrad = True     # weight-gradient GEMMs on a side stream, concurrent with the dgrad chain
         self._side = None
+        self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
+        self._wq = []
+        self._keep = None
         assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
 
     # ------------------------------------------------------------------ weights
@@ -116,17 +119,28 @@ class EncoderEngine:
         return self._side
 
     def _wgrad(self, dy, xin, dw, dbias, beta):
-        side = self.side_stream(dy.device)
-        if side is None:
-            ops.gemm_tn(dy, xin, dw, dbias, beta=beta)
+        """queue dW = beta*dW + dy^T xin (and dbias); `flush_wgrads` issues what is queued"""
+        self._wq.append((dy, xin, dw, dbias, beta))
+        if not self.group_wgrad:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        """Issue the queued weight gradients as one grouped launch (ops.gemm_tn_grouped) -- on the side stream when
+        overlap_wgrad, ordered after everything the current stream has produced so far."""
+        q, self._wq = self._wq, []
+        if not q:
             return
-        main = torch.cuda.current_stream()
-        ev = main.record_event()
+        side = self.side_stream(q[0][0].device)
+        if side is None:
+            ops.gemm_tn_grouped(q, ws_tag="tn")
+            return
+        ev = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            ops.gemm_tn(dy, xin, dw, dbias, beta=beta, ws_tag="tn_side")
-        dy.record_stream(side)
-        xin.record_stream(side)
+            ops.gemm_tn_grouped(q, ws_tag="tn_side")
+        for dy, xin, _, _, _ in q:
+            dy.record_stream(side)
+            xin.record_stream(side)
 
     def join_side_stream(self):
         if self._side is not None:
@@ -141,7 +155,9 @@ class EncoderEngine:
         nb = len(rates)
         if not training or all(r == 0.0 for r in rates):
             return [None] * nb
-        keep = torch.tensor([1.0 - r for r in rates], device=device, dtype=F32).view(nb, 1)
+        if self._keep is None or self._keep[0] != (tuple(rates), device):   # cached: a host->device copy blocks the host
+            self._keep = ((tuple(rates), device), torch.tensor([1.0 - r for r in rates], device=device, dtype=F32).view(nb, 1))
+        keep = self._keep[1]
         n1, n2, n3 = B * N, B * T, B
         sc = torch.floor(keep + torch.rand((nb, n1 + n2 + n3), device=device)) / keep
         s1, s2, s3 = sc[:, :n1], sc[:, n1:n1 + n2], sc[:, n1 + n2:]
@@ -313,6 +329,7 @@ class EncoderEngine:
                                       "resizes at inference only, vit.py:374)")
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
+        self.flush_wgrads()
         self.join_side_stream()
         self.saved = None
 
@@ -386,4 +403,5 @@ class EncoderEngine:
         lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R], dxs=dy_next[:R], dxs_scale=s3p)
         if has_prev:
             ops.cast_scale(dx[R:], s3p[R:] if s3p is not None else None, out=dy_next[R:])
+        self.flush_wgrads()
         return dy_next

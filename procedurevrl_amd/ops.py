@@ -145,6 +145,42 @@ def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
     return dW
 
 
+TN_GROUP_MAX = 8
+
+
+def gemm_tn_grouped(problems, ws_tag="tn_group"):
+    """problems: list of (P, Q, dW, dbias | None, beta), each as gemm_tn -- all issued as ONE grouped launch when every
+    N and K is a multiple of 256 (pvrl_gemm_tn_grouped_bf16), otherwise one gemm_tn per problem."""
+    from ._lib import TnProblem
+    L = lib()
+    if not problems:
+        return
+    ok = 1 < len(problems) <= TN_GROUP_MAX and all(
+        P.shape[1] % 256 == 0 and Q.shape[1] % 256 == 0 and P.shape[0] >= 1 for P, Q, _, _, _ in problems)
+    if not ok:
+        for i in range(0, len(problems), 1):
+            P, Q, dW, dbias, beta = problems[i]
+            gemm_tn(P, Q, dW, dbias, beta=beta, ws_tag=ws_tag)
+        return
+    arr = (TnProblem * len(problems))()
+    flops = 0.0
+    for a, (P, Q, dW, dbias, beta) in zip(arr, problems):
+        _chk2d(P, BF16); _chk2d(Q, BF16)
+        M, N = P.shape
+        K = Q.shape[1]
+        assert Q.shape[0] == M and dW.shape == (N, K) and dW.is_contiguous() and dW.dtype == F32
+        assert dbias is None or (dbias.dtype == F32 and dbias.is_contiguous() and dbias.numel() == N)
+        a.P, a.ldp, a.Q, a.ldq, a.M, a.N, a.K = P.data_ptr(), _ld(P), Q.data_ptr(), _ld(Q), M, N, K
+        a.beta, a.dW, a.dbias = float(beta), dW.data_ptr(), (None if dbias is None else dbias.data_ptr())
+        flops += 2.0 * M * N * K
+    ap = ctypes.addressof(arr)
+    splits = L.call("pvrl_gemm_tn_grouped_plan_splits", len(problems), ap)
+    nbytes = L.call("pvrl_gemm_tn_grouped_workspace_bytes", len(problems), ap, splits)
+    ws = workspace(nbytes, problems[0][0].device, ws_tag)
+    _timed("gemm_tn_grouped+reduce", flops, lambda: L.call(
+        "pvrl_gemm_tn_grouped_bf16", len(problems), ap, splits, _ptr(ws), ws.numel(), _stream()))
+
+
 # ----------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------

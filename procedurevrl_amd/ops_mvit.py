@@ -72,8 +72,11 @@ def pool_bwd(dy, conv_out, qkv, dqkv, col0, B, H, thw, stride, w, gamma, eps, dw
     L = lib()
     scratch = torch.empty_like(conv_out)
     assert dy.dtype == BF16 and dy.is_contiguous() and dw.is_contiguous() and dw.dtype == F32
+    from .ops import workspace
+    ws = workspace(L.call("pvrl_mvit_pool_bwd_workspace_bytes"), dy.device, "mvit_pool_bwd")
     L.call("pvrl_mvit_pool_bwd", _ptr(dy), _ptr(conv_out), _ptr(qkv), _ptr(dqkv), qkv.stride(0), col0, B, H, *thw,
-           *stride, _ptr(w), _ptr(gamma), float(eps), _ptr(scratch), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _stream())
+           *stride, _ptr(w), _ptr(gamma), float(eps), _ptr(scratch), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+           ws.numel(), _stream())
 
 
 def maxpool_fwd(x, B, thw, s, C):
@@ -110,8 +113,12 @@ def rel_fwd(Q, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it):
 
 def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt):
     L = lib()
+    from .ops import workspace
+    ws = workspace(L.call("pvrl_mvit_rel_bwd_workspace_bytes", BH, *q_thw, *k_thw), drel.device, "mvit_rel_bwd")
+    assert dRh.is_contiguous() and dRw.is_contiguous() and dRt.is_contiguous()
     L.call("pvrl_mvit_rel_bwd", _ptr(drel), _ptr(Q), _ptr(dQ), BH, *q_thw, *k_thw, _ptr(Rh), _ptr(Rw), _ptr(Rt), _ptr(ih),
-           _ptr(iw), _ptr(it), _ptr(dRh), _ptr(dRw), _ptr(dRt), _stream())
+           _ptr(iw), _ptr(it), dRh.shape[0], dRw.shape[0], dRt.shape[0], _ptr(dRh), _ptr(dRw), _ptr(dRt), _ptr(ws),
+           ws.numel(), _stream())
 
 
 def attn_fwd(q, k, v, rel, B, H, Lq, k_thw, scale, ldo):

@@ -115,7 +115,7 @@ def check_gemm_nt_tiles():
             bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
             ref = bf(A) @ bf(W).t()
             Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
-            for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
                 L.call("pvrl_debug_set_gemm_tile", knob)
                 o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_BF16, bias=bias.to(dev()))
                 out.append((f"gemm_nt tile{knob} bf16 {M}x{N}x{K}", rel(o, ref + bias), TOL_BF16))
@@ -189,6 +189,44 @@ def check_gemm_tn_variants():
                 out.append((f"gemm_tn[{name}] dbias {M2}x{N2}x{K2}", rel(db, bf(P2).sum(0)), 1e-4))
     finally:
         L.call("pvrl_debug_set_gemm_tn_tile", 0)
+    return out
+
+
+def check_gemm_tn_grouped():
+    """several weight gradients in one launch (pvrl_gemm_tn_grouped_bf16): ragged and differing M, bias / no bias,
+    accumulate, bit-identical across repeats, and the per-problem fallback for shapes the grouped kernel refuses"""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(33)
+    out = []
+    shapes = [(1569, 768, 256, True, 0.0), (1569, 256, 768, True, 1.0), (1568, 256, 256, False, 0.0),
+              (1569, 512, 256, True, 0.0), (1000, 256, 512, True, 1.0)]
+    def make():
+        probs, refs = [], []
+        gg = torch.Generator().manual_seed(34)
+        for (M, N, K, hb, beta) in shapes:
+            P = torch.randn(M, N, generator=gg); Q = torch.randn(M, K, generator=gg)
+            w0 = torch.randn(N, K, generator=gg); b0 = torch.randn(N, generator=gg)
+            dW = w0.to(dev()).clone(); db = b0.to(dev()).clone() if hb else None
+            probs.append((P.to(dev(), BF), Q.to(dev(), BF), dW, db, beta))
+            refs.append((beta * w0 + bf(P).t() @ bf(Q), beta * b0 + bf(P).sum(0)))
+        return probs, refs
+    probs, refs = make()
+    ops.gemm_tn_grouped(probs)
+    for (M, N, K, hb, beta), (_, _, dW, db, _), (rw, rb) in zip(shapes, probs, refs):
+        out.append((f"gemm_tn_grouped dW {M}x{N}x{K} beta={beta}", rel(dW, rw), 1e-4))
+        if hb:
+            out.append((f"gemm_tn_grouped dbias {M}x{N}x{K}", rel(db, rb), 1e-4))
+    probs2, _ = make()
+    ops.gemm_tn_grouped(probs2)
+    same = all(torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3])) for a, b in zip(probs, probs2))
+    out.append(("gemm_tn_grouped bit-identical across repeats", 0.0 if same else 1.0, 0.5))
+    # a 128-multiple shape in the list -> one plain launch per problem, same results
+    P = torch.randn(500, 128, generator=g); Q = torch.randn(500, 384, generator=g)
+    dW = torch.zeros(128, 384, device=dev())
+    probs3, refs3 = make()
+    ops.gemm_tn_grouped(probs3[:2] + [(P.to(dev(), BF), Q.to(dev(), BF), dW, None, 0.0)])
+    out.append(("gemm_tn_grouped fallback dW", rel(dW, bf(P).t() @ bf(Q)), 1e-4))
+    out.append(("gemm_tn_grouped fallback dW[0]", rel(probs3[0][2], refs3[0][0]), 1e-4))
     return out
 
 
@@ -486,5 +524,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
