@@ -222,21 +222,31 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_f_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent."""
-    path = os.path.join(ROOT, "profiles", "r1_f_traffic.json")
+    (profiles/r1_g_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
+    A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
+    path = os.path.join(ROOT, "profiles", "r1_g_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
     epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
     if kernel.startswith("gemm_tn"):
-        keys = [k for k in t if k.startswith("gemm_tn_") or k.startswith("tn_reduce_kernel")]
-    else:
-        e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
-        keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]
+        want = "gemm_tn_rt32_grouped_kernel" if "grouped" in kernel else "gemm_tn_rt32_kernel"
+        if want not in t:
+            return None
+        b = t[want]["hbm_bytes_per_launch"]
+        red = t.get("tn_reduce_kernel")
+        if red:
+            nmain = sum(v.get("launches", 0) for k, v in t.items() if k.startswith("gemm_tn_"))
+            per = red.get("launches", 0) / nmain if nmain else 1.0      # reduces per weight gradient problem
+            nprob = 7.0 if "grouped" in kernel else 1.0                 # a transformer block's seven nn.Linear
+            b += red["hbm_bytes_per_launch"] * (nprob if per > 1.5 else 1.0)
+        return round(b, 0)
+    e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
+    keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]
     if not keys:
         return None
     main = max(keys, key=lambda k: t[k]["avg_us"])
-    return round(sum(t[k]["hbm_bytes_per_launch"] for k in keys if k == main or k.startswith("tn_reduce")), 0)
+    return round(t[main]["hbm_bytes_per_launch"], 0)
 
 
 def cpu_baseline(args):

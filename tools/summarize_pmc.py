@@ -36,7 +36,7 @@ def main():
         dmu = sum(dm.get(k, [1.0])) / max(1, len(dm.get(k, [1.0])))
         util = mf / (1024 * dmu * 1e-9 * 2.1e9) if dmu else 0.0     # 1024 SIMDs, ~2.1 GHz under load
         rows.append([k, n, f"{d / 1e3:.1f}", f"{rd / 1e6:.1f}", f"{wr / 1e6:.1f}", f"{(rd + wr) / d:.0f}", f"{100 * util:.1f}"])
-        traffic[k] = {"hbm_bytes_per_launch": rd + wr, "avg_us": d / 1e3}
+        traffic[k] = {"hbm_bytes_per_launch": rd + wr, "avg_us": d / 1e3, "launches": n}
     with open(sys.argv[4], "w", newline="") as fo:
         fo.write("# rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES} (separate passes) -- "
                  "python bench.py --steps 3 --warmup 1; read MB = 2*FETCH_SIZE KiB (gfx950 correction)\n")
