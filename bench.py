@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--host-profile", action="store_true", help="cProfile the host side of the timed steps (stderr)")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
+    ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of HIP-graph replay of the encoder")
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient instead of one per block")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
@@ -109,6 +110,9 @@ def main():
         vt.engine.overlap_wgrad = False
     if args.no_wgrad_group and hasattr(vt.engine, "group_wgrad"):
         vt.engine.group_wgrad = False
+    graphs = hasattr(vt.engine, "use_graphs") and vt.engine.use_graphs and not args.no_graphs
+    if hasattr(vt.engine, "use_graphs"):
+        vt.engine.use_graphs = graphs
     optimizer = construct_optimizer(model, cfg)
     set_lr(optimizer, cfg.SOLVER.BASE_LR)
     optimizer.grad_scale = 1.0 / world
@@ -138,19 +142,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if graphs:      # set-up, like building the model: the encoder's launch sequence is captured into HIP graphs on its
+        for _ in range(vt.engine.GRAPH_WARMUP + 1):   # third call, whatever --warmup is
+            step()
     for _ in range(args.warmup):
         loss = step()
     barrier()
-    if not args.no_kernel_timing:
-        ops.KERNEL_TIMING = []
+    # Per-kernel HIP events cannot be recorded inside a captured graph (ROCm refuses external event nodes), so with
+    # graphs the LAST step of the timed region is issued eagerly -- the same kernels, launched one by one -- and carries
+    # the events; without graphs every step does.
+    timing_steps = set() if args.no_kernel_timing else ({args.steps - 1} if graphs else set(range(args.steps)))
     prof = None
     if args.host_profile:
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    timed_events = []
+    for k in range(args.steps):
+        if k in timing_steps:
+            ops.KERNEL_TIMING = timed_events
+            vt.engine.use_graphs = False
         loss = step()
+        if k in timing_steps:
+            ops.KERNEL_TIMING = None
+            vt.engine.use_graphs = graphs
     if prof is not None:
         import pstats
         prof.disable()
@@ -162,13 +178,15 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    timing = ops.collect_kernel_timing() if not args.no_kernel_timing else None
+    ops.KERNEL_TIMING = timed_events if timing_steps else None
+    timing = ops.collect_kernel_timing() if timing_steps else None
     ops.KERNEL_TIMING = None
     # isolated leg (untimed, not part of `value`): the same step with the weight-gradient GEMMs on the main stream, so
     # that a launch's event-timed duration is the kernel's own and not its share of a GPU it co-runs on with the dgrad
     # chain (under overlap the TN and NT kernels each see about half the CUs and their durations double)
     isolated = None
     if timing and getattr(vt.engine, "overlap_wgrad", False):
+        vt.engine.use_graphs = False
         vt.engine.overlap_wgrad = False
         step(); barrier()
         ops.KERNEL_TIMING = []
@@ -178,6 +196,7 @@ def main():
         iso = ops.collect_kernel_timing()
         ops.KERNEL_TIMING = None
         vt.engine.overlap_wgrad = True
+        vt.engine.use_graphs = graphs
         if iso and timing["roofline"]["kernel"] in iso["summary"]:
             k = iso["summary"][timing["roofline"]["kernel"]]
             isolated = {"achieved": k["tflops"], "frac": round(k["tflops"] / 2500.0, 4), "avg_launch_us": k["avg_us"],
@@ -198,7 +217,7 @@ def main():
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "loss": float(loss.item()), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
+            "loss": float(loss.item()), "hip_graphs": bool(graphs), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
             "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),
                            "frac_of_bf16_peak": round(value / world * wtrain / 2.5e15, 4),
                            "w_train_gflop_per_clip": round(wtrain / 1e9, 2)},

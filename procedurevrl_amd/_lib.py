@@ -65,17 +65,19 @@ class _Lib:
                 "(there is no CPU or PyTorch fallback for the HIP path)")
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self._fn = {}
         for name, (ret, args) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError -> loud failure on a missing export
             fn.restype = _RET[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
+            self._fn[name] = (fn, ret == "int")
         for k, v in header_constants().items():
             setattr(self, k, v)
 
     def call(self, name, *args):
-        fn = getattr(self.cdll, name)
+        fn, is_status = self._fn[name]
         rc = fn(*args)
-        if self.protos[name][0] == "int" and rc != 0:
+        if is_status and rc != 0:
             raise PvrlError(f"{name} failed with status {rc}")
         return rc
 

@@ -15,6 +15,7 @@ copy kernels.  Activations are bf16 GEMM operands; the residual stream, LayerNor
 statistics, softmax statistics and all parameter gradients are fp32.
 """
 import math
+import os
 
 import torch
 
@@ -69,6 +70,8 @@ class _W:
 
 
 class EncoderEngine:
+    _capturing = None     # "fwd" / "bwd" while a HIP graph of that pass is being captured (class default for subclasses)
+
     def __init__(self, model):
         """`model` is a procedurevrl_amd.vit.VisionTransformer (same parameter names as the reference)."""
         self.m = model
@@ -84,7 +87,14 @@ class EncoderEngine:
         self._side = None
         self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
         self._wq = []
+        self._side_keep = []
         self._keep = None
+        self.use_graphs = os.environ.get("PVRL_HIP_GRAPHS", "1") == "1"   # see _graph_forward
+        self._capturing = None
+        self._graphs = {}
+        self._gpool = None
+        self._gkey = None
+        self._gseen = {}
         assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
 
     # ------------------------------------------------------------------ weights
@@ -94,7 +104,10 @@ class EncoderEngine:
             e = _W()
             self._w[id(p)] = e
         ver = (p._version, getattr(self.m, "weights_epoch", 0), p.data_ptr())
-        if e.ver != ver or e.w is None or e.w.device != p.device:
+        if self._capturing == "bwd":      # the forward graph of the same step refreshed the copies
+            assert e.w is not None and (e.t is not None or not need_t)
+            return e
+        if self._capturing == "fwd" or e.ver != ver or e.w is None or e.w.device != p.device:
             w2 = p.detach().reshape(p.shape[0], -1).contiguous()
             same = e.w is not None and e.w.device == p.device
             e.w, t = ops.cast_weight(w2, out=e.w if same else None, out_t=e.t if same else None, need_t=need_t)
@@ -138,13 +151,19 @@ class EncoderEngine:
         with torch.cuda.stream(side):
             side.wait_event(ev)
             ops.gemm_tn_grouped(q, ws_tag="tn_side")
-        for dy, xin, _, _, _ in q:
-            dy.record_stream(side)
-            xin.record_stream(side)
+            done = side.record_event()
+        # The operands must outlive the side-stream kernels.  Tensor.record_stream would do that, but every pending
+        # record makes EACH later allocation poll its event (measured: torch.empty 2 -> 52 us with ~170 records in flight,
+        # 20 ms of host time per step); instead the references are parked here until the launch's event has completed,
+        # or until join_side_stream() has ordered the main stream behind the side stream.
+        self._side_keep.append((done, [t for dy, xin, _, _, _ in q for t in (dy, xin)]))
+        while not self._capturing and self._side_keep and self._side_keep[0][0].query():
+            self._side_keep.pop(0)        # (no event queries while capturing: there everything is held until the join)
 
     def join_side_stream(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        self._side_keep.clear()      # later allocations are ordered behind the join on the current stream
 
     # ------------------------------------------------------------------ drop path
     def _droppath_all(self, B, N, T, device, training):
@@ -194,7 +213,14 @@ class EncoderEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, frames, training, droppath=None, save=True):
         """frames fp32 [B, 3, T, H, W] on the GPU (or transform.DecodedClips) -> (feat fp32 [B, C] = norm(x)[:, 0]).
-        `droppath`: optional list (per block) of dicts from expand_droppath, to pin the RNG draws."""
+        `droppath`: optional list (per block) of dicts from expand_droppath, to pin the RNG draws.
+        With `use_graphs` the launch sequence of a (shape, mode) is captured once into a HIP graph and replayed."""
+        if self.use_graphs and droppath is None and isinstance(frames, torch.Tensor) and frames.is_cuda:
+            return self._graph_forward(frames, training, save)
+        self._gkey = None
+        return self._forward(frames, training, droppath, save)
+
+    def _forward(self, frames, training, droppath=None, save=True):
         L = lib()
         m = self.m
         B, _, T, HI, WI = frames.shape
@@ -282,38 +308,206 @@ class EncoderEngine:
                                      lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp))
         return x3
 
+    # ------------------------------------------------------------------ HIP graphs
+    # One training step of the encoder is ~1,400 kernel launches (~7 ms of Python on an idle host, several times that
+    # when the node's cores are contended -- measured up to 95 ms, more than the 57 ms the GPU needs).  The launch
+    # sequence of a given (shape, mode) never changes, so it is captured once (torch.cuda.CUDAGraph = hipGraph; the
+    # C ABI launches on the capturing stream like on any other) and replayed: forward and backward are one graph each,
+    # sharing a memory pool so the activations saved by the forward graph are the backward graph's inputs.  What a
+    # replay cannot express falls back to the eager path: pinned DropPath draws, DecodedClips inputs, gradient
+    # accumulation into existing .grad tensors.
+    GRAPH_WARMUP = 2      # eager calls of a key before it is captured (lazy workspaces / caches settle)
+
+    GRAPH_MAX_KEYS = 4    # captured (shape, mode) combinations kept; others run eagerly
+
+    def _graph_key(self, frames, training, save):
+        m = self.m
+        # parameter / gradient storage is baked into a graph: a re-homed parameter (optimizer flat buffer, .to()) is a new key
+        return (tuple(frames.shape), bool(training), bool(save), frames.device.index, tuple(m.drop_path_rates),
+                m.blocks[0].attn.qkv.weight.data_ptr(), m.norm.weight.data_ptr(), self.grad_store().flat.data_ptr())
+
+    def _graph_forward(self, frames, training, save):
+        key = self._graph_key(frames, training, save)
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._gseen.get(key, 0)
+            self._gseen[key] = n + 1
+            if n < self.GRAPH_WARMUP or len(self._graphs) >= self.GRAPH_MAX_KEYS:
+                self._gkey = None
+                return self._forward(frames, training, None, save)
+            try:
+                g = self._capture_forward(key, frames, training, save)
+            except Exception as e:      # never fatal: the eager launch sequence is the same kernels
+                self._graph_failed("forward", e)
+                self._gkey = None
+                return self._forward(frames, training, None, save)
+        g["frames"].copy_(frames)
+        g["fwd"].replay()
+        self.saved = g["saved"]
+        self._gkey = key if save else None
+        return g["feat"]
+
+    def _graph_failed(self, what, e):
+        import warnings
+        warnings.warn(f"HIP graph capture of the encoder {what} failed ({type(e).__name__}: {e}); continuing with eager "
+                      "launches")
+        self.use_graphs = False
+        self._capturing = None
+        self._graphs = {}
+        self._wq = []
+        self._side_keep = []
+        torch.cuda.synchronize()
+
+    def _capture_forward(self, key, frames, training, save):
+        if self._gpool is None:
+            self._gpool = torch.cuda.graph_pool_handle()
+        st = torch.empty_like(frames)
+        st.copy_(frames)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = "fwd"
+        try:
+            with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                feat = self._forward(st, training, None, save)
+        finally:
+            self._capturing = None
+        g = dict(fwd=graph, frames=st, feat=feat, saved=self.saved if save else None)
+        self._graphs[key] = g
+        return g
+
+    def _grads_fresh(self):
+        return all(p.grad is None for p in self._enc_params())
+
+    def _enc_params(self):
+        """the parameters whose gradients backward() writes"""
+        m = self.m
+        ps = [m.cls_token, m.pos_embed, m.time_embed] + list(m.patch_embed.parameters()) + list(m.norm.parameters())
+        for blk in m.blocks:
+            ps += list(blk.parameters())
+        return [p for p in ps if p.requires_grad]
+
+    def _graph_backward(self, dfeat):
+        g = self._graphs[self._gkey]
+        if not self._grads_fresh():                     # accumulation into existing gradients: beta = 1 launches
+            self.saved = dict(g["saved"]); self.saved["blocks"] = list(g["saved"]["blocks"])
+            return self._backward(dfeat)
+        staged = self.grad_hook is not None             # cut the graph where the data-parallel reducer hooks in
+        nb = len(self.m.blocks)
+        slot = "bwd_staged" if staged else "bwd"
+        if g.get(slot) is None and not self._capture_backward(g, slot, staged, nb, dfeat):
+            self.saved = dict(g["saved"]); self.saved["blocks"] = list(g["saved"]["blocks"])
+            self._gkey = None
+            return self._backward(dfeat)
+        gb = g[slot]
+        gb["dfeat"].copy_(dfeat)
+        if not staged:
+            gb["graphs"][0].replay()
+        else:
+            for k, graph in enumerate(gb["graphs"]):
+                graph.replay()
+                self.grad_hook(nb - 1 - k)
+        for p, v in gb["touched"]:
+            p.grad = v
+        self.saved = None
+        self._gkey = None
+
+    def _capture_backward(self, g, slot, staged, nb, dfeat):
+        """-> True when g[slot] holds the captured graph(s); False after a failed capture (graphs are then switched off)"""
+        st_in = torch.empty_like(dfeat.contiguous())
+        st_in.copy_(dfeat)
+        torch.cuda.synchronize()
+        hook, self.grad_hook = self.grad_hook, None
+        gs = self.grad_store()
+        before = {id(p) for p in gs.params if p.grad is not None}
+        graphs = []
+        self._capturing = "bwd"
+        err = None
+        try:
+            self.saved = g["saved"]
+            if not staged:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                    self._backward(st_in)
+                graphs.append(graph)
+            else:
+                # one graph per block (the first also holds the final-norm stage, the last the embedding stage); a
+                # capture cannot end with side-stream work in flight, so each stage joins its weight gradients
+                state = None
+                for i in range(nb - 1, -1, -1):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                        if state is None:
+                            state = self._bwd_begin(st_in)
+                        self._bwd_block(state, i)
+                        if i == 0:
+                            self._bwd_end(state)
+                        else:
+                            self.join_side_stream()
+                    graphs.append(graph)
+        except Exception as e:          # never fatal: the eager launch sequence is the same kernels
+            err = e
+        finally:
+            self._capturing = None
+            self.grad_hook = hook
+        touched = [(p, p.grad) for p in gs.params if p.grad is not None and id(p) not in before]
+        for p, _ in touched:            # capture ran no kernel: undo its host-side effect
+            p.grad = None
+        if err is not None:
+            self._graph_failed("backward", err)
+            return False
+        g[slot] = dict(graphs=graphs, dfeat=st_in, touched=touched)
+        return True
+
     # ------------------------------------------------------------------ backward
     def backward(self, dfeat):
         """dfeat fp32 [B, C]: gradient of the loss w.r.t. forward()'s output.  Writes every encoder
         parameter gradient into the GradStore views (p.grad) and returns nothing."""
-        L = lib()
+        if self._gkey is not None:
+            return self._graph_backward(dfeat)
+        return self._backward(dfeat)
+
+    def _backward(self, dfeat):
+        st = self._bwd_begin(dfeat)
+        for i in range(len(self.m.blocks) - 1, -1, -1):
+            self._bwd_block(st, i)
+            if self.grad_hook is not None:
+                self.grad_hook(i)   # block i's parameter gradients are final: the reducer may start its all-reduce
+        self._bwd_end(st)
+
+    # the three stages of backward(); a stage boundary is where the gradient hook may run (and where a staged HIP-graph
+    # capture is cut, see _graph_backward)
+    def _bwd_begin(self, dfeat):
         m = self.m
         sv = self.saved
         assert sv is not None, "backward() without a saved forward()"
+        if self._capturing:          # the captured forward's activations are reused by every replay: work on a copy
+            sv = dict(sv)
+            sv["blocks"] = list(sv["blocks"])
         gs = self.grad_store()
-        B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
-        C = self.C
-        dev = dfeat.device
-
-        dx = torch.zeros((M, C), device=dev, dtype=F32)
+        R, M = sv["R"], sv["M"]
+        dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
         mean, rstd = sv["norm_stats"]
         (dg, bg), (db, bb) = gs.target(m.norm.weight), gs.target(m.norm.bias)
         ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
                           dx_out=dx[R:], beta_acc=bg)
-
         # dy = bf16(DropPath-scale * dx) is the operand of each block's first backward GEMMs; after the first block it is
         # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
         last = len(m.blocks) - 1
         s3 = sv["blocks"][last]["dp"]["s3_all"] if sv["blocks"][last]["dp"] else None
         dy = ops.cast_scale(dx, s3)
-        for i in range(last, -1, -1):
-            nxt = sv["blocks"][i - 1]["dp"] if i > 0 else None
-            dy = self._block_bwd(m.blocks[i], sv["blocks"][i], sv, dx, gs, dy, i > 0, nxt)
-            sv["blocks"][i] = None  # free activations as we go
-            if self.grad_hook is not None:
-                self.grad_hook(i)   # block i's parameter gradients are final: the reducer may start its all-reduce
+        return dict(sv=sv, gs=gs, dx=dx, dy=dy)
 
+    def _bwd_block(self, st, i):
+        sv = st["sv"]
+        nxt = sv["blocks"][i - 1]["dp"] if i > 0 else None
+        st["dy"] = self._block_bwd(self.m.blocks[i], sv["blocks"][i], sv, st["dx"], st["gs"], st["dy"], i > 0, nxt)
+        sv["blocks"][i] = None  # free activations as we go
+
+    def _bwd_end(self, st):
         # ---- embedding prologue + patch embed (vit.py:174-180, 370-407) ----
+        m = self.m
+        sv, gs, dx, dy = st["sv"], st["gs"], st["dx"], st["dy"]
+        B, T, N, R, C = sv["B"], sv["T"], sv["N"], sv["R"], self.C
         dz = dy[:R]     # block 0's last LayerNorm backward emitted the unscaled bf16 copy of dx[:R]
         w = m.patch_embed.proj.weight
         (dw, bw), (dbias, _) = gs.target(w), gs.target(m.patch_embed.proj.bias)

@@ -219,6 +219,7 @@ class MViTEngine:
     Token matrices are fp32 [B*L + B, pad128(C)]: patch tokens (b, t, h, w) first, the B cls tokens last."""
 
     _weight = EncoderEngine._weight      # un-padded bf16 copies for the width-512 stacks (order transformer, text tower)
+    _capturing = None                    # (EncoderEngine._weight consults it; this engine never captures HIP graphs)
 
     def __init__(self, owner, enc):
         self.m = owner                   # the wrapper (weights_epoch, grad_target)

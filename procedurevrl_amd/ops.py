@@ -56,8 +56,12 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream     # (device index) -> hipStream_t as int; ~20x cheaper than
+_cur_device = torch._C._cuda_getDevice                # torch.cuda.current_stream().cuda_stream (8 us per call)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
 
 
 def _chk2d(t, dtype=None):

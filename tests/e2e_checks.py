@@ -359,5 +359,63 @@ def check_step_is_bit_reproducible():
             ("gradients differ between two runs (count)", float((res[0][1] != res[1][1]).sum()), 0.0)]
 
 
-ALL_CHECKS = [check_step_is_bit_reproducible, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
+def check_hip_graph_replay():
+    """The HIP-graph replay of the encoder step (engine.use_graphs: forward = one graph, backward = one graph, or one
+    per block when a data-parallel gradient hook is installed) launches the same kernels as the eager path: logits and
+    every gradient bit-identical with DropPath off, on inputs the graph was not captured on; accumulation into existing
+    gradients falls back to eager launches; with DropPath on, successive replays draw different masks."""
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    out = []
+    cfg = make_cfg(2, 48, 200, drop_path=0.0)
+    model = build(cfg, synthetic_label_emb(200, 512, seed=1)).to(DEV).train()
+    eng = model.model.engine
+    with torch.no_grad():
+        for blk in model.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(5, 3, 8, 48, 48, generator=g).to(DEV) for _ in range(2)]
+    teacher = (torch.randn(5, 200, generator=g) * 3).to(DEV)
+
+    def step(x, zero=True):
+        if zero:
+            model.zero_grad(set_to_none=True)
+        pred = model(x)
+        kl_topk_loss(pred, teacher, 5).backward()
+        return pred.detach().clone(), model.model.adopt_grads().flat.clone()
+
+    eng.use_graphs = False
+    ref = [step(x) for x in xs]
+    eng.use_graphs = True
+    for _ in range(eng.GRAPH_WARMUP + 1):
+        step(xs[0])
+    out.append(("graphs were captured (0 = yes)", 0.0 if len(eng._graphs) == 1 else 1.0, 0.5))
+    for i in (1, 0):
+        pred, grads = step(xs[i])
+        out.append((f"graph replay, input {i}: logits differ (count)", float((pred != ref[i][0]).sum()), 0.0))
+        out.append((f"graph replay, input {i}: gradients differ (count)", float((grads != ref[i][1]).sum()), 0.0))
+    calls = []
+    eng.grad_hook = calls.append
+    for i in (0, 1):
+        del calls[:]
+        pred, grads = step(xs[i])
+        out.append((f"staged replay, input {i}: gradients differ (count)", float((grads != ref[i][1]).sum()), 0.0))
+        out.append((f"staged replay, input {i}: hook order wrong", 0.0 if calls == [1, 0] else 1.0, 0.5))
+    eng.grad_hook = None
+    _, acc = step(xs[0], zero=False)         # accumulate on top of the gradients of xs[1]
+    out.append(("accumulating step after a replay (eager fallback)", rel(acc, ref[0][1] + ref[1][1]), 1e-5))
+    # DropPath: the masks come from torch's graph-safe Philox state and must differ from replay to replay
+    cfg = make_cfg(2, 48, 200, drop_path=0.3)
+    model = build(cfg, synthetic_label_emb(200, 512, seed=1)).to(DEV).train()
+    preds = []
+    for _ in range(model.model.engine.GRAPH_WARMUP + 3):
+        model.zero_grad(set_to_none=True)
+        pred = model(xs[0])
+        kl_topk_loss(pred, teacher, 5).backward()
+        preds.append(pred.detach().clone())
+    out.append(("DropPath masks repeat across replays (0 = they differ)", 1.0 if torch.equal(preds[-1], preds[-2]) else 0.0, 0.5))
+    return out
+
+
+ALL_CHECKS = [check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
               check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size]

@@ -13,7 +13,7 @@ __device__ __forceinline__ int swz_x(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int w_row(int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); }
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
-struct P { const bf16* A; long lda; const bf16* W; long ldw; int M, N, K; bf16* out; long ldo; int tiles_m, tiles_n, gm; };
+struct P { const bf16* A; long lda; const bf16* W; long ldw; int M, N, K; bf16* out; long ldo; int tiles_m, tiles_n, gm; float* ws; int splits; };
 
 template <int ABL>
 __global__ __launch_bounds__(1024) void k(P p) {
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(1024) void k(P p) {
     tm = mbase + g * GM + (r - tn * gm);
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = (ABL == 6) ? (int)blockIdx.y * (p.K / p.splits) : 0;
   const bf16* gsrc[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
@@ -48,10 +49,10 @@ __global__ __launch_bounds__(1024) void k(P p) {
       const int row = it * 8 + (lane >> 3);
       int grow = m0 + row;
       grow = grow < p.M ? grow : p.M - 1;
-      gsrc[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+      gsrc[j] = p.A + (long)grow * p.lda + kbeg + ((pc ^ swz_x(row)) << 3);
     } else {
       const int row = (it - BM / 8) * 8 + (lane >> 3);
-      gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w(row)) << 3);
+      gsrc[j] = p.W + (long)(n0 + row) * p.ldw + kbeg + ((pc ^ swz_w(row)) << 3);
     }
   }
   auto stage = [&](int buf, int k0) {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(1024) void k(P p) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = p.K / BK;
+  const int nk = (ABL == 6 ? p.K / p.splits : p.K) / BK;
   stage(0, 0);
   if (ABL == 1 || ABL == 5) stage(1, BK);
   bf16x8 xf0[4], wf0[4], xf1[4], wf1[4];
@@ -136,6 +137,14 @@ __global__ __launch_bounds__(1024) void k(P p) {
       }
     }
   }
+  if (ABL == 6) {   // fp32 partial in register order: [tile][split][wave][reg][lane] x f32x4
+    float* w = p.ws + ((((long)(tm * p.tiles_n + tn) * p.splits + blockIdx.y) * 16 + wave) * 16) * 256;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(w + ((mt * 4 + nt) * 64 + lane) * 4) = acc[mt][nt];
+    return;
+  }
   // plain bf16 epilogue (natural order is irrelevant for timing: 8 consecutive columns per lane)
   const int q = lane >> 4, i = lane & 15;
 #pragma unroll
@@ -150,6 +159,64 @@ __global__ __launch_bounds__(1024) void k(P p) {
       *reinterpret_cast<bf16x8*>(p.out + (long)m * p.ldo + n0 + wn * 64 + 32 * c + 8 * q) = o;
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void fixup(P p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int y = 0; y < p.splits; ++y) {
+    const float* w = p.ws + ((((long)blockIdx.x * p.splits + y) * 16 + wave) * 16) * 256;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += *reinterpret_cast<const f32x4*>(w + ((mt * 4 + nt) * 64 + lane) * 4);
+  }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (bf16)acc[mt][2 * c][e]; o[4 + e] = (bf16)acc[mt][2 * c + 1][e]; }
+      *reinterpret_cast<bf16x8*>(p.out + (long)m * p.ldo + n0 + wn * 64 + 32 * c + 8 * q) = o;
+    }
+  }
+}
+
+// main rows as full tiles (whole rounds of 256 CUs) + the ragged last round cut into `splits` K-ranges + fix-up
+float run_split(P p, int reps, int splits) {
+  const int T = p.tiles_m * p.tiles_n, full = T / 256;
+  const int tm_main = full * 256 / p.tiles_n;
+  P a = p; a.M = tm_main * 256; a.tiles_m = tm_main;
+  P b = p; b.A = p.A + (long)tm_main * 256 * p.lda; b.out = p.out + (long)tm_main * 256 * p.ldo; b.M = p.M - tm_main * 256;
+  b.tiles_m = p.tiles_m - tm_main; b.splits = splits;
+  const int nwa = 8 * ((a.tiles_m + 7) / 8) * a.tiles_n, nwb = 8 * ((b.tiles_m + 7) / 8) * b.tiles_n;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  auto once = [&]() {
+    hipLaunchKernelGGL(k<0>, dim3(nwa), dim3(1024), 0, 0, a);
+    hipLaunchKernelGGL(k<6>, dim3(nwb, splits), dim3(1024), 0, 0, b);
+    hipLaunchKernelGGL(fixup, dim3(b.tiles_m * b.tiles_n), dim3(1024), 0, 0, b);
+  };
+  for (int i = 0; i < 3; ++i) once();
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) once();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("   split: main %d tiles, tail %d tiles x %d -> ", a.tiles_m * a.tiles_n, b.tiles_m * b.tiles_n, splits);
+  return ms * 1e3f / reps;
 }
 
 template <int ABL>
@@ -181,13 +248,15 @@ int main() {
     hipMalloc(&A, ha.size() * 2); hipMalloc(&W, hw.size() * 2); hipMalloc(&O, (size_t)M * N * 2);
     hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-    P p{A, K, W, K, M, N, K, O, N, (M + 255) / 256, N / 256, 2};
+    float* WS; hipMalloc(&WS, (size_t)256 * 4 * 256 * 256 * 4);
+    P p{A, K, W, K, M, N, K, O, N, (M + 255) / 256, N / 256, 2, WS, 1};
     const double fl = 2.0 * M * N * K;
     const float t0 = run<0>(p, 20), t1 = run<1>(p, 20), t2 = run<2>(p, 20), t3 = run<3>(p, 20), t4 = run<4>(p, 20),
                 t5 = run<5>(p, 20);
     printf("N=%d K=%d  full %.1f us (%.0f TF/s) | no-DMA %.1f | no-LDS-read %.1f | no-MFMA %.1f | no-barrier %.1f | MFMA-only %.1f (%.0f TF/s)\n",
            N, K, t0, fl / t0 / 1e6, t1, t2, t3, t4, t5, fl / t5 / 1e6);
-    hipFree(A); hipFree(W); hipFree(O);
+    if (N == 768) { for (int sp = 2; sp <= 4; ++sp) { if ((K / 64) % sp) continue; const float ts = run_split(p, 20, sp); printf("%.1f us (full %.1f)\n", ts, t0); } }
+    hipFree(A); hipFree(W); hipFree(O); hipFree(WS);
   }
   return 0;
 }
