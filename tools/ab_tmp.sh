@@ -1,5 +1,14 @@
-export PVRL_DIST_BACKEND=gloo PVRL_SINGLE_DEVICE=1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 2 --batch 4 --no-cpu-baseline 2>&1 | grep -v "^W\|^\[W\|^$" | tail -3 | cut -c1-400
-unset PVRL_DIST_BACKEND PVRL_SINGLE_DEVICE
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-python tools/bench_full_step.py 2>&1 | tail -2 | cut -c1-300
+NC=$(nproc)
+echo "cores $NC"
+PIDS=""
+for i in $(seq 1 $((NC * 3))); do
+  python -c "while True: pass" &
+  PIDS="$PIDS $!"
+done
+sleep 2
+python bench.py --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('contended graphs   ', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+python bench.py --no-cpu-baseline --no-kernel-timing --no-graphs 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('contended no-graphs', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+kill $PIDS
+wait 2>/dev/null
+python bench.py --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('quiet graphs       ', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+python bench.py --no-cpu-baseline --no-kernel-timing --no-graphs 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('quiet no-graphs    ', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
