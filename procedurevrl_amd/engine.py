@@ -69,9 +69,172 @@ class _W:
         self.ver = -1
 
 
-class EncoderEngine:
-    _capturing = None     # "fwd" / "bwd" while a HIP graph of that pass is being captured (class default for subclasses)
+class GraphReplay:
+    """HIP-graph replay of an encoder engine's training / inference step.
 
+    One training step of the encoder is ~1,400 kernel launches (~7 ms of Python on an idle host, several times that
+    when the node's cores are contended -- measured up to 95 ms, more than the 57 ms the GPU needs).  The launch
+    sequence of a given (shape, mode) never changes, so it is captured once (torch.cuda.CUDAGraph = hipGraph; the
+    C ABI launches on the capturing stream like on any other) and replayed: forward and backward are one graph each
+    (backward: one per block when a data-parallel gradient hook is installed and the engine has staged backward),
+    sharing a memory pool so the activations saved by the forward graph are the backward graph's inputs.  What a
+    replay cannot express falls back to the eager path: pinned DropPath draws, DecodedClips inputs, gradient
+    accumulation into existing .grad tensors.
+
+    The engine provides: _eager_forward(frames, training, save), _eager_backward(dfeat), _graph_key(frames, training,
+    save), _enc_params() (the parameters whose gradients backward writes), `saved`, `grad_hook`, and consults
+    `self._capturing` ("fwd": refresh every weight copy inside the graph, "bwd": reuse them, and keep side-stream
+    operands alive until the join).  Optional: _bwd_begin / _bwd_block / _bwd_end + join_side_stream for staged capture.
+    """
+    GRAPH_WARMUP = 2      # eager calls of a key before it is captured (lazy workspaces / caches settle)
+    GRAPH_MAX_KEYS = 4    # captured (shape, mode) combinations kept; others run eagerly
+    _capturing = None     # "fwd" / "bwd" while a HIP graph of that pass is being captured
+
+    def _graph_init(self):
+        self.use_graphs = os.environ.get("PVRL_HIP_GRAPHS", "1") == "1"
+        self._capturing = None
+        self._graphs = {}
+        self._gpool = None
+        self._gkey = None
+        self._gseen = {}
+
+    def _graph_reset_host_state(self):
+        pass
+
+    @staticmethod
+    def _saved_copy(saved):
+        """backward() consumes its `saved` dict (frees block entries as it goes): replays hand it a shallow copy"""
+        sv = dict(saved)
+        sv["blocks"] = list(saved["blocks"])
+        return sv
+
+    def _graph_forward(self, frames, training, save):
+        key = self._graph_key(frames, training, save)
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._gseen.get(key, 0)
+            self._gseen[key] = n + 1
+            if n < self.GRAPH_WARMUP or len(self._graphs) >= self.GRAPH_MAX_KEYS:
+                self._gkey = None
+                return self._eager_forward(frames, training, save)
+            try:
+                g = self._capture_forward(key, frames, training, save)
+            except Exception as e:      # never fatal: the eager launch sequence is the same kernels
+                self._graph_failed("forward", e)
+                self._gkey = None
+                return self._eager_forward(frames, training, save)
+        g["frames"].copy_(frames)
+        g["fwd"].replay()
+        self.saved = g["saved"]
+        self._gkey = key if save else None
+        return g["feat"]
+
+    def _graph_failed(self, what, e):
+        import warnings
+        warnings.warn(f"HIP graph capture of the encoder {what} failed ({type(e).__name__}: {e}); continuing with eager "
+                      "launches")
+        self.use_graphs = False
+        self._capturing = None
+        self._graphs = {}
+        self._graph_reset_host_state()
+        torch.cuda.synchronize()
+
+    def _capture_forward(self, key, frames, training, save):
+        if self._gpool is None:
+            self._gpool = torch.cuda.graph_pool_handle()
+        st = torch.empty_like(frames)
+        st.copy_(frames)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = "fwd"
+        try:
+            with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                feat = self._eager_forward(st, training, save)
+        finally:
+            self._capturing = None
+        g = dict(fwd=graph, frames=st, feat=feat, saved=self.saved if save else None)
+        self._graphs[key] = g
+        return g
+
+    def _grads_fresh(self):
+        return all(p.grad is None for p in self._enc_params())
+
+    def _graph_backward(self, dfeat):
+        g = self._graphs[self._gkey]
+        staged_ok = hasattr(self, "_bwd_begin")
+        if not self._grads_fresh() or (self.grad_hook is not None and not staged_ok):
+            # accumulation into existing gradients (beta = 1 launches), or a hook this engine cannot stage: eager launches
+            self.saved = self._saved_copy(g["saved"])
+            self._gkey = None
+            return self._eager_backward(dfeat)
+        staged = self.grad_hook is not None             # cut the graph where the data-parallel reducer hooks in
+        nb = len(g["saved"]["blocks"])
+        slot = "bwd_staged" if staged else "bwd"
+        if g.get(slot) is None and not self._capture_backward(g, slot, staged, nb, dfeat):
+            self.saved = self._saved_copy(g["saved"])
+            self._gkey = None
+            return self._eager_backward(dfeat)
+        gb = g[slot]
+        gb["dfeat"].copy_(dfeat)
+        if not staged:
+            gb["graphs"][0].replay()
+        else:
+            for k, graph in enumerate(gb["graphs"]):
+                graph.replay()
+                self.grad_hook(nb - 1 - k)
+        for p, v in gb["touched"]:
+            p.grad = v
+        self.saved = None
+        self._gkey = None
+
+    def _capture_backward(self, g, slot, staged, nb, dfeat):
+        """-> True when g[slot] holds the captured graph(s); False after a failed capture (graphs are then switched off)"""
+        st_in = torch.empty_like(dfeat.contiguous())
+        st_in.copy_(dfeat)
+        torch.cuda.synchronize()
+        hook, self.grad_hook = self.grad_hook, None
+        params = self._enc_params()
+        graphs = []
+        self._capturing = "bwd"
+        err = None
+        try:
+            self.saved = self._saved_copy(g["saved"])
+            if not staged:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                    self._eager_backward(st_in)
+                graphs.append(graph)
+            else:
+                # one graph per block (the first also holds the final-norm stage, the last the embedding stage); a
+                # capture cannot end with side-stream work in flight, so each stage joins its weight gradients
+                state = None
+                for i in range(nb - 1, -1, -1):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
+                        if state is None:
+                            state = self._bwd_begin(st_in)
+                        self._bwd_block(state, i)
+                        if i == 0:
+                            self._bwd_end(state)
+                        else:
+                            self.join_side_stream()
+                    graphs.append(graph)
+        except Exception as e:          # never fatal: the eager launch sequence is the same kernels
+            err = e
+        finally:
+            self._capturing = None
+            self.grad_hook = hook
+        touched = [(p, p.grad) for p in params if p.grad is not None]     # all were None (_grads_fresh)
+        for p, _ in touched:            # capture ran no kernel: undo its host-side effect
+            p.grad = None
+        if err is not None:
+            self._graph_failed("backward", err)
+            return False
+        g[slot] = dict(graphs=graphs, dfeat=st_in, touched=touched)
+        return True
+
+
+class EncoderEngine(GraphReplay):
     def __init__(self, model):
         """`model` is a procedurevrl_amd.vit.VisionTransformer (same parameter names as the reference)."""
         self.m = model
@@ -89,12 +252,7 @@ class EncoderEngine:
         self._wq = []
         self._side_keep = []
         self._keep = None
-        self.use_graphs = os.environ.get("PVRL_HIP_GRAPHS", "1") == "1"   # see _graph_forward
-        self._capturing = None
-        self._graphs = {}
-        self._gpool = None
-        self._gkey = None
-        self._gseen = {}
+        self._graph_init()            # HIP-graph replay of the step (GraphReplay)
         assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
 
     # ------------------------------------------------------------------ weights
@@ -308,17 +466,12 @@ class EncoderEngine:
                                      lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp))
         return x3
 
-    # ------------------------------------------------------------------ HIP graphs
-    # One training step of the encoder is ~1,400 kernel launches (~7 ms of Python on an idle host, several times that
-    # when the node's cores are contended -- measured up to 95 ms, more than the 57 ms the GPU needs).  The launch
-    # sequence of a given (shape, mode) never changes, so it is captured once (torch.cuda.CUDAGraph = hipGraph; the
-    # C ABI launches on the capturing stream like on any other) and replayed: forward and backward are one graph each,
-    # sharing a memory pool so the activations saved by the forward graph are the backward graph's inputs.  What a
-    # replay cannot express falls back to the eager path: pinned DropPath draws, DecodedClips inputs, gradient
-    # accumulation into existing .grad tensors.
-    GRAPH_WARMUP = 2      # eager calls of a key before it is captured (lazy workspaces / caches settle)
+    # ------------------------------------------------------------------ HIP graphs (GraphReplay)
+    def _eager_forward(self, frames, training, save):
+        return self._forward(frames, training, None, save)
 
-    GRAPH_MAX_KEYS = 4    # captured (shape, mode) combinations kept; others run eagerly
+    def _eager_backward(self, dfeat):
+        return self._backward(dfeat)
 
     def _graph_key(self, frames, training, save):
         m = self.m
@@ -326,57 +479,9 @@ class EncoderEngine:
         return (tuple(frames.shape), bool(training), bool(save), frames.device.index, tuple(m.drop_path_rates),
                 m.blocks[0].attn.qkv.weight.data_ptr(), m.norm.weight.data_ptr(), self.grad_store().flat.data_ptr())
 
-    def _graph_forward(self, frames, training, save):
-        key = self._graph_key(frames, training, save)
-        g = self._graphs.get(key)
-        if g is None:
-            n = self._gseen.get(key, 0)
-            self._gseen[key] = n + 1
-            if n < self.GRAPH_WARMUP or len(self._graphs) >= self.GRAPH_MAX_KEYS:
-                self._gkey = None
-                return self._forward(frames, training, None, save)
-            try:
-                g = self._capture_forward(key, frames, training, save)
-            except Exception as e:      # never fatal: the eager launch sequence is the same kernels
-                self._graph_failed("forward", e)
-                self._gkey = None
-                return self._forward(frames, training, None, save)
-        g["frames"].copy_(frames)
-        g["fwd"].replay()
-        self.saved = g["saved"]
-        self._gkey = key if save else None
-        return g["feat"]
-
-    def _graph_failed(self, what, e):
-        import warnings
-        warnings.warn(f"HIP graph capture of the encoder {what} failed ({type(e).__name__}: {e}); continuing with eager "
-                      "launches")
-        self.use_graphs = False
-        self._capturing = None
-        self._graphs = {}
+    def _graph_reset_host_state(self):
         self._wq = []
         self._side_keep = []
-        torch.cuda.synchronize()
-
-    def _capture_forward(self, key, frames, training, save):
-        if self._gpool is None:
-            self._gpool = torch.cuda.graph_pool_handle()
-        st = torch.empty_like(frames)
-        st.copy_(frames)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        self._capturing = "fwd"
-        try:
-            with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
-                feat = self._forward(st, training, None, save)
-        finally:
-            self._capturing = None
-        g = dict(fwd=graph, frames=st, feat=feat, saved=self.saved if save else None)
-        self._graphs[key] = g
-        return g
-
-    def _grads_fresh(self):
-        return all(p.grad is None for p in self._enc_params())
 
     def _enc_params(self):
         """the parameters whose gradients backward() writes"""
@@ -385,78 +490,6 @@ class EncoderEngine:
         for blk in m.blocks:
             ps += list(blk.parameters())
         return [p for p in ps if p.requires_grad]
-
-    def _graph_backward(self, dfeat):
-        g = self._graphs[self._gkey]
-        if not self._grads_fresh():                     # accumulation into existing gradients: beta = 1 launches
-            self.saved = dict(g["saved"]); self.saved["blocks"] = list(g["saved"]["blocks"])
-            return self._backward(dfeat)
-        staged = self.grad_hook is not None             # cut the graph where the data-parallel reducer hooks in
-        nb = len(self.m.blocks)
-        slot = "bwd_staged" if staged else "bwd"
-        if g.get(slot) is None and not self._capture_backward(g, slot, staged, nb, dfeat):
-            self.saved = dict(g["saved"]); self.saved["blocks"] = list(g["saved"]["blocks"])
-            self._gkey = None
-            return self._backward(dfeat)
-        gb = g[slot]
-        gb["dfeat"].copy_(dfeat)
-        if not staged:
-            gb["graphs"][0].replay()
-        else:
-            for k, graph in enumerate(gb["graphs"]):
-                graph.replay()
-                self.grad_hook(nb - 1 - k)
-        for p, v in gb["touched"]:
-            p.grad = v
-        self.saved = None
-        self._gkey = None
-
-    def _capture_backward(self, g, slot, staged, nb, dfeat):
-        """-> True when g[slot] holds the captured graph(s); False after a failed capture (graphs are then switched off)"""
-        st_in = torch.empty_like(dfeat.contiguous())
-        st_in.copy_(dfeat)
-        torch.cuda.synchronize()
-        hook, self.grad_hook = self.grad_hook, None
-        gs = self.grad_store()
-        before = {id(p) for p in gs.params if p.grad is not None}
-        graphs = []
-        self._capturing = "bwd"
-        err = None
-        try:
-            self.saved = g["saved"]
-            if not staged:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
-                    self._backward(st_in)
-                graphs.append(graph)
-            else:
-                # one graph per block (the first also holds the final-norm stage, the last the embedding stage); a
-                # capture cannot end with side-stream work in flight, so each stage joins its weight gradients
-                state = None
-                for i in range(nb - 1, -1, -1):
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
-                        if state is None:
-                            state = self._bwd_begin(st_in)
-                        self._bwd_block(state, i)
-                        if i == 0:
-                            self._bwd_end(state)
-                        else:
-                            self.join_side_stream()
-                    graphs.append(graph)
-        except Exception as e:          # never fatal: the eager launch sequence is the same kernels
-            err = e
-        finally:
-            self._capturing = None
-            self.grad_hook = hook
-        touched = [(p, p.grad) for p in gs.params if p.grad is not None and id(p) not in before]
-        for p, _ in touched:            # capture ran no kernel: undo its host-side effect
-            p.grad = None
-        if err is not None:
-            self._graph_failed("backward", err)
-            return False
-        g[slot] = dict(graphs=graphs, dfeat=st_in, touched=touched)
-        return True
 
     # ------------------------------------------------------------------ backward
     def backward(self, dfeat):
@@ -480,9 +513,6 @@ class EncoderEngine:
         m = self.m
         sv = self.saved
         assert sv is not None, "backward() without a saved forward()"
-        if self._capturing:          # the captured forward's activations are reused by every replay: work on a copy
-            sv = dict(sv)
-            sv["blocks"] = list(sv["blocks"])
         gs = self.grad_store()
         R, M = sv["R"], sv["M"]
         dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)

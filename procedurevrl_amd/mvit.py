@@ -20,7 +20,7 @@ from . import ops
 from . import ops_mvit as om
 from ._lib import lib
 from .build import MODEL_REGISTRY
-from .engine import EncoderEngine, GradStore
+from .engine import EncoderEngine, GradStore, GraphReplay
 from .vit import VisionTransformer as _StepMatchingModel, trunc_normal_
 
 BF16 = torch.bfloat16
@@ -214,12 +214,13 @@ class _PW:
     __slots__ = ("w", "t", "b", "ver", "N", "K")
 
 
-class MViTEngine:
+class MViTEngine(GraphReplay):
     """Kernel schedule of MViT_encoder.forward (slowfast_mvit/mvit.py:346-407) and its hand-written backward.
-    Token matrices are fp32 [B*L + B, pad128(C)]: patch tokens (b, t, h, w) first, the B cls tokens last."""
+    Token matrices are fp32 [B*L + B, pad128(C)]: patch tokens (b, t, h, w) first, the B cls tokens last.
+    The ~3,000 launches of a step are replayed from HIP graphs (engine.GraphReplay; backward unstaged: with a
+    data-parallel gradient hook installed the backward is launched eagerly)."""
 
     _weight = EncoderEngine._weight      # un-padded bf16 copies for the width-512 stacks (order transformer, text tower)
-    _capturing = None                    # (EncoderEngine._weight consults it; this engine never captures HIP graphs)
 
     def __init__(self, owner, enc):
         self.m = owner                   # the wrapper (weights_epoch, grad_target)
@@ -229,13 +230,43 @@ class MViTEngine:
         self._idx = {}
         self.saved = None
         self.grad_hook = None
+        self._graph_init()
+
+    # -------------------------------------------------------------- HIP graphs (engine.GraphReplay)
+    def _eager_forward(self, frames, training, save):
+        return self._forward(frames, training, save, None)
+
+    def _eager_backward(self, dfeat):
+        return self._backward(dfeat)
+
+    def _graph_key(self, frames, training, save):
+        enc = self.enc
+        return (tuple(frames.shape), bool(training), bool(save), frames.device.index, tuple(enc.drop_path_rates),
+                enc.blocks[0].attn.qkv.weight.data_ptr(), enc.norm.weight.data_ptr(), self.m.grad_store().flat.data_ptr())
+
+    def _enc_params(self):
+        return [p for p in self.enc.parameters() if p.requires_grad]
+
+    def forward(self, frames, training, save=True, droppath=None):
+        if self.use_graphs and droppath is None and isinstance(frames, torch.Tensor) and frames.is_cuda:
+            return self._graph_forward(frames, training, save)
+        self._gkey = None
+        return self._forward(frames, training, save, droppath)
+
+    def backward(self, dfeat):
+        if self._gkey is not None:
+            return self._graph_backward(dfeat)
+        return self._backward(dfeat)
 
     # -------------------------------------------------------------- weights
     def _wpad(self, weight, bias=None, Np=None, Kp=None):
         e = self._pw.get(id(weight))
         ver = (weight._version, bias._version if bias is not None else -1, getattr(self.m, "weights_epoch", 0),
                weight.data_ptr())
-        if e is None or e.ver != ver or e.w.device != weight.device:
+        if self._capturing == "bwd":      # the forward graph of the same step refreshed the padded copies
+            assert e is not None
+            return e
+        if self._capturing == "fwd" or e is None or e.ver != ver or e.w.device != weight.device:
             w2 = weight.detach().reshape(weight.shape[0], -1).contiguous()
             N, K = w2.shape
             Np = om.pad128(N) if Np is None else Np
@@ -294,7 +325,7 @@ class MViTEngine:
                 out.append(tuple(torch.floor(keep + torch.rand(B, device=device)) / keep for _ in range(2)))
         return out
 
-    def forward(self, frames, training, save=True, droppath=None):
+    def _forward(self, frames, training, save=True, droppath=None):
         L = lib()
         enc = self.enc
         mv = enc.cfg.MVIT
@@ -375,7 +406,7 @@ class MViTEngine:
         return x2
 
     # -------------------------------------------------------------- backward
-    def backward(self, dfeat):
+    def _backward(self, dfeat):
         L = lib()
         enc = self.enc
         sv = self.saved

@@ -394,6 +394,42 @@ def check_mvit_pretrain_steps():
             ("mvit pretraining: loss after 5 steps / first loss", losses[-1] / losses[0], 0.999)]
 
 
+def check_mvit_hip_graph_replay():
+    """MViT encoder step replayed from HIP graphs (engine.GraphReplay) vs the eager launches of the same kernels.  The
+    MViT backward still accumulates a few parameter gradients with fp32 atomics (LayerNorm, max-pool scatter), so the
+    comparison is to a tolerance of accumulation-order noise, not bit-exact; features are bit-identical."""
+    from procedurevrl_amd.build import build_model
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    g = _load("mvit_small")
+    cfg = _mvit_cfg(g["mvit"], 4, 64, K=128)
+    cfg.TRAIN.LABEL_EMB = synthetic_label_emb(128, 512, seed=1)
+    torch.manual_seed(0)
+    model = build_model(cfg, gpu_id=0).train()
+    eng = model.model.engine
+    gen = torch.Generator().manual_seed(6)
+    xs = [torch.randn(3, 3, 4, 64, 64, generator=gen).to(DEV) for _ in range(2)]
+    teacher = (torch.randn(3, 128, generator=gen) * 3).to(DEV)
+
+    def step(x):
+        model.zero_grad(set_to_none=True)
+        pred = model(x)
+        kl_topk_loss(pred, teacher, 5).backward()
+        return pred.detach().clone(), model.model.adopt_grads().flat.clone()
+
+    eng.use_graphs = False
+    ref = [step(x) for x in xs]
+    eng.use_graphs = True
+    for _ in range(eng.GRAPH_WARMUP + 1):
+        step(xs[0])
+    out = [("mvit graphs were captured (0 = yes)", 0.0 if len(eng._graphs) == 1 else 1.0, 0.5)]
+    for i in (1, 0):
+        pred, grads = step(xs[i])
+        out.append((f"mvit graph replay, input {i}: logits differ (count)", float((pred != ref[i][0]).sum()), 0.0))
+        out.append((f"mvit graph replay, input {i}: gradients vs eager", rel(grads, ref[i][1]), 1e-4))
+    return out
+
+
 def check_mvit_s_full_size_step_vs_oracle():
     """MViTv2-S at BASELINE config-5 size (16 x 224^2, 16 blocks): one clip's features AND parameter gradients of the HIP
     path against the CPU oracle (pinned to the reference by the golden tests) -- the 25,089-query / 1,569-key attention
@@ -426,4 +462,4 @@ def check_mvit_s_full_size_step_vs_oracle():
     return out
 
 
-ALL_CHECKS = [check_mvit_s_full_size_step_vs_oracle, check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
+ALL_CHECKS = [check_mvit_s_full_size_step_vs_oracle, check_mvit_hip_graph_replay, check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]
