@@ -460,6 +460,13 @@ __global__ __launch_bounds__(256) void pool_wgrad_reduce_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------- max-pool skip
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(p)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
 struct MaxPoolGeom {
   int B, T, H, W, k, s, Ho, Wo, C;   // kernel (1,k,k), stride (1,s,s), padding (0,k/2,k/2)
   long ldi, ldo;
@@ -823,7 +830,10 @@ extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* d
                                      int64_t H, int64_t W, int64_t s, int64_t C, float* dx, void* stream) {
   MaxPoolGeom g;
   if (!x || !dy || !dx || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
-  if (hipMemsetAsync(dx, 0, (size_t)B * T * H * W * ldi * sizeof(float), (hipStream_t)stream) != hipSuccess) return PVRL_EHIP;
+  // zero dx with a kernel, not hipMemsetAsync: the memset node of a captured HIP graph did not re-zero the buffer on
+  // replay (ROCm 7.2: gradients accumulated across replays until they overflowed), a kernel node does
+  const long nz = (long)B * T * H * W * ldi;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(grid_for((nz + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dx, nz);
   const long total = ((long)B * T * g.Ho * g.Wo + B) * C;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx);
   PVRL_LAUNCH_CHECK();

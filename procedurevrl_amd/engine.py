@@ -261,7 +261,9 @@ class EncoderEngine(GraphReplay):
         if e is None:
             e = _W()
             self._w[id(p)] = e
-        ver = (p._version, getattr(self.m, "weights_epoch", 0), p.data_ptr())
+        # the fused optimiser updates trainable parameters through its flat buffer (no _version bump) and advances
+        # weights_epoch instead; frozen parameters (text tower) only change through versioned in-place copies
+        ver = (p._version, getattr(self.m, "weights_epoch", 0) if p.requires_grad else 0, p.data_ptr())
         if self._capturing == "bwd":      # the forward graph of the same step refreshed the copies
             assert e.w is not None and (e.t is not None or not need_t)
             return e

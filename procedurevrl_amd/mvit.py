@@ -429,7 +429,8 @@ class MViTEngine(GraphReplay):
         # patch embed (weight gradient only: the input needs none) and cls token
         e0 = enc.plan[0]["dim"]
         R = dx.shape[0] - B
-        wpe = self._wpad(enc.patch_embed.proj.weight, enc.patch_embed.proj.bias)
+        pw = enc.patch_embed.proj.weight      # same padded shape as the forward asked for (one cache entry, not two that evict each other)
+        wpe = self._wpad(pw, enc.patch_embed.proj.bias, Np=om.pad128(e0), Kp=512 * ((pw[0].numel() + 511) // 512))
         dxb = ops.cast_scale(dx[:R])
         self._wgrad(dxb, sv["a_pe"], enc.patch_embed.proj.weight, enc.patch_embed.proj.bias, wpe)
         gc, bc = self._grad(enc.cls_token)

@@ -118,10 +118,16 @@ def gemm_nt_f32(A, B, bias=None, alpha=1.0, out=None):
 _ws_cache = {}
 
 
+_ws_retired = []     # outgrown workspaces stay allocated: a captured HIP graph may have their address baked in
+
+
 def workspace(nbytes, device, tag="default"):
     key = (tag, str(device))
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            _ws_retired.append(w)
+            nbytes = max(int(nbytes), w.numel() * 3 // 2)      # geometric growth bounds what is retired
         w = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
         _ws_cache[key] = w
     return w

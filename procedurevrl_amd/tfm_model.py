@@ -9,6 +9,7 @@ attention kernels).  Every random draw of the reference forward (`mask_inds` :14
 them.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -221,13 +222,47 @@ class ClipTextModel(nn.Module):
             nn.init.normal_(block.mlp.c_fc.weight, std=(2 * width) ** -0.5)
             nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
         nn.init.normal_(self.text_projection, std=width ** -0.5)
+        self.use_graphs = os.environ.get("PVRL_HIP_GRAPHS", "1") == "1"
+        self._graphs, self._gseen = {}, {}
 
     def bind(self, owner):
         self._owner = [owner]
 
     @torch.no_grad()
     def encode_text(self, text):
-        """text int64 [n, 77] -> fp32 [n, embed_dim]; frozen, forward only."""
+        """text int64 [n, 77] -> fp32 [n, embed_dim]; frozen, forward only.  The ~110 launches of the tower are replayed
+        from a HIP graph after two eager calls of a shape (same switch as the encoder: PVRL_HIP_GRAPHS=0 disables)."""
+        if not (text.is_cuda and self.use_graphs):
+            return self._encode_text(text)
+        blk0 = self.transformer.resblocks[0]
+        key = (tuple(text.shape), text.dtype, text.device.index, self.text_projection.data_ptr(),
+               self.token_embedding.weight.data_ptr(), self.text_projection._version, blk0.attn.in_proj_weight._version,
+               blk0.mlp.c_fc.weight._version)      # a checkpoint load (in-place copy) is a new key
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._gseen.get(key, 0)
+            self._gseen[key] = n + 1
+            if n < 2 or len(self._graphs) >= 4:
+                return self._encode_text(text)
+            try:
+                st = text.clone()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = self._encode_text(st)
+                g = self._graphs[key] = (graph, st, out)
+            except Exception as e:          # never fatal: the eager launches are the same kernels
+                import warnings
+                warnings.warn(f"HIP graph capture of the text tower failed ({type(e).__name__}: {e}); launching eagerly")
+                self.use_graphs = False
+                torch.cuda.synchronize()
+                return self._encode_text(text)
+        graph, st, out = g
+        st.copy_(text)
+        graph.replay()
+        return out.clone()
+
+    def _encode_text(self, text):
         from .tfm_engine import StackEngine
         own = self._owner[0]
         n, S = text.shape
