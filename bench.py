@@ -273,7 +273,7 @@ def cpu_baseline(args):
     timed on this host's cores on a bounded sample: the checker timed as a baseline, never the product."""
     import torch
     from oracle import timesformer_oracle as orc
-    return orc.timed_train_step(clips=2, frames=args.frames, classes=args.classes, threads=16)
+    return orc.timed_train_step(clips=max(1, 32 // args.frames), frames=args.frames, classes=args.classes, threads=16, repeats=3)
 
 
 if __name__ == "__main__":
