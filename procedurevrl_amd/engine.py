@@ -127,7 +127,7 @@ class GraphReplay:
         g["fwd"].replay()
         self.saved = g["saved"]
         self._gkey = key if save else None
-        return g["feat"]
+        return g["feat"].clone()        # the graph's own output buffer is overwritten by the next replay
 
     def _graph_failed(self, what, e):
         import warnings
@@ -478,7 +478,7 @@ class EncoderEngine(GraphReplay):
     def _graph_key(self, frames, training, save):
         m = self.m
         # parameter / gradient storage is baked into a graph: a re-homed parameter (optimizer flat buffer, .to()) is a new key
-        return (tuple(frames.shape), bool(training), bool(save), frames.device.index, tuple(m.drop_path_rates),
+        return (tuple(frames.shape), frames.dtype, bool(training), bool(save), frames.device.index, tuple(m.drop_path_rates),
                 m.blocks[0].attn.qkv.weight.data_ptr(), m.norm.weight.data_ptr(), self.grad_store().flat.data_ptr())
 
     def _graph_reset_host_state(self):

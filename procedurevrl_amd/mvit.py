@@ -241,7 +241,7 @@ class MViTEngine(GraphReplay):
 
     def _graph_key(self, frames, training, save):
         enc = self.enc
-        return (tuple(frames.shape), bool(training), bool(save), frames.device.index, tuple(enc.drop_path_rates),
+        return (tuple(frames.shape), frames.dtype, bool(training), bool(save), frames.device.index, tuple(enc.drop_path_rates),
                 enc.blocks[0].attn.qkv.weight.data_ptr(), enc.norm.weight.data_ptr(), self.m.grad_store().flat.data_ptr())
 
     def _enc_params(self):
