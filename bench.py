@@ -217,7 +217,8 @@ def main():
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "loss": float(loss.item()), "hip_graphs": bool(graphs), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
+            "loss": float(loss.item()), "hip_graphs": bool(graphs), "hbm_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
+            "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
             "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),
                            "frac_of_bf16_peak": round(value / world * wtrain / 2.5e15, 4),
                            "w_train_gflop_per_clip": round(wtrain / 1e9, 2)},
