@@ -254,6 +254,15 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float*
 
 /* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
  * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */
+/* pvrl_cast_weight_bf16 for many weight matrices in one launch (the bf16 operand copies of every nn.Linear of the
+ * encoder after an optimiser step): out [R][C] and, when out_t is not null, out_t [C][R], both dense. */
+typedef struct pvrl_cast_problem {
+  const float* in;   /* fp32 [R][C] */
+  void* out;         /* bf16 [R][C] */
+  void* out_t;       /* bf16 [C][R] or null */
+  int64_t R, C;
+} pvrl_cast_problem;
+int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* problems, void* stream);
 int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R, int64_t C,
                               void* stream);
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so")
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
-    "const pvrl_tn_problem*": ctypes.c_void_p,
+    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -51,6 +51,12 @@ class TnProblem(ctypes.Structure):
     _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_int64), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
                 ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("beta", ctypes.c_float),
                 ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
+
+
+class CastProblem(ctypes.Structure):
+    """`pvrl_cast_problem` of include/pvrl.h"""
+    _fields_ = [("inp", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_t", ctypes.c_void_p), ("R", ctypes.c_int64),
+                ("C", ctypes.c_int64)]
 
 
 class PvrlError(RuntimeError):

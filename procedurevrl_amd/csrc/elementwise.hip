@@ -220,6 +220,38 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
   }
 }
 
+// The same for up to 96 weight matrices in ONE launch (a ViT-B encoder has 85: one 6-us launch each otherwise).
+constexpr int CAST_MULTI_MAX = 96;
+struct CastItem { const float* in; bf16* out; bf16* out_t; int R, C, first, tiles_c; };
+struct CastMulti { int n; CastItem it[CAST_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void cast_weight_multi_kernel(CastMulti g) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = g.n - 1;                       // last item whose first block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= g.it[mid].first) lo = mid; else hi = mid - 1;
+  }
+  const CastItem w = g.it[lo];
+  const int b = (int)blockIdx.x - w.first;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (b % w.tiles_c) * 32, r0 = (b / w.tiles_c) * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    const float v = (r < w.R && c < w.C) ? w.in[(long)r * w.C + c] : 0.f;
+    tile[ty + 8 * k][tx] = v;
+    if (r < w.R && c < w.C) w.out[(long)r * w.C + c] = (bf16)v;
+  }
+  __syncthreads();
+  if (w.out_t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, r = r0 + tx;
+      if (r < w.R && c < w.C) w.out_t[(long)c * w.R + r] = (bf16)tile[tx][ty + 8 * k];
+    }
+  }
+}
+
 // out[g][c] = resid[g][c] + alpha * sum_t scale[g*G + t] * in[g*G + t][c]
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict__ in, long ldi, int groups, int G, int C,
@@ -343,6 +375,26 @@ extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, in
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
                      (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)C, (long)R);
   PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* problems, void* stream) {
+  if (n < 0 || (n > 0 && !problems)) return PVRL_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += CAST_MULTI_MAX) {
+    CastMulti g = {};
+    g.n = n - i0 < CAST_MULTI_MAX ? n - i0 : CAST_MULTI_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const pvrl_cast_problem& q = problems[i0 + i];
+      if (!q.in || !q.out || q.R <= 0 || q.C <= 0) return PVRL_EINVAL;
+      CastItem& w = g.it[i];
+      w.in = q.in; w.out = (bf16*)q.out; w.out_t = (bf16*)q.out_t; w.R = (int)q.R; w.C = (int)q.C;
+      w.first = blocks; w.tiles_c = (int)cdiv(q.C, 32);
+      blocks += w.tiles_c * (int)cdiv(q.R, 32);
+    }
+    hipLaunchKernelGGL(cast_weight_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    PVRL_LAUNCH_CHECK();
+  }
   return PVRL_OK;
 }
 

@@ -1072,6 +1072,43 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
+// the same for every problem of a grouped launch in ONE kernel (seven 10-us launches per transformer block otherwise)
+constexpr int TN_RED_MAX = 8;
+struct TnReduceGroup {
+  int nprob, splits;
+  int first[TN_RED_MAX + 1];                 // first block of each problem
+  const float* part[TN_RED_MAX]; const float* cpart[TN_RED_MAX];
+  float* out[TN_RED_MAX]; float* bias_out[TN_RED_MAX];
+  long NK[TN_RED_MAX]; int N[TN_RED_MAX]; float beta[TN_RED_MAX];
+};
+__global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnReduceGroup g) {
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < TN_RED_MAX; ++t)
+    if (t < g.nprob && (int)blockIdx.x >= g.first[t]) q = t;
+  const float* __restrict__ part = g.part[q];
+  const float* __restrict__ cpart = g.cpart[q];
+  float* __restrict__ out = g.out[q];
+  float* __restrict__ bias_out = g.bias_out[q];
+  const long NK = g.NK[q];
+  const int N = g.N[q];
+  const float beta = g.beta[q];
+  const long idx4 = (long)((int)blockIdx.x - g.first[q]) * 256 + threadIdx.x;
+  const long n4 = NK >> 2;
+  if (idx4 < n4) {
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[idx4];
+    for (int s = 1; s < g.splits; ++s) a += reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
+    if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
+    reinterpret_cast<f32x4*>(out)[idx4] = a;
+  } else if (bias_out && idx4 - n4 < N) {
+    const int n = (int)(idx4 - n4);
+    float a = 0.f;
+    for (int s = 0; s < g.splits; ++s) a += cpart[(long)s * N + n];
+    if (beta != 0.f) a += beta * bias_out[n];
+    bias_out[n] = a;
+  }
+}
+
 // 0 = heuristic (register-transposed 256x256 kernel when N and K are multiples of 256, else 128x128 register-staged),
 // 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 / 16 waves, 4 = 256x256 / 8 waves,
 // 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed with 16x16x32 MFMAs, 7 = the same with 32x32x16 MFMAs
@@ -1248,13 +1285,19 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
   g.per_xcd = cdiv(first, 8);
   hipLaunchKernelGGL(gemm_tn_rt32_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(256), 0, s, g);
   PVRL_LAUNCH_CHECK();
+  static_assert(TN_RED_MAX >= TN_GROUP_MAX, "reduce table too small");
+  TnReduceGroup r = {};
+  r.nprob = nprob; r.splits = (int)splits;
+  int blocks = 0;
   for (int i = 0; i < nprob; ++i) {
     const pvrl_tn_problem& q = problems[i];
-    const long NK = q.N * q.K;
-    const long nthreads = (NK >> 2) + (q.dbias ? q.N : 0);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, g.prob[i].part,
-                       g.prob[i].cpart, (int)splits, NK, (int)q.N, q.beta, q.dW, q.dbias);
-    PVRL_LAUNCH_CHECK();
+    r.part[i] = g.prob[i].part; r.cpart[i] = g.prob[i].cpart; r.out[i] = q.dW; r.bias_out[i] = q.dbias;
+    r.NK[i] = q.N * q.K; r.N[i] = (int)q.N; r.beta[i] = q.beta;
+    r.first[i] = blocks;
+    blocks += (int)cdiv((r.NK[i] >> 2) + (q.dbias ? q.N : 0), 256);
   }
+  r.first[nprob] = blocks;
+  hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, r);
+  PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

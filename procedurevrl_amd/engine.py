@@ -89,6 +89,7 @@ class GraphReplay:
     GRAPH_WARMUP = 2      # eager calls of a key before it is captured (lazy workspaces / caches settle)
     GRAPH_MAX_KEYS = 4    # captured (shape, mode) combinations kept; others run eagerly
     _capturing = None     # "fwd" / "bwd" while a HIP graph of that pass is being captured
+    _refreshed = False    # EncoderEngine: every weight copy was just rebuilt by _refresh_weights()
 
     def _graph_init(self):
         self.use_graphs = os.environ.get("PVRL_HIP_GRAPHS", "1") == "1"
@@ -253,6 +254,7 @@ class EncoderEngine(GraphReplay):
         self._side_keep = []
         self._keep = None
         self._graph_init()            # HIP-graph replay of the step (GraphReplay)
+        self._refreshed = False
         assert self.C == 768 and self.C // self.H == 64, "kernels are built for ViT-B (C=768, head_dim=64)"
 
     # ------------------------------------------------------------------ weights
@@ -267,7 +269,7 @@ class EncoderEngine(GraphReplay):
         if self._capturing == "bwd":      # the forward graph of the same step refreshed the copies
             assert e.w is not None and (e.t is not None or not need_t)
             return e
-        if self._capturing == "fwd" or e.ver != ver or e.w is None or e.w.device != p.device:
+        if (self._capturing == "fwd" and not self._refreshed) or e.ver != ver or e.w is None or e.w.device != p.device:
             w2 = p.detach().reshape(p.shape[0], -1).contiguous()
             same = e.w is not None and e.w.device == p.device
             e.w, t = ops.cast_weight(w2, out=e.w if same else None, out_t=e.t if same else None, need_t=need_t)
@@ -275,6 +277,40 @@ class EncoderEngine(GraphReplay):
                 e.t = t
             e.ver = ver
         return e
+
+    def _refresh_weights(self):
+        """Bring the bf16 operand copies of every encoder weight up to date in ONE launch (pvrl_cast_weights_multi_bf16)
+        instead of one 6-us launch per matrix on first use; afterwards _weight() finds every version current."""
+        m = self.m
+        todo = []
+        plist = [(m.patch_embed.proj.weight, False)]
+        for blk in m.blocks:
+            plist += [(blk.temporal_attn.qkv.weight, True), (blk.temporal_attn.proj.weight, True),
+                      (blk.temporal_fc.weight, True), (blk.attn.qkv.weight, True), (blk.attn.proj.weight, True),
+                      (blk.mlp.fc1.weight, True), (blk.mlp.fc2.weight, True)]
+        epoch = getattr(m, "weights_epoch", 0)
+        for p, need_t in plist:
+            e = self._w.get(id(p))
+            if e is None:
+                e = _W()
+                self._w[id(p)] = e
+            ver = (p._version, epoch if p.requires_grad else 0, p.data_ptr())
+            fresh = e.ver == ver and e.w is not None and e.w.device == p.device and (e.t is not None or not need_t)
+            if fresh and self._capturing != "fwd":
+                continue
+            w2 = p.detach().reshape(p.shape[0], -1)
+            if not w2.is_contiguous():
+                continue                       # left to _weight()
+            if e.w is None or e.w.device != p.device:
+                e.w = torch.empty(w2.shape, device=p.device, dtype=BF16)
+                e.t = None
+            if need_t and e.t is None:
+                e.t = torch.empty((w2.shape[1], w2.shape[0]), device=p.device, dtype=BF16)
+            todo.append((w2, e.w, e.t if need_t else None, e, ver))
+        if todo:
+            ops.cast_weights_multi([(w2, w, t) for w2, w, t, _, _ in todo])
+            for _, _, _, e, ver in todo:
+                e.ver = ver
 
     def grad_store(self):
         return self.m.grad_store()
@@ -383,6 +419,8 @@ class EncoderEngine(GraphReplay):
     def _forward(self, frames, training, droppath=None, save=True):
         L = lib()
         m = self.m
+        self._refresh_weights()
+        self._refreshed = True
         B, _, T, HI, WI = frames.shape
         Wp = WI // 16
         N = (HI // 16) * Wp
@@ -411,6 +449,7 @@ class EncoderEngine(GraphReplay):
 
         feat, mean, rstd = ops.layernorm_fwd(x[R:], m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
                                              out_dtype=F32)
+        self._refreshed = False
         if save:
             sv["x_final"] = x
             sv["norm_stats"] = (mean, rstd)

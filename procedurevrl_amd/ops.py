@@ -388,6 +388,20 @@ def cast_weight(w, out=None, out_t=None, need_t=True):
     return out, (out_t if need_t else None)
 
 
+def cast_weights_multi(items):
+    """items: list of (w fp32 [R, C] contiguous, out bf16 [R, C], out_t bf16 [C, R] or None) -- one launch for all."""
+    from ._lib import CastProblem
+    if not items:
+        return
+    arr = (CastProblem * len(items))()
+    for a, (w, out, out_t) in zip(arr, items):
+        assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous() and out.is_contiguous() and out.dtype == BF16
+        assert out_t is None or (out_t.is_contiguous() and out_t.dtype == BF16)
+        a.inp, a.out, a.out_t = w.data_ptr(), out.data_ptr(), (None if out_t is None else out_t.data_ptr())
+        a.R, a.C = w.shape
+    lib().call("pvrl_cast_weights_multi_bf16", len(items), ctypes.addressof(arr), _stream())
+
+
 def group_reduce(x, groups, G, scale=None, alpha=1.0, resid=None, out=None, out_dtype=F32):
     L = lib()
     _chk2d(x)

@@ -230,6 +230,28 @@ def check_gemm_tn_grouped():
     return out
 
 
+def check_cast_weights_multi():
+    """pvrl_cast_weights_multi_bf16: many fp32 weight matrices -> bf16 copy + transposed copy in one launch (ragged
+    shapes, with and without the transposed copy, more than one launch worth of items)"""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(41)
+    shapes = [(768, 768), (2304, 768), (768, 588), (33, 65), (512, 2048), (1, 7)] * 17 + [(100, 31)]
+    items, refs = [], []
+    for k, (R, C) in enumerate(shapes):
+        w = torch.randn(R, C, generator=g)
+        out = torch.zeros(R, C, device=dev(), dtype=BF)
+        out_t = torch.zeros(C, R, device=dev(), dtype=BF) if k % 3 else None
+        items.append((w.to(dev()), out, out_t))
+        refs.append(w.to(BF))
+    ops.cast_weights_multi(items)
+    bad = 0
+    for (w, out, out_t), r in zip(items, refs):
+        bad += int(not torch.equal(out.cpu(), r))
+        if out_t is not None:
+            bad += int(not torch.equal(out_t.cpu(), r.t().contiguous()))
+    return [(f"cast_weights_multi: {len(shapes)} matrices, mismatching copies", float(bad), 0.0)]
+
+
 def check_layernorm():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(4)
@@ -524,5 +546,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_cast_weights_multi, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
