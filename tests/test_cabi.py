@@ -35,6 +35,28 @@ def test_pure_size_queries_run_without_a_gpu():
     assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 25 * 2 * 768 * 4
 
 
+def test_grouped_weight_gradient_plan_runs_without_a_gpu():
+    """pvrl_gemm_tn_grouped_plan_splits / _workspace_bytes are pure host functions: a transformer block's seven weight
+    gradients (153 tiles of 256x256) are cut into 5 row slices = 765 work items = 2.99 rounds of 256 CUs; shapes that are
+    not multiples of 256, an empty list and more than 8 problems are refused."""
+    import ctypes as C
+    L = _lib.lib()
+    M = 50208
+    dims = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (768, 768), (768, 768), (2304, 768)]
+    arr = (_lib.TnProblem * len(dims))()
+    for a, (N, K) in zip(arr, dims):
+        a.P, a.ldp, a.Q, a.ldq, a.M, a.N, a.K, a.beta, a.dW, a.dbias = 16, N, 16, K, M, N, K, 0.0, 16, None
+    ap = C.addressof(arr)
+    assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) == 5
+    want = sum(5 * (N * K + N) * 4 for N, K in dims)
+    assert L.call("pvrl_gemm_tn_grouped_workspace_bytes", len(dims), ap, 5) == want
+    arr[2].N = 640                                            # not a multiple of 256
+    assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) == -1
+    assert L.call("pvrl_gemm_tn_grouped_plan_splits", 0, ap) == -1
+    assert L.call("pvrl_gemm_tn_grouped_plan_splits", 9, ap) == -1
+    assert L.call("pvrl_mvit_pool_bwd_workspace_bytes") == 2048 * 27 * 96 * 4
+
+
 def test_product_path_fails_loudly_without_gpu():
     import pytest
     import torch

@@ -1,19 +1,7 @@
-timeout 900 python -m pytest tests/test_mvit_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2
-for g in 1 0; do
-PVRL_HIP_GRAPHS=$g python - <<'PY' 2>&1 | grep -v "^$\|UserWarning\|Consider\|not loading" | tail -5 | cut -c1-200
-import sys, os, torch
-sys.argv = ["bench_full_step.py", "--arch", "mvit", "--steps", "8", "--warmup", "4"]
-import procedurevrl_amd.vit as vit
-orig = vit.pretrain_loss
-n = [0]
-def pl(pred, teacher, mse, cfg):
-    r = orig(pred, teacher, mse, cfg)
-    n[0] += 1
-    if n[0] >= 10:
-        print("graphs", os.environ["PVRL_HIP_GRAPHS"], "step", n[0], "loss", float(r[0]))
-    return r
-vit.pretrain_loss = pl
-import runpy
-runpy.run_path("tools/bench_full_step.py", run_name="__main__")
-PY
+timeout 1200 python -m pytest tests/test_e2e_gpu.py tests/test_mvit_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -1
+rocm-smi --showmeminfo vram 2>/dev/null | grep -i "used" | head -2
+uptime
+for i in 1 2 3; do
+python bench.py --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('run', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"
+uptime | sed 's/.*load/load/'
 done
