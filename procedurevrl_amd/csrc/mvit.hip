@@ -106,14 +106,37 @@ __global__ __launch_bounds__(256) void ln_g_fwd_kernel(const float* __restrict__
   }
 }
 
+// out[j] += sum_b part[b][j]  (j < half -> out0[j], else out1[j - half]); fixed order: 16 outputs x 16 slices of the
+// block list per workgroup, slices combined through LDS.  Replaces same-address fp32 atomics (bit-reproducible).
+__global__ __launch_bounds__(256) void partials_add_kernel(const float* __restrict__ part, int nblk, int n,
+                                                           float* __restrict__ out0, float* __restrict__ out1, int half) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + o;
+  float a0 = 0.f, a1 = 0.f;
+  if (j < n) {
+    int b = sl;
+    for (; b + 16 < nblk; b += 32) { a0 += part[(long)b * n + j]; a1 += part[(long)(b + 16) * n + j]; }
+    if (b < nblk) a0 += part[(long)b * n + j];
+  }
+  red[sl][o] = a0 + a1;
+  __syncthreads();
+  if (sl == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    float* dst = j < half ? out0 + j : out1 + (j - half);
+    *dst += t;
+  }
+}
+
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gamma * dy ; dgamma += dy * xhat ; dbeta += dy
 template <typename TD>
 __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                        long ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ dres, long ldr, float* __restrict__ dx,
-                                                       long lddx, int C, int Cpad, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, long M) {
+                                                       long lddx, int C, int Cpad, float* __restrict__ part, long M) {
   __shared__ float red[2][4][64 * LNG_MAX / 4];   // reduced in four column quarters to stay small
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[LNG_MAX], ab[LNG_MAX];
@@ -167,8 +190,8 @@ __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy
         if (c < C) {
           const float a = red[0][0][jj * 64 + lane] + red[0][1][jj * 64 + lane] + red[0][2][jj * 64 + lane] + red[0][3][jj * 64 + lane];
           const float b = red[1][0][jj * 64 + lane] + red[1][1][jj * 64 + lane] + red[1][2][jj * 64 + lane] + red[1][3][jj * 64 + lane];
-          atomicAdd(dgamma + c, a);
-          atomicAdd(dbeta + c, b);
+          part[(long)blockIdx.x * 2 * C + c] = a;          // per-workgroup partials, summed by partials_add_kernel
+          part[(long)blockIdx.x * 2 * C + C + c] = b;
         }
       }
     }
@@ -275,7 +298,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ cbuf,
                                                           PoolGeom g, const float* __restrict__ gamma, float eps,
                                                           bf16* __restrict__ dc, bf16* __restrict__ dqkv,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ part) {
   __shared__ float red[2][16][HD];
   const int sub = threadIdx.x & 15, c0 = sub * 6, tl = threadIdx.x >> 4;
   const int Lo = g.To * g.Ho * g.Wo;
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict
     float a = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) a += red[which][t][c];
-    atomicAdd((which ? dbeta : dgamma) + c, a);
+    part[(long)blockIdx.x * 2 * HD + which * HD + c] = a;      // summed by partials_add_kernel (dgamma then dbeta)
   }
 }
 
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict_
 }
 
 // weight gradient of the depthwise conv: dW[c][tap] += sum_{b,h,out} dc[out][c] * x[in(out, tap)][c]
-// block = 8 token lanes x 24 channel quads (8-byte loads); each thread keeps 27 x 4 sums in registers.  The 27 neighbour
+// block = 8 token lanes x 24 channel quads (8-byte loads); each thread keeps 27 x 4 sums in registers (no atomics).  The 27 neighbour
 // loads of a token are unconditional (clamped address, 0/1 mask) so they are all in flight together.
 constexpr int PW_LANES = 8, PW_CQ = HD / 4;
 __device__ __forceinline__ f32x4 ld4bf(const bf16* p) {
@@ -424,11 +447,15 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16
     for (int t = 0; t < 27; ++t) acc[t] += d * xv[t];
   }
   __syncthreads();
+  for (int k = 0; k < PW_LANES; ++k) {      // the 8 token lanes add their sums one after the other: a fixed order
+    if (tl == k) {
 #pragma unroll
-  for (int t = 0; t < 27; ++t)
+      for (int t = 0; t < 27; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&red[t][c0 + e], acc[t][e]);      // LDS: 8 lanes per address
-  __syncthreads();
+        for (int e = 0; e < 4; ++e) red[t][c0 + e] += acc[t][e];
+    }
+    __syncthreads();
+  }
   float* mine = part + (long)blockIdx.x * (27 * HD);
   for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) mine[i] = red[i / HD][i % HD];
 }
@@ -460,13 +487,6 @@ __global__ __launch_bounds__(256) void pool_wgrad_reduce_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------- max-pool skip
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
-    reinterpret_cast<f32x4*>(p)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
-}
-
 struct MaxPoolGeom {
   int B, T, H, W, k, s, Ho, Wo, C;   // kernel (1,k,k), stride (1,s,s), padding (0,k/2,k/2)
   long ldi, ldo;
@@ -506,38 +526,57 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 
-// dx (pre-zeroed by the caller for the token rows) += routed dy: every output sends its gradient to the FIRST maximum of its
-// window in scan order (torch max_pool3d keeps the first `val > maxval`); cls rows are copied.
+// dx = routed dy: every output sends its gradient to the FIRST maximum of its window in scan order (torch max_pool3d
+// keeps the first `val > maxval`); cls rows are copied.  Written as a GATHER -- each input position re-scans the (at most
+// 2 x 2) windows that contain it and adds, in a fixed order, the gradients of those it wins -- so there are no atomics
+// (bit-reproducible) and dx needs no zero fill.  4 channels per thread.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           MaxPoolGeom g, float* __restrict__ dx) {
+  const int c4n = g.C >> 2;
   const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
-  const long rows = g.B * Lo + g.B;
-  const long total = rows * g.C;
+  const long rows = g.B * L + g.B;
+  const long total = rows * c4n;
   const int pad = g.k / 2;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % g.C);
-    const long row = idx / g.C;
-    const float d = dy[row * g.ldo + c];
-    if (row >= g.B * Lo) {
-      dx[(g.B * L + (row - g.B * Lo)) * g.ldi + c] = d;
+    const int c = (int)(idx % c4n) * 4;
+    const long row = idx / c4n;
+    if (row >= g.B * L) {
+      *reinterpret_cast<f32x4*>(dx + row * g.ldi + c) =
+          *reinterpret_cast<const f32x4*>(dy + (g.B * Lo + (row - g.B * L)) * g.ldo + c);
       continue;
     }
-    const int wo = (int)(row % g.Wo), ho = (int)((row / g.Wo) % g.Ho);
-    const long bt = row / ((long)g.Wo * g.Ho);
-    float m = -INFINITY;
-    long arg = -1;
-    for (int yy = 0; yy < g.k; ++yy) {
-      const int yi = ho * g.s - pad + yy;
-      if (yi < 0 || yi >= g.H) continue;
-      for (int xx = 0; xx < g.k; ++xx) {
-        const int xi = wo * g.s - pad + xx;
-        if (xi < 0 || xi >= g.W) continue;
-        const long r = (bt * g.H + yi) * g.W + xi;
-        const float v = x[r * g.ldi + c];
-        if (v > m || arg < 0) { m = v; arg = r; }
+    const int xi = (int)(row % g.W), yi = (int)((row / g.W) % g.H);
+    const long bt = row / ((long)g.W * g.H);
+    const int me = yi * g.W + xi;
+    int ho0 = (yi + pad - g.k + 1 + g.s - 1) / g.s, ho1 = (yi + pad) / g.s;     // windows with yi in [ho*s-pad, ho*s-pad+k-1]
+    int wo0 = (xi + pad - g.k + 1 + g.s - 1) / g.s, wo1 = (xi + pad) / g.s;
+    if (yi + pad - g.k + 1 < 0) ho0 = 0;
+    if (xi + pad - g.k + 1 < 0) wo0 = 0;
+    ho1 = ho1 < g.Ho - 1 ? ho1 : g.Ho - 1;
+    wo1 = wo1 < g.Wo - 1 ? wo1 : g.Wo - 1;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ho = ho0; ho <= ho1; ++ho)
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {-1, -1, -1, -1};
+        for (int yy = 0; yy < g.k; ++yy) {
+          const int y2 = ho * g.s - pad + yy;
+          if (y2 < 0 || y2 >= g.H) continue;
+          for (int xx = 0; xx < g.k; ++xx) {
+            const int x2 = wo * g.s - pad + xx;
+            if (x2 < 0 || x2 >= g.W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bt * g.H + y2) * g.W + x2) * g.ldi + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v[e] > m[e] || arg[e] < 0) { m[e] = v[e]; arg[e] = y2 * g.W + x2; }
+          }
+        }
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((bt * g.Ho + ho) * g.Wo + wo) * g.ldo + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (arg[e] == me) acc[e] += d[e];
       }
-    }
-    atomicAdd(dx + arg * g.ldi + c, d);
+    *reinterpret_cast<f32x4*>(dx + row * g.ldi + c) = acc;
   }
 }
 
@@ -724,24 +763,35 @@ extern "C" int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* ga
   return PVRL_OK;
 }
 
+extern "C" int64_t pvrl_layernorm_g_bwd_workspace_bytes(int64_t M, int64_t C) {
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  return blocks * 2 * C * (int64_t)sizeof(float);
+}
+
 extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
                                     const float* mean, const float* rstd, const float* gamma, const float* dres,
                                     int64_t ldr, float* dx, int64_t lddx, int64_t M, int64_t C, int64_t Cpad,
-                                    float* dgamma, float* dbeta, void* stream) {
+                                    float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
   if (M <= 0) return PVRL_OK;
-  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || C <= 0 || C > 64 * LNG_MAX || Cpad < C ||
-      Cpad > 64 * LNG_MAX)
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace || C <= 0 || C > 64 * LNG_MAX ||
+      Cpad < C || Cpad > 64 * LNG_MAX || workspace_bytes < pvrl_layernorm_g_bwd_workspace_bytes(M, C))
     return PVRL_EINVAL;
   long blocks = (M + 3) / 4;
   if (blocks > 1024) blocks = 1024;
+  float* part = (float*)workspace;
   if (dy_is_f32)
     hipLaunchKernelGGL(ln_g_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (int)C, (int)Cpad, dgamma, dbeta, (long)M);
+                       (int)C, (int)Cpad, part, (long)M);
   else
     hipLaunchKernelGGL(ln_g_bwd_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (int)C, (int)Cpad, dgamma, dbeta, (long)M);
+                       (int)C, (int)Cpad, part, (long)M);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partials_add_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)part, (int)blocks, (int)(2 * C), dgamma, dbeta, (int)C);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -770,7 +820,10 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   return PVRL_OK;
 }
 
-extern "C" int64_t pvrl_mvit_pool_bwd_workspace_bytes(void) { return (int64_t)PW_MAX_WG * 27 * HD * sizeof(float); }
+constexpr int PLN_MAX_WG = 2048;    // workgroups (= partial rows) of pool_ln_bwd_kernel
+extern "C" int64_t pvrl_mvit_pool_bwd_workspace_bytes(void) {
+  return ((int64_t)PW_MAX_WG * 27 * HD + (int64_t)PLN_MAX_WG * 2 * HD) * sizeof(float);
+}
 
 extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const void* qkv, void* dqkv, int64_t ld,
                                   int64_t col0, int64_t B, int64_t H, int64_t T, int64_t Hh, int64_t Ww, int64_t st,
@@ -785,9 +838,13 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   const long Lo = (long)g.To * g.Ho * g.Wo;
   const long ntok = (long)B * H * (Lo + 1);
   long blocks = (ntok * 16 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > PLN_MAX_WG) blocks = PLN_MAX_WG;
+  float* lnpart = (float*)workspace + (long)PW_MAX_WG * 27 * HD;
   hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)conv_out,
-                     g, gamma, eps, (bf16*)dc_scratch, (bf16*)dqkv, dgamma, dbeta);
+                     g, gamma, eps, (bf16*)dc_scratch, (bf16*)dqkv, lnpart);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partials_add_kernel, dim3((2 * HD + 15) / 16), dim3(256), 0, s, (const float*)lnpart, (int)blocks,
+                     2 * HD, dgamma, dbeta, HD);
   PVRL_LAUNCH_CHECK();
   const long nin = (long)B * H * T * Hh * Ww;
   hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
@@ -830,11 +887,10 @@ extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* d
                                      int64_t H, int64_t W, int64_t s, int64_t C, float* dx, void* stream) {
   MaxPoolGeom g;
   if (!x || !dy || !dx || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
-  // zero dx with a kernel, not hipMemsetAsync: the memset node of a captured HIP graph did not re-zero the buffer on
-  // replay (ROCm 7.2: gradients accumulated across replays until they overflowed), a kernel node does
-  const long nz = (long)B * T * H * W * ldi;
-  hipLaunchKernelGGL(zero_f32_kernel, dim3(grid_for((nz + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dx, nz);
-  const long total = ((long)B * T * g.Ho * g.Wo + B) * C;
+  // (no zero fill: the gather kernel writes every element.  An earlier scatter version zeroed dx with hipMemsetAsync, whose
+  //  memset node in a captured HIP graph did not re-zero the buffer on replay -- ROCm 7.2 -- so gradients accumulated
+  //  across replays; nothing on a captured path uses hipMemset* any more.)
+  const long total = ((long)B * T * H * W + B) * (C >> 2);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;

@@ -46,9 +46,11 @@ def ln_bwd(dy, x, C, mean, rstd, gamma, dgamma, dbeta, dres=None, Cpad=None):
     Cpad = C if Cpad is None else Cpad
     dx = torch.empty((M, Cpad), device=x.device, dtype=F32)
     assert dy.dtype in (F32, BF16) and dy.stride(1) == 1 and dgamma.dtype == F32 and dgamma.is_contiguous()
+    from .ops import workspace
+    ws = workspace(L.call("pvrl_layernorm_g_bwd_workspace_bytes", M, C), x.device, "mvit_ln_g")
     L.call("pvrl_layernorm_g_bwd", _ptr(dy), dy.stride(0), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean),
            _ptr(rstd), _ptr(gamma), _ptr(dres), dres.stride(0) if dres is not None else 0, _ptr(dx), dx.stride(0), M, C,
-           Cpad, _ptr(dgamma), _ptr(dbeta), _stream())
+           Cpad, _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream())
     return dx
 
 
@@ -96,7 +98,7 @@ def maxpool_bwd(x, dy, B, thw, s, C):
     T, H, W = thw
     dx = torch.empty_like(x)
     if x.shape[1] > C:
-        dx[B * T * H * W:, C:].zero_()
+        dx[:, C:].zero_()          # the kernel writes the C real columns of every row; the padding stays zero
     L.call("pvrl_mvit_maxpool_bwd", _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), B, T, H, W, s, C, _ptr(dx), _stream())
     return dx
 

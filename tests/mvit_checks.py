@@ -395,9 +395,8 @@ def check_mvit_pretrain_steps():
 
 
 def check_mvit_hip_graph_replay():
-    """MViT encoder step replayed from HIP graphs (engine.GraphReplay) vs the eager launches of the same kernels.  The
-    MViT backward still accumulates a few parameter gradients with fp32 atomics (LayerNorm, max-pool scatter), so the
-    comparison is to a tolerance of accumulation-order noise, not bit-exact; features are bit-identical."""
+    """MViT encoder step replayed from HIP graphs (engine.GraphReplay) vs the eager launches of the same kernels: logits
+    AND gradients bit-identical (every reduction of the MViT path has a fixed order too: no floating-point atomics)."""
     from procedurevrl_amd.build import build_model
     from procedurevrl_amd.datasets import synthetic_label_emb
     from procedurevrl_amd.functional import kl_topk_loss
@@ -426,7 +425,7 @@ def check_mvit_hip_graph_replay():
     for k, i in enumerate((1, 0, 1, 0, 1)):     # several replays: state must not leak from one replay into the next
         pred, grads = step(xs[i])                # (a captured hipMemsetAsync did not re-zero a max-pool gradient buffer)
         out.append((f"mvit graph replay {k}, input {i}: logits differ (count)", float((pred != ref[i][0]).sum()), 0.0))
-        out.append((f"mvit graph replay {k}, input {i}: gradients vs eager", rel(grads, ref[i][1]), 1e-4))
+        out.append((f"mvit graph replay {k}, input {i}: gradients differ (count)", float((grads != ref[i][1]).sum()), 0.0))
     return out
 
 

@@ -54,7 +54,7 @@ def test_grouped_weight_gradient_plan_runs_without_a_gpu():
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) == -1
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", 0, ap) == -1
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", 9, ap) == -1
-    assert L.call("pvrl_mvit_pool_bwd_workspace_bytes") == 2048 * 27 * 96 * 4
+    assert L.call("pvrl_mvit_pool_bwd_workspace_bytes") == (2048 * 27 * 96 + 2048 * 2 * 96) * 4
 
 
 def test_product_path_fails_loudly_without_gpu():
