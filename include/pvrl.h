@@ -30,17 +30,19 @@ extern "C" {
 #define PVRL_EPI_BF16 0      /* out0 bf16 = rowscale * (acc + bias)                                   */
 #define PVRL_EPI_GELU 1      /* u = acc + bias; out0 bf16 = u; out1 bf16 = GELU_erf(u)  (vit.py:54-60) */
 #define PVRL_EPI_QGELU 2     /* same with QuickGELU x*sigmoid(1.702x)          (tfm_model.py:27-29)   */
-#define PVRL_EPI_RESID_F32 3 /* out0 f32 = aux_f32[m % rowmod] + rowscale * (acc + bias)              */
+#define PVRL_EPI_RESID_F32 3 /* out0 f32 = aux_f32[m % rowmod] + rowscale * (acc + bias) + bias2      */
 #define PVRL_EPI_F32 4       /* out0 f32 = rowscale * (acc + bias)                                    */
 #define PVRL_EPI_DGELU 5     /* out0 bf16 = rowscale * acc * GELU_erf'(aux_bf16)   (MLP backward)     */
 #define PVRL_EPI_DQGELU 6    /* out0 bf16 = rowscale * acc * QuickGELU'(aux_bf16)                     */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.
  * Replaces nn.Linear forward (vit.py:54-60,75-92,133; tfm_model.py:35-41) and, with the
- * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M. */
+ * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M.  bias2 (fp32 [N] or null,
+ * PVRL_EPI_RESID_F32 only) is added after the row scale: x + rs * (o W_e^T + b_e) + b_fc of the fused temporal branch. */
 int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
                       int epilogue, const float* bias, const float* rowscale, const void* aux, int64_t aux_ld,
-                      int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, void* stream);
+                      int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, const float* bias2,
+                      void* stream);
 
 /* Benchmark knob: force the GEMM tile (0 heuristic, 1 128x128, 2 256x128, 3 256x256). Not used by the model. */
 int pvrl_debug_set_gemm_tile(int tile);
@@ -91,7 +93,9 @@ int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* problems, int64_
 /* LayerNorm over fp32 rows, C in {512, 768} (vit.py:104,109,116,228 eps 1e-6; tfm_model.py:18-24 eps 1e-5).
  * fwd: y = (x - mean) * rstd * gamma + beta  -> bf16 (GEMM operand) or fp32.
  * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows; optionally also writes
- *      dxs_bf16[m] = bf16(dxs_scale[m] * dx_out[m]) for m < dxs_rows (the next stage's bf16 GEMM operand, DropPath-scaled). */
+ *      dxs_bf16[m] = bf16(dxs_scale[m] * dx_out[m]) for m < dxs_rows (the next stage's bf16 GEMM operand, DropPath-scaled)
+ *      and dxsum[c] = beta_acc * old + sum over m < dxs_rows of dx_out[m][c] (the UNscaled column sums = the gradient of a
+ *      bias added after the DropPath scale, optional). */
 int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                        int64_t ldy, int out_is_f32, float* mean, float* rstd, int64_t M, int64_t C, void* stream);
 int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C);
@@ -99,7 +103,7 @@ int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float*
                        const float* rstd, const float* gamma, const float* dx_in, int64_t ldi, float* dx_out,
                        int64_t ldo, float beta_acc, float* dgamma, float* dbeta, void* workspace,
                        int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16, int64_t ldxs, const float* dxs_scale,
-                       int64_t dxs_rows, void* stream);
+                       int64_t dxs_rows, float* dxsum, void* stream);
 
 /* Temporal attention for T = 8 (Block.forward temporal branch, vit.py:129-135 via Attention.forward
  * vit.py:75-92): sequences are 8 consecutive rows of the packed qkv [rows][3*H*64]. */

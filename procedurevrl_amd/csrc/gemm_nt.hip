@@ -27,6 +27,7 @@ struct GemmNT {
   const bf16* W; long ldw;
   int M, N, K;
   const float* bias;      // [N] or null
+  const float* bias2;     // [N] or null: added AFTER the row scale (fp32-residual epilogue only)
   const float* rowscale;  // [M] or null
   const void* aux;        // fp32 residual [*, aux_ld] or bf16 pre-activation [M, aux_ld]
   long aux_ld; int aux_rowmod;
@@ -83,7 +84,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
         f32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
-        if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + off);
+        if constexpr (EPI == PVRL_EPI_RESID_F32) {
+          ov += *reinterpret_cast<const f32x4*>(r + off);
+          if (p.bias2) ov += *reinterpret_cast<const f32x4*>(p.bias2 + nw0 + 8 * q + off);
+        }
         *reinterpret_cast<f32x4*>(o + off) = ov;
       }
     }
@@ -747,7 +751,10 @@ __device__ __forceinline__ void epi_row16(const GemmNT& p, const f32x16& a, int 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 ov = (f32x4){rs * v[4 * c], rs * v[4 * c + 1], rs * v[4 * c + 2], rs * v[4 * c + 3]};
-      if constexpr (EPI == PVRL_EPI_RESID_F32) ov += *reinterpret_cast<const f32x4*>(r + 4 * c);
+      if constexpr (EPI == PVRL_EPI_RESID_F32) {
+        ov += *reinterpret_cast<const f32x4*>(r + 4 * c);
+        if (p.bias2) ov += *reinterpret_cast<const f32x4*>(p.bias2 + n + 4 * c);
+      }
       *reinterpret_cast<f32x4*>(o + 4 * c) = ov;
     }
   } else if constexpr (EPI == PVRL_EPI_BF16) {
@@ -1314,8 +1321,9 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
 extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N,
                                  int64_t K, int epilogue, const float* bias, const float* rowscale,
                                  const void* aux, int64_t aux_ld, int64_t aux_rowmod, void* out0, int64_t ld0,
-                                 void* out1, int64_t ld1, void* stream) {
+                                 void* out1, int64_t ld1, const float* bias2, void* stream) {
   if (M <= 0) return PVRL_OK;
+  if (bias2 && epilogue != PVRL_EPI_RESID_F32) return PVRL_EINVAL;
   if (!A || !W || !out0 || N <= 0 || K <= 0 || (N % 128) || (K % BK)) return PVRL_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ld0 % 8)) return PVRL_EINVAL;
   if ((epilogue == PVRL_EPI_GELU || epilogue == PVRL_EPI_QGELU) && (!out1 || (ld1 % 8))) return PVRL_EINVAL;
@@ -1325,7 +1333,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   GemmNT p;
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  p.bias = bias; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
+  p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
   p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = g_nt_gm;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {

@@ -77,16 +77,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dx_in, long ldi, float* __restrict__ dx_out,
                                                      long ldo, float* __restrict__ part, int M, bf16* __restrict__ dxs,
-                                                     long ldxs, const float* __restrict__ dxs_scale, int dxs_rows) {
+                                                     long ldxs, const float* __restrict__ dxs_scale, int dxs_rows,
+                                                     int want_sum) {
   constexpr int NV = C / 256;
   __shared__ float red[4][2][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 g[NV], dg[NV], db[NV];
+  const int pstride = (2 + want_sum) * C;       // floats per workgroup in `part`: dgamma | dbeta | (column sums of dx_out)
+  f32x4 g[NV], dg[NV], db[NV], ds[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     g[j] = *reinterpret_cast<const f32x4*>(gamma + 4 * lane + 256 * j);
     dg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     db[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
       for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - c1 - xh[j][e] * c2);
       if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + (long)row * ldi + c);
       *reinterpret_cast<f32x4*>(dx_out + (long)row * ldo + c) = o;
+      if (want_sum && row < dxs_rows) ds[j] += o;      // unscaled column sums of the rows that feed the next stage
       if (dxs && row < dxs_rows) {   // bf16 (optionally DropPath-scaled) copy: the GEMM operand of the next backward stage
         const float sc = dxs_scale ? dxs_scale[row] : 1.f;
         Vec4IO<bf16>::store(dxs + (long)row * ldxs + c, sc * o);
@@ -135,7 +139,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   __syncthreads();
   for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
     const int w = idx / C, c = idx - w * C;
-    part[(long)blockIdx.x * 2 * C + idx] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+    part[(long)blockIdx.x * pstride + idx] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+  }
+  if (want_sum) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = 4 * lane + 256 * j;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][0][c + e] = ds[j][e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      part[(long)blockIdx.x * pstride + 2 * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
   }
 }
 
@@ -143,15 +159,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 // 16 columns x 16 row groups per block (64-byte row segments), LDS tree at the end: 96 blocks for C = 768.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta,
                                                              float* __restrict__ out0, float* __restrict__ out1,
-                                                             int half) {
+                                                             int half, int pstride) {
   __shared__ float red[16][17];
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   float a0 = 0.f, a1 = 0.f;
   if (j < n) {
     int b = g;
-    for (; b + 16 < nblk; b += 32) { a0 += part[(long)b * n + j]; a1 += part[(long)(b + 16) * n + j]; }
-    if (b < nblk) a0 += part[(long)b * n + j];
+    for (; b + 16 < nblk; b += 32) { a0 += part[(long)b * pstride + j]; a1 += part[(long)(b + 16) * pstride + j]; }
+    if (b < nblk) a0 += part[(long)b * pstride + j];
   }
   red[g][c] = a0 + a1;
   __syncthreads();
@@ -190,14 +206,14 @@ extern "C" int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 
 extern "C" int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C) {
   const int64_t nblk = cdiv(M > 0 ? M : 1, 4) < LN_BWD_MAX_BLOCKS ? cdiv(M > 0 ? M : 1, 4) : LN_BWD_MAX_BLOCKS;
-  return nblk * 2 * C * (int64_t)sizeof(float);
+  return nblk * 3 * C * (int64_t)sizeof(float);   // dgamma | dbeta | optional column sums of dx_out
 }
 
 extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
                                   const float* mean, const float* rstd, const float* gamma, const float* dx_in,
                                   int64_t ldi, float* dx_out, int64_t ldo, float beta_acc, float* dgamma, float* dbeta,
                                   void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16,
-                                  int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, void* stream) {
+                                  int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, float* dxsum, void* stream) {
   if (M <= 0) return PVRL_OK;
   if (!dy || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta || !workspace) return PVRL_EINVAL;
   if ((ldx % 4) || (lddy % 4) || (ldo % 4) || (dx_in && (ldi % 4))) return PVRL_EINVAL;
@@ -206,20 +222,27 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
   hipStream_t s = (hipStream_t)stream;
   const int nblk = cdiv(M, 4) < LN_BWD_MAX_BLOCKS ? cdiv(M, 4) : LN_BWD_MAX_BLOCKS;
   float* part = (float*)workspace;
+  const int want_sum = dxsum ? 1 : 0;
+  const int pstride = (2 + want_sum) * (int)C;
 #define LN_BWD(CC)                                                                                                   \
   if (dy_is_f32)                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, float>), dim3(nblk), dim3(256), 0, s, (const float*)dy, (long)lddy, x,      \
                        (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
-                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows);                                         \
+                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);                               \
   else                                                                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)dy, (long)lddy, x,        \
                        (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
-                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows);
+                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);
   if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, s, part, nblk,
-                     (int)(2 * C), beta_acc, dgamma, dbeta, (int)C);
+                     (int)(2 * C), beta_acc, dgamma, dbeta, (int)C, pstride);
   PVRL_LAUNCH_CHECK();
+  if (dxsum) {
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, part + 2 * C, nblk, (int)C,
+                       beta_acc, dxsum, dxsum, (int)C, pstride);
+    PVRL_LAUNCH_CHECK();
+  }
   return PVRL_OK;
 }

@@ -81,7 +81,7 @@ def _ld(t):
 # ----------------------------------------------------------------------------------------
 # GEMMs
 # ----------------------------------------------------------------------------------------
-def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=None, out1=None):
+def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=None, out1=None, bias2=None):
     """epilogue(A[M,K] @ W[N,K]^T).  Returns out0 (and out1 for the GELU epilogues)."""
     L = lib()
     _chk2d(A, BF16); _chk2d(W, BF16)
@@ -97,7 +97,7 @@ def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=No
     _timed("gemm_nt_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
         _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
-        _ptr(out1), _ld(out1) if out1 is not None else 0, _stream()))
+        _ptr(out1), _ld(out1) if out1 is not None else 0, _ptr(bias2), _stream()))
     return (out0, out1) if two else out0
 
 
@@ -207,8 +207,10 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=BF16, out=None, save_stats=True
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0, dxs=None, dxs_scale=None):
-    """`dxs` (optional bf16 [rows <= M, C]) additionally receives bf16(dxs_scale[m] * dx_out[m])."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0, dxs=None, dxs_scale=None,
+                  dxsum=None, dxsum_beta=None):
+    """`dxs` (optional bf16 [rows <= M, C]) additionally receives bf16(dxs_scale[m] * dx_out[m]); `dxsum` (optional fp32
+    [C]) the unscaled column sums of those rows of dx_out (dxsum = dxsum_beta * dxsum + sums)."""
     L = lib()
     _chk2d(dy); _chk2d(x, F32)
     M, C = x.shape
@@ -216,10 +218,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
         dx_out = torch.empty((M, C), device=x.device, dtype=F32)
     nbytes = L.call("pvrl_layernorm_bwd_workspace_bytes", M, C)
     ws = workspace(nbytes, x.device, "ln")
+    tgt = dxsum
+    if dxsum is not None:
+        assert dxs is not None and dxsum.dtype == F32 and dxsum.is_contiguous() and dxsum.numel() == C
+        if (beta_acc if dxsum_beta is None else dxsum_beta) != beta_acc:      # the kernel has one beta for all three sums
+            tgt = torch.empty_like(dxsum)
     L.call("pvrl_layernorm_bwd", _ptr(dy), _ld(dy), 1 if dy.dtype == F32 else 0, _ptr(x), _ld(x), _ptr(mean),
            _ptr(rstd), _ptr(gamma), _ptr(dx_in), _ld(dx_in) if dx_in is not None else 0, _ptr(dx_out), _ld(dx_out),
            float(beta_acc), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _ptr(dxs),
-           _ld(dxs) if dxs is not None else 0, _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _stream())
+           _ld(dxs) if dxs is not None else 0, _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _ptr(tgt),
+           _stream())
+    if tgt is not dxsum:
+        if beta_acc != 0.0:
+            raise PvrlError("layernorm_bwd: dxsum_beta = 0 with beta_acc != 0 is not supported")
+        dxsum.mul_(float(dxsum_beta)).add_(tgt)
     return dx_out
 
 

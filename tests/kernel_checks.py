@@ -56,6 +56,9 @@ def check_gemm_nt():
         out.append((f"gemm_nt f32 {M}x{N}x{K}", rel(o, ref + bias), 1e-4))
         o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bd, rowscale=rsd, aux=resid.to(dev()))
         out.append((f"gemm_nt resid {M}x{N}x{K}", rel(o, resid + rs[:, None] * (ref + bias)), 1e-4))
+        b2 = torch.randn(N, generator=g)
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bd, rowscale=rsd, aux=resid.to(dev()), bias2=b2.to(dev()))
+        out.append((f"gemm_nt resid + unscaled bias2 {M}x{N}x{K}", rel(o, resid + rs[:, None] * (ref + bias) + b2), 1e-4))
         rm = 7
         o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bd, aux=resid[:rm].contiguous().to(dev()), aux_rowmod=rm)
         out.append((f"gemm_nt resid-mod {M}x{N}x{K}", rel(o, resid[torch.arange(M) % rm] + ref + bias), 1e-4))
@@ -288,6 +291,13 @@ def check_layernorm():
         dxs = torch.zeros(rows, C, device=dev(), dtype=BF)
         dx2 = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg, db, dxs=dxs, dxs_scale=sc.to(dev()))
         out.append((f"ln_bwd fused bf16 scaled copy {M}x{C}", rel(dxs, (sc[:, None] * dx2.cpu())[:rows]), 5e-3))
+        cs = torch.full((C,), 2.0, device=dev())
+        dg2, db2 = torch.ones(C, device=dev()), torch.ones(C, device=dev())
+        dx3 = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg2, db2, dxs=dxs, dxs_scale=sc.to(dev()),
+                                beta_acc=1.0, dxsum=cs)
+        out.append((f"ln_bwd unscaled column sums of the emitted rows (accumulating) {M}x{C}",
+                    rel(cs, 2.0 + dx3.cpu()[:rows].sum(0)), 1e-5))
+        out.append((f"ln_bwd dgamma with the column-sum output on {M}x{C}", rel(dg2, 1.0 + dg.cpu()), 1e-5))
     return out
 
 

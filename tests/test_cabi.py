@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_pure_size_queries_run_without_a_gpu():
     L = _lib.lib()
     assert L.call("pvrl_gemm_tn_workspace_bytes", 768, 768, 8) == 8 * (768 * 768 + 768) * 4 + 256
-    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 25 * 2 * 768 * 4
+    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 25 * 3 * 768 * 4
 
 
 def test_grouped_weight_gradient_plan_runs_without_a_gpu():
