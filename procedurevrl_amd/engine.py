@@ -61,12 +61,13 @@ class GradStore:
 
 class _W:
     """bf16 operand copies of one weight matrix: `w` = [N, K] for forward, `t` = [K, N] for the data gradient."""
-    __slots__ = ("w", "t", "ver")
+    __slots__ = ("w", "t", "ver", "be")
 
     def __init__(self):
         self.w = None
         self.t = None
         self.ver = -1
+        self.be = None      # fused temporal map only: fp32 [1, N] bias W_fc b_proj
 
 
 class GraphReplay:
@@ -251,6 +252,7 @@ class EncoderEngine(GraphReplay):
         self._side = None
         self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
         self._wq = []
+        self._wpost = []
         self._side_keep = []
         self._keep = None
         self._graph_init()            # HIP-graph replay of the step (GraphReplay)
@@ -312,6 +314,52 @@ class EncoderEngine(GraphReplay):
             for _, _, _, e, ver in todo:
                 e.ver = ver
 
+    def _fused_temporal(self, blk):
+        """The temporal branch applies two linear maps back to back (vit.py:131-134: temporal_attn.proj, DropPath, then
+        temporal_fc), so  x + fc(rs * proj(o)) = x + rs * (o W_e^T + b_e) + b_fc  with  W_e = W_fc W_proj,  b_e = W_fc b_proj:
+        ONE 50k-row GEMM forward (and one data-gradient / one weight-gradient GEMM backward) instead of two each.
+        W_e is rebuilt from the bf16 operand copies whenever either weight changed (a 768^3 MFMA GEMM); the parameter
+        gradients are recovered from dW_e in backward (`_temporal_chain`)."""
+        wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
+        e = self._w.get(("fused_t", id(wf)))
+        if e is None:
+            e = _W()
+            self._w[("fused_t", id(wf))] = e
+        ef, ep = self._weight(wf), self._weight(wp)
+        ver = (ef.ver, ep.ver, blk.temporal_attn.proj.bias._version)
+        if self._capturing == "bwd":
+            return e
+        if self._capturing == "fwd" or e.ver != ver or e.w is None:
+            L = lib()
+            we = ops.gemm_nt(ef.w, ep.t, L.PVRL_EPI_F32)                    # [out, in] = W_fc [out, mid] . W_proj [mid, in]
+            e.w, e.t = ops.cast_weight(we, out=e.w, out_t=e.t)
+            e.be = ops.gemm_nt_f32(blk.temporal_attn.proj.bias.detach().view(1, -1), wf.detach(), out=e.be)   # [1, out]
+            e.ver = ver
+        return e
+
+    def _temporal_chain(self, blk, gs, dwe, dbe):
+        """dW_e [out, in], db_e [out] (fp32, from the weight-gradient GEMM of the fused map) -> gradients of the four
+        parameters:  dW_fc = dW_e W_proj^T + db_e b_proj^T,  dW_proj = W_fc^T dW_e,  db_proj = W_fc^T db_e  (db_fc comes from the LayerNorm
+        backward's column sums).  Runs on the stream of the weight-gradient launch, right behind it."""
+        L = lib()
+        wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
+        ef, ep = self._weight(wf), self._weight(wp)
+        dwe_b, dwe_t = ops.cast_weight(dwe)                                   # bf16 [out, in] and [in, out]
+        for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t)):            # [out,mid] = dW_e.W_p^T ; [mid,in] = W_f^T.dW_e
+            g, beta = gs.target(lin_w)
+            if beta == 0.0:
+                ops.gemm_nt(A, W, L.PVRL_EPI_F32, out0=g)
+            else:
+                ops.gemm_nt(A, W, L.PVRL_EPI_RESID_F32, aux=g, out0=g)
+        # proj's bias rides through temporal_fc too (b_e = W_fc b_proj): its share of dW_fc is the outer product db_e x b_proj
+        gs.target(wf)[0].addr_(dbe, blk.temporal_attn.proj.bias.detach())
+        gb, beta = gs.target(blk.temporal_attn.proj.bias)
+        dbp = ops.gemm_nt_f32(dbe.view(1, -1), wf.detach().t().contiguous())  # [1, mid] = db_e . W_fc
+        if beta == 0.0:
+            gb.copy_(dbp.view(-1))
+        else:
+            gb.add_(dbp.view(-1))
+
     def grad_store(self):
         return self.m.grad_store()
 
@@ -327,9 +375,12 @@ class EncoderEngine(GraphReplay):
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def _wgrad(self, dy, xin, dw, dbias, beta):
-        """queue dW = beta*dW + dy^T xin (and dbias); `flush_wgrads` issues what is queued"""
+    def _wgrad(self, dy, xin, dw, dbias, beta, post=None):
+        """queue dW = beta*dW + dy^T xin (and dbias); `flush_wgrads` issues what is queued.  `post` (optional callable)
+        runs right behind the launch on the same stream (consumers of dW)."""
         self._wq.append((dy, xin, dw, dbias, beta))
+        if post is not None:
+            self._wpost.append(post)
         if not self.group_wgrad:
             self.flush_wgrads()
 
@@ -337,22 +388,27 @@ class EncoderEngine(GraphReplay):
         """Issue the queued weight gradients as one grouped launch (ops.gemm_tn_grouped) -- on the side stream when
         overlap_wgrad, ordered after everything the current stream has produced so far."""
         q, self._wq = self._wq, []
+        post, self._wpost = self._wpost, []
         if not q:
             return
         side = self.side_stream(q[0][0].device)
         if side is None:
             ops.gemm_tn_grouped(q, ws_tag="tn")
+            for f in post:
+                f()
             return
         ev = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(side):
             side.wait_event(ev)
             ops.gemm_tn_grouped(q, ws_tag="tn_side")
+            for f in post:
+                f()
             done = side.record_event()
         # The operands must outlive the side-stream kernels.  Tensor.record_stream would do that, but every pending
         # record makes EACH later allocation poll its event (measured: torch.empty 2 -> 52 us with ~170 records in flight,
         # 20 ms of host time per step); instead the references are parked here until the launch's event has completed,
         # or until join_side_stream() has ordered the main stream behind the side stream.
-        self._side_keep.append((done, [t for dy, xin, _, _, _ in q for t in (dy, xin)]))
+        self._side_keep.append((done, [t for dy, xin, dw, db, _ in q for t in (dy, xin, dw, db) if t is not None]))
         while not self._capturing and self._side_keep and self._side_keep[0][0].query():
             self._side_keep.pop(0)        # (no event queries while capturing: there everything is held until the join)
 
@@ -476,10 +532,9 @@ class EncoderEngine(GraphReplay):
             o_t = ops.attn_t8_fwd(qkv_t, B * N, H, self.scale)
         else:
             o_t, _, lse_t = ops.attn_fwd(qkv_t, B * N, T, H, self.scale, mode=0)
-        p_t = ops.gemm_nt(o_t, self._weight(blk.temporal_attn.proj.weight).w, L.PVRL_EPI_BF16,
-                          bias=P(blk.temporal_attn.proj.bias), rowscale=s1_tok)
         x1 = torch.empty_like(x0)
-        ops.gemm_nt(p_t, self._weight(blk.temporal_fc.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.temporal_fc.bias),
+        fe = self._fused_temporal(blk)          # proj then temporal_fc as one linear map
+        ops.gemm_nt(o_t, fe.w, L.PVRL_EPI_RESID_F32, bias=fe.be.view(-1), rowscale=s1_tok, bias2=P(blk.temporal_fc.bias),
                     aux=x0[:R], out0=x1[:R])
         x1[R:] = x0[R:]
 
@@ -503,7 +558,7 @@ class EncoderEngine(GraphReplay):
                     rowscale=s3_all, aux=x2, out0=x3)
         if save:
             sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
-                                     lse_t=lse_t, p_t=p_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
+                                     lse_t=lse_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
                                      lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp))
         return x3
 
@@ -522,6 +577,7 @@ class EncoderEngine(GraphReplay):
 
     def _graph_reset_host_state(self):
         self._wq = []
+        self._wpost = []
         self._side_keep = []
 
     def _enc_params(self):
@@ -622,10 +678,10 @@ class EncoderEngine(GraphReplay):
             (dw, bw), (dbias, _) = gs.target(lin.weight), gs.target(lin.bias)
             self._wgrad(dy, xin, dw, dbias, bw)
 
-        def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None):
+        def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None, dxsum=None, dxsum_beta=None):
             (dg, bg), (db, _) = gs.target(ln.weight), gs.target(ln.bias)
             ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg,
-                              dxs=dxs, dxs_scale=dxs_scale)
+                              dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta)
 
         # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
         wgrad(dy, s["g"], blk.mlp.fc2)
@@ -647,14 +703,17 @@ class EncoderEngine(GraphReplay):
         wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
         dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
         del dqkv, do, dps
+        # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
         dz = torch.empty((R, C), device=dev, dtype=BF16)
-        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz)                            # also emits bf16(dx[:R])
+        dbf, bbf = gs.target(blk.temporal_fc.bias)
+        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz, dxs_scale=s1_tok, dxsum=dbf, dxsum_beta=bbf)
 
-        # ---- temporal (rows [0, R); cls rows pass straight through) ----
-        wgrad(dz, s["p_t"], blk.temporal_fc)
-        dpt = ops.gemm_nt(dz, self._weight(blk.temporal_fc.weight).t, L.PVRL_EPI_BF16, rowscale=s1_tok)
-        wgrad(dpt, s["o_t"], blk.temporal_attn.proj)
-        dot = ops.gemm_nt(dpt, self._weight(blk.temporal_attn.proj.weight).t, L.PVRL_EPI_BF16)
+        # ---- temporal (rows [0, R); cls rows pass straight through): proj + temporal_fc as ONE map W_e (_fused_temporal)
+        fe = self._fused_temporal(blk)
+        dwe = torch.empty((C, C), device=dev, dtype=F32)
+        dbe = torch.empty(C, device=dev, dtype=F32)
+        self._wgrad(dz, s["o_t"], dwe, dbe, 0.0, post=lambda b=blk, w=dwe, v=dbe: self._temporal_chain(b, gs, w, v))
+        dot = ops.gemm_nt(dz, fe.t, L.PVRL_EPI_BF16)
         if T == 8:
             dqkv_t = ops.attn_t8_bwd(s["qkv_t"], dot, B * N, H, self.scale)
         else:
