@@ -242,9 +242,9 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_h_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
+    (profiles/r1_i_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
     A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
-    path = os.path.join(ROOT, "profiles", "r1_h_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_i_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
