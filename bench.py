@@ -143,8 +143,8 @@ def main():
         torch.cuda.synchronize()
 
     if graphs:      # set-up, like building the model: the encoder's launch sequence is captured into HIP graphs on its
-        for _ in range(vt.engine.GRAPH_WARMUP + 1):   # third call, whatever --warmup is
-            step()
+        for _ in range(vt.engine.GRAPH_WARMUP + 2):   # third call, whatever --warmup is; the first replay-only step after
+            step()                                     # a capture is slow too (measured 0.1-1 s once), so it is set-up as well
     for _ in range(args.warmup):
         loss = step()
     barrier()

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"])
     ap.add_argument("--videos", type=int, default=4)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=6)   # graphs are captured on the 3rd step; the next one is slow once
     args = ap.parse_args()
     import torch
     from procedurevrl_amd.build import build_model
@@ -73,15 +73,19 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for k in range(args.steps):
         loss = step()
+        evs[k + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    per_step = [round(evs[k].elapsed_time(evs[k + 1]), 1) for k in range(args.steps)]
     clips = args.videos * 9
     print(json.dumps({"workload": f"full pre-training step, {args.arch}, {args.videos} videos x 9 clips of {frames}x224^2, "
                                   "CLIP-text teacher (12 layers) + order transformer + KL/MSE + AdamW",
-                      "clips_per_s": round(clips / dt, 2), "ms_per_step": round(1e3 * dt, 2), "loss": float(loss)}))
+                      "clips_per_s": round(clips / dt, 2), "ms_per_step": round(1e3 * dt, 2), "per_step_ms": per_step, "loss": float(loss)}))
 
 
 if __name__ == "__main__":
