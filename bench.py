@@ -145,6 +145,13 @@ def main():
     if graphs:      # set-up, like building the model: the encoder's launch sequence is captured into HIP graphs on its
         for _ in range(vt.engine.GRAPH_WARMUP + 2):   # third call, whatever --warmup is; the first replay-only step after
             step()                                     # a capture is slow too (measured 0.1-1 s once), so it is set-up as well
+        if not args.no_kernel_timing:                  # and one eager, event-instrumented step: the timed region ends with one
+            ops.KERNEL_TIMING = []
+            vt.engine.use_graphs = False
+            step()
+            ops.KERNEL_TIMING = None
+            vt.engine.use_graphs = True
+            step()
     for _ in range(args.warmup):
         loss = step()
     barrier()
