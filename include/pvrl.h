@@ -260,6 +260,12 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float*
 
 /* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
  * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */
+/* y[r] = beta * y[r] + sum_c W[r][c] * x[c] for a small dense matrix W (fp32, or bf16 when w_is_bf16), fp32 x and y:
+ * the bias products of the fused temporal branch, b_e = W_fc b_proj and db_proj = W_fc^T db_e (the latter on the
+ * transposed bf16 operand copy), vit.py:131-134. */
+int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float* x, float beta, float* y,
+                       void* stream);
+
 /* pvrl_cast_weight_bf16 for many weight matrices in one launch (the bf16 operand copies of every nn.Linear of the
  * encoder after an optimiser step): out [R][C] and, when out_t is not null, out_t [C][R], both dense. */
 typedef struct pvrl_cast_problem {

@@ -220,6 +220,20 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
   }
 }
 
+// y[r] = beta * y[r] + sum_c W[r][c] * x[c]: one wave per row of a small dense matrix (fp32 or bf16), fp32 x / y.
+// (W_fc b_proj and W_fc^T db_e of the fused temporal branch: 768 x 768, a few microseconds)
+template <typename TW>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const TW* __restrict__ W, long ld, int R, int C,
+                                                        const float* __restrict__ x, float beta, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float a = 0.f;
+  for (int c = lane; c < C; c += 64) a += (float)W[(long)r * ld + c] * x[c];
+  a = wave_sum(a);
+  if (lane == 0) y[r] = (beta != 0.f ? beta * y[r] : 0.f) + a;
+}
+
 // The same for up to 96 weight matrices in ONE launch (a ViT-B encoder has 85: one 6-us launch each otherwise).
 constexpr int CAST_MULTI_MAX = 96;
 struct CastItem { const float* in; bf16* out; bf16* out_t; int R, C, first, tiles_c; };
@@ -374,6 +388,21 @@ extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, in
   if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
                      (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)C, (long)R);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float* x, float beta,
+                                  float* y, void* stream) {
+  if (R <= 0) return PVRL_OK;
+  if (!W || !x || !y || C <= 0 || ld < C) return PVRL_EINVAL;
+  const dim3 grid((unsigned)cdiv(R, 4)), blk(256);
+  if (w_is_bf16)
+    hipLaunchKernelGGL(gemv_rows_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)W, (long)ld, (int)R, (int)C,
+                       x, beta, y);
+  else
+    hipLaunchKernelGGL(gemv_rows_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)W, (long)ld, (int)R, (int)C,
+                       x, beta, y);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

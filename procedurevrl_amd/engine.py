@@ -67,7 +67,7 @@ class _W:
         self.w = None
         self.t = None
         self.ver = -1
-        self.be = None      # fused temporal map only: fp32 [1, N] bias W_fc b_proj
+        self.be = None      # fused temporal map only: fp32 [N] bias W_fc b_proj
 
 
 class GraphReplay:
@@ -333,7 +333,7 @@ class EncoderEngine(GraphReplay):
             L = lib()
             we = ops.gemm_nt(ef.w, ep.t, L.PVRL_EPI_F32)                    # [out, in] = W_fc [out, mid] . W_proj [mid, in]
             e.w, e.t = ops.cast_weight(we, out=e.w, out_t=e.t)
-            e.be = ops.gemm_nt_f32(blk.temporal_attn.proj.bias.detach().view(1, -1), wf.detach(), out=e.be)   # [1, out]
+            e.be = ops.gemv_rows(wf.detach(), blk.temporal_attn.proj.bias.detach(), out=e.be)                 # [out]
             e.ver = ver
         return e
 
@@ -354,11 +354,7 @@ class EncoderEngine(GraphReplay):
         # proj's bias rides through temporal_fc too (b_e = W_fc b_proj): its share of dW_fc is the outer product db_e x b_proj
         gs.target(wf)[0].addr_(dbe, blk.temporal_attn.proj.bias.detach())
         gb, beta = gs.target(blk.temporal_attn.proj.bias)
-        dbp = ops.gemm_nt_f32(dbe.view(1, -1), wf.detach().t().contiguous())  # [1, mid] = db_e . W_fc
-        if beta == 0.0:
-            gb.copy_(dbp.view(-1))
-        else:
-            gb.add_(dbp.view(-1))
+        ops.gemv_rows(ef.t, dbe, out=gb, beta=beta)                           # [mid] = W_fc^T db_e (bf16 operand copy)
 
     def grad_store(self):
         return self.m.grad_store()
@@ -534,7 +530,7 @@ class EncoderEngine(GraphReplay):
             o_t, _, lse_t = ops.attn_fwd(qkv_t, B * N, T, H, self.scale, mode=0)
         x1 = torch.empty_like(x0)
         fe = self._fused_temporal(blk)          # proj then temporal_fc as one linear map
-        ops.gemm_nt(o_t, fe.w, L.PVRL_EPI_RESID_F32, bias=fe.be.view(-1), rowscale=s1_tok, bias2=P(blk.temporal_fc.bias),
+        ops.gemm_nt(o_t, fe.w, L.PVRL_EPI_RESID_F32, bias=fe.be, rowscale=s1_tok, bias2=P(blk.temporal_fc.bias),
                     aux=x0[:R], out0=x1[:R])
         x1[R:] = x0[R:]
 

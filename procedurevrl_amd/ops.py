@@ -400,6 +400,19 @@ def cast_weight(w, out=None, out_t=None, need_t=True):
     return out, (out_t if need_t else None)
 
 
+def gemv_rows(W, x, out=None, beta=0.0):
+    """out[r] = beta * out[r] + W[r, :] . x  (W fp32 or bf16 [R, C] row-major, x fp32 [C]) -> fp32 [R]"""
+    _chk2d(W)
+    R, C = W.shape
+    assert x.dtype == F32 and x.is_contiguous() and x.numel() == C
+    if out is None:
+        out = torch.empty(R, device=W.device, dtype=F32)
+    assert out.dtype == F32 and out.is_contiguous() and out.numel() == R
+    lib().call("pvrl_gemv_rows_f32", _ptr(W), 1 if W.dtype == BF16 else 0, _ld(W), R, C, _ptr(x), float(beta), _ptr(out),
+               _stream())
+    return out
+
+
 def cast_weights_multi(items):
     """items: list of (w fp32 [R, C] contiguous, out bf16 [R, C], out_t bf16 [C, R] or None) -- one launch for all."""
     from ._lib import CastProblem

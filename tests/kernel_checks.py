@@ -255,6 +255,23 @@ def check_cast_weights_multi():
     return [(f"cast_weights_multi: {len(shapes)} matrices, mismatching copies", float(bad), 0.0)]
 
 
+def check_gemv_rows():
+    """pvrl_gemv_rows_f32: y = beta*y + W x for fp32 and bf16 matrices (ragged sizes, leading dimension > C)"""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(43)
+    out = []
+    for (R, C) in [(768, 768), (5, 70), (513, 129)]:
+        Wf = torch.randn(R, C + 8, generator=g)[:, :C]
+        x = torch.randn(C, generator=g)
+        y0 = torch.randn(R, generator=g)
+        y = ops.gemv_rows(Wf.to(dev()), x.to(dev()))
+        out.append((f"gemv_rows fp32 {R}x{C}", rel(y, Wf @ x), 1e-5))
+        yb = y0.to(dev()).clone()
+        ops.gemv_rows(Wf.to(dev(), BF), x.to(dev()), out=yb, beta=1.0)
+        out.append((f"gemv_rows bf16 accumulate {R}x{C}", rel(yb, y0 + bf(Wf) @ x), 1e-5))
+    return out
+
+
 def check_layernorm():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(4)
@@ -556,5 +573,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_cast_weights_multi, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
