@@ -242,14 +242,14 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ 
   __syncthreads();
   const int sub = threadIdx.x & 15, c0 = sub * 6;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
-  const long ntok = (long)g.B * g.H * (Lo + 1);
+  const unsigned ntok = (unsigned)((long)g.B * g.H * (Lo + 1));     // < 2^27 (checked by the launcher): 32-bit index math
   float gm[6], bt[6];
 #pragma unroll
   for (int e = 0; e < 6; ++e) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
-  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
-    const int lo = (int)(tok % (Lo + 1));
-    const long bh = tok / (Lo + 1);
-    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+  for (unsigned tok = (blockIdx.x * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
+    const int lo = (int)(tok % (unsigned)(Lo + 1));
+    const unsigned bh = tok / (unsigned)(Lo + 1);
+    const int h = (int)(bh % (unsigned)g.H), b = (int)(bh / (unsigned)g.H);
     const int col = g.col0 + h * HD + c0;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (lo == Lo) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ 
         }
       }
     }
-    st6(cbuf + tok * HD + c0, acc);
+    st6(cbuf + (long)tok * HD + c0, acc);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 6; ++e) s += acc[e];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ 
     float o[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) o[e] = (acc[e] - mu) * rs * gm[e] + bt[e];
-    st6(y + tok * HD + c0, o);
+    st6(y + (long)tok * HD + c0, o);
   }
 }
 
@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict
 }
 
 // data gradient of the depthwise conv: dX[b, l_in, h, c] = sum_taps dc[out(l_in, tap)][c] * w[c][tap]
+// S > 0: spatial stride S (a power of two) with temporal stride 1 -- every shipped MViT config -- so the 39 stride
+// divisions / remainders per token become shifts and masks and the token decomposition is 32-bit; S = 0: any strides.
+template <int S>
 __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict__ dc, PoolGeom g,
                                                          const float* __restrict__ w, bf16* __restrict__ dqkv) {
   __shared__ float ws[27 * HD];
@@ -361,33 +364,33 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict_
   __syncthreads();
   const int sub = threadIdx.x & 15, c0 = sub * 6;
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
-  const long ntok = (long)g.B * g.H * L;
-  for (long tok = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; tok < ntok; tok += ((long)gridDim.x * 256) >> 4) {
-    const int l = (int)(tok % L);
-    const long bh = tok / L;
-    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
-    const int xi = l % g.Ww, yi = (l / g.Ww) % g.Hh, ti = l / (g.Ww * g.Hh);
+  const int st = S ? 1 : g.st, sh = S ? S : g.sh, sw = S ? S : g.sw;
+  const unsigned ntok = (unsigned)((long)g.B * g.H * L);          // < 2^31 (checked by the launcher)
+  for (unsigned tok = (blockIdx.x * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
+    const unsigned l = tok % (unsigned)L, bh = tok / (unsigned)L;
+    const unsigned h = bh % (unsigned)g.H, b = bh / (unsigned)g.H;
+    const int xi = (int)(l % (unsigned)g.Ww), yi = (int)((l / (unsigned)g.Ww) % (unsigned)g.Hh), ti = (int)(l / (unsigned)(g.Ww * g.Hh));
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int tn = ti + 1 - a;
-      if (tn < 0 || tn % g.st) continue;
-      const int to = tn / g.st;
+      if (tn < 0 || (S ? 0 : tn % st)) continue;
+      const int to = S ? tn : tn / st;
       if (to >= g.To) continue;
 #pragma unroll
       for (int yy = 0; yy < 3; ++yy) {
         const int yn = yi + 1 - yy;
-        if (yn < 0 || yn % g.sh) continue;
-        const int yo = yn / g.sh;
+        if (yn < 0 || (S ? (yn & (S - 1)) : yn % sh)) continue;
+        const int yo = S ? yn / S : yn / sh;
         if (yo >= g.Ho) continue;
 #pragma unroll
         for (int xx = 0; xx < 3; ++xx) {
           const int xn = xi + 1 - xx;
-          if (xn < 0 || xn % g.sw) continue;
-          const int xo = xn / g.sw;
+          if (xn < 0 || (S ? (xn & (S - 1)) : xn % sw)) continue;
+          const int xo = S ? xn / S : xn / sw;
           if (xo >= g.Wo) continue;
           float v[6];
-          ld6(dc + (bh * (Lo + 1) + ((long)to * g.Ho + yo) * g.Wo + xo) * HD + c0, v);
+          ld6(dc + ((long)bh * (Lo + 1) + ((long)to * g.Ho + yo) * g.Wo + xo) * HD + c0, v);
           const float* wt = ws + ((a * 3 + yy) * 3 + xx) * HD + c0;
 #pragma unroll
           for (int e = 0; e < 6; ++e) acc[e] = fmaf(v[e], wt[e], acc[e]);
@@ -814,6 +817,7 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   PoolGeom g;
   if (!qkv || !w || !gamma || !beta || !y || !conv_out || pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0)) return PVRL_EINVAL;
   const long ntok = (long)B * H * ((long)g.To * g.Ho * g.Wo + 1);
+  if (ntok >= (1L << 27)) return PVRL_EINVAL;         // 16 lanes per token, 32-bit token arithmetic in the kernel
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, g,
                      w, gamma, beta, eps, (bf16*)y, (bf16*)conv_out);
   PVRL_LAUNCH_CHECK();
@@ -847,8 +851,14 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
                      2 * HD, dgamma, dbeta, HD);
   PVRL_LAUNCH_CHECK();
   const long nin = (long)B * H * T * Hh * Ww;
-  hipLaunchKernelGGL(pool_dgrad_kernel, dim3(grid_for(nin * 16)), dim3(256), 0, s, (const bf16*)dc_scratch, g, w,
-                     (bf16*)dqkv);
+  if (nin >= (1L << 27)) return PVRL_EINVAL;          // 16 lanes per token, 32-bit token arithmetic in the kernel
+  {
+    const dim3 dg(grid_for(nin * 16)), db(256);
+    const int S = (st == 1 && sh == sw && (sh == 1 || sh == 2 || sh == 4 || sh == 8)) ? (int)sh : 0;
+#define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const bf16*)dc_scratch, g, w, (bf16*)dqkv)
+    if (S == 1) DGRAD(1); else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
+#undef DGRAD
+  }
   PVRL_LAUNCH_CHECK();
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
   if (wb > PW_MAX_WG) wb = PW_MAX_WG;
