@@ -918,6 +918,183 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4x32_kernel(GemmNT p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The 4-wave 32x32x16 kernel above with the staging discipline of gemm_tn_rt32: operands come in through registers (eight
+// raw-ISA 16-byte global loads per lane and stage, two stages ahead, ONE counted vmcnt per stage) and go to LDS with
+// ds_write_b128 -- an LDS-DMA piece costs 60-185 issue cycles next to MFMAs (MI355X_MICROARCH.md), eight of them a
+// stage's whole MFMA time; a global load + a ds_write_b128 cost a fraction of that.  Two LDS slots of 32 KiB, operand
+// image in rotated 16-byte-chunk planes (conflict-free reads and writes).  Knob 13.  MEASURED (MI355X, M = 50,208): 698-814
+// TFLOP/s against 969-1069 for the 16-wave default (qkv 254 vs 183 us, dfc1 292 vs 222 us) -- the same as the LDS-DMA form
+// (knob 10), so neither the DMA issue cost nor bank conflicts were what held the 4-wave NT kernels back: its stage takes
+// ~2,100 cycles for 1,024 cycles of MFMA, exactly like gemm_tn_rt32's; with one wave per SIMD every LDS / barrier latency is
+// exposed, with four (the default) it is not.  The clean ISA (one vmcnt(8) per stage, no scratch in the loop) rules out a
+// scheduling accident.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_rt32_kernel(GemmNT p) {
+  constexpr int BM = 256, BN = 256, BKS = 32, NS = 2;
+  constexpr int XBYTES = BM * BKS * 2, STAGE = 2 * XBYTES;   // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int GM = p.gm;
+  int tm, tn;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    const int cm = qm + (xcd < rm ? 1 : 0);
+    const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+    if (j >= cm * p.tiles_n) return;
+    const int gsz = GM * p.tiles_n;
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: waves 0,1 bring X rows 128 w .., waves 2,3 W rows; 8 LDS-DMA instructions (16 rows x 64 B) per wave and stage
+  const char* gsrc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = (wave & 1) * 128 + e * 16 + (lane >> 2);
+    const int pc = lane & 3;
+    if (wave < 2) {
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      gsrc[e] = reinterpret_cast<const char*>(p.A + (long)grow * p.lda + (pc << 3));
+    } else {
+      gsrc[e] = reinterpret_cast<const char*>(p.W + (long)(n0 + row) * p.ldw + (pc << 3));
+    }
+  }
+  // LDS image of an operand stage: four 4 KiB planes, plane c = the 16-byte k-chunk c of all 256 rows, rotated by 64 c bytes:
+  // a fragment read (32 consecutive rows of one chunk) is 512 contiguous bytes, and the four chunks of a row -- written by
+  // four neighbouring lanes -- land 64 bytes apart in the bank row instead of on the same banks
+  auto lds_off = [&](int row, int c) { return c * 4096 + ((row * 16 + c * 64) & 4095); };
+  const int opbase = wave < 2 ? 0 : XBYTES;
+  // raw-ISA loads (the compiler's own waits would drain the younger register set, see gemm_tn_rt32): set r holds the 8
+  // 16-byte pieces this lane contributes to one stage; `wait_set` = all 8 of the OLDER set have landed
+  auto gload = [&](u32x4* r, int kt, int nk) {
+    const int kc = kt < nk ? kt : nk - 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[e]) : "v"(gsrc[e] + kc * (BKS * 2)) : "memory");
+  };
+  auto wait_set = [&](u32x4* r) {
+    asm volatile("s_waitcnt vmcnt(8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+  };
+  int woffs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) woffs[e] = opbase + lds_off((wave & 1) * 128 + e * 16 + (lane >> 2), lane & 3);
+  auto lwrite = [&](const u32x4* r, int e, char* slot) { *reinterpret_cast<u32x4*>(slot + woffs[e]) = r[e]; };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // fragment addresses of block b, K = 16 sub-step u: row r, 16-byte chunk 2u + kg
+  const int i32 = lane & 31, kg = lane >> 5;
+  int xoff[2][4], woff[2][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int rx = wm * 128 + b * 32 + i32;
+    const int rw = wn * 128 + b * 32 + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      xoff[u][b] = lds_off(rx, 2 * u + kg);
+      woff[u][b] = XBYTES + lds_off(rw, 2 * u + kg);
+    }
+  }
+  auto rd = [&](const char* b, int off) { return *reinterpret_cast<const bf16x8*>(b + off); };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  bf16x8 xa[4], wa[4], xb[4], wb[4];
+  auto mma = [&](const bf16x8* xf, const bf16x8* wf) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+  };
+  u32x4 ra[8], rb[8];
+  // one K = 32 stage: 32 MFMAs | 16 fragment reads of the NEXT stage from `rs` | the 8 staged pieces of set r -> slot `ws`
+  auto step = [&](const char* rs, const u32x4* r, char* ws) {
+    mma(xa, wa);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { xa[t] = rd(rs, xoff[0][t]); wa[t] = rd(rs, woff[0][t]); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lwrite(r, e, ws);
+    mma(xb, wb);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { xb[t] = rd(rs, xoff[1][t]); wb[t] = rd(rs, woff[1][t]); }
+#pragma unroll
+    for (int e = 4; e < 8; ++e) lwrite(r, e, ws);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+
+  const int nk = p.K / BKS;     // even (K % 64 == 0)
+  char* slot0 = smem;
+  char* slot1 = smem + STAGE;
+  gload(ra, 0, nk);
+  gload(rb, 1, nk);
+  wait_set(ra);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lwrite(ra, e, slot0);
+  gload(ra, 2, nk);
+  lds_barrier();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xa[t] = rd(slot0, xoff[0][t]); wa[t] = rd(slot0, woff[0][t]);
+    xb[t] = rd(slot0, xoff[1][t]); wb[t] = rd(slot0, woff[1][t]);
+  }
+  wait_set(rb);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lwrite(rb, e, slot1);
+  gload(rb, 3, nk);
+  for (int kt = 0; kt < nk; kt += 2) {
+    lds_barrier();
+    wait_set(ra);
+    step(slot1, ra, slot0);
+    gload(ra, kt + 4, nk);
+    lds_barrier();
+    wait_set(rb);
+    step(slot0, rb, slot1);
+    gload(rb, kt + 5, nk);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // D layout: lane (col m = lane % 32, kg): register e <-> MFMA row rho = (e/4)*8 + kg*4 + e%4 <-> column 16 kg + e
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wm * 128 + mb * 32 + i32;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) epi_row16<EPI>(p, acc[mb][nb], m, n0 + wn * 128 + nb * 32 + 16 * kg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 8 waves (2 per SIMD), each a 128(m) x 64(n) block as 4 x 2 blocks of v_mfma_f32_32x32x16_bf16; BK = 64, 2-stage LDS-DMA,
 // natural-order swizzle (swz_x) for both operands, W rows permuted as in the 4-wave 32x32 kernel, generic 16-column row
 // epilogue.  Benchmark knob 11.  MEASURED (MI355X, M=50208): 15-22% slower than the 16-wave default on every NT shape
@@ -1289,6 +1466,15 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
     q.tiles_m = cdiv(q.M, 256);
     q.nwg = 8 * cdiv(q.tiles_m, 8) * q.tiles_n;
     hipLaunchKernelGGL((gemm_nt_w8x32_kernel<EPI>), dim3(q.nwg), dim3(512), 0, s, q);
+    PVRL_LAUNCH_CHECK();
+    return PVRL_OK;
+  }
+  if (t == 13 && p.N % 256 == 0 && p.K % 64 == 0) {
+    GemmNT q = p;
+    q.tiles_n = q.N / 256;
+    q.tiles_m = cdiv(q.M, 256);
+    q.nwg = 8 * cdiv(q.tiles_m, 8) * q.tiles_n;
+    hipLaunchKernelGGL((gemm_nt_rt32_kernel<EPI>), dim3(q.nwg), dim3(256), 0, s, q);
     PVRL_LAUNCH_CHECK();
     return PVRL_OK;
   }

@@ -62,7 +62,7 @@ def main():
         gemm_case(f"nt[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
         gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
     for rep in range(2):
-        for tile, tg in ((3, "256 16 waves"), (8, "ring 256x128 s3"), (5, "w128 8 waves")):
+        for tile, tg in ((3, "256 16 waves"), (13, "4 waves, register-staged, 32x32x16")):
             L.call("pvrl_debug_set_gemm_tile", tile)
             gemm_case(f"ab[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
