@@ -810,6 +810,182 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt_kernel(GemmTN p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Register-transposed staging with EIGHT waves (two per SIMD): wave block 128(n) x 64(k) = 8 x 4 blocks of 16x16x32 MFMAs
+// (128 accumulator registers), 64-row stages (64 KiB, two slots), every lane still transposes one 8(m) x 8(col) block per
+// stage -- half the staging work per MFMA of the four-wave kernels, and a second wave per SIMD to cover LDS / barrier
+// latency (the four-wave kernels need ~2,100 cycles per 1,024-cycle MFMA stage).  One register set, one 64-row stage ahead.
+// MEASURED (same-process A/B, M = 50,208): wfc1 233 vs 247 us, wfc2 237 vs 248, wqkv 189 vs 190, wproj 76 vs 80 against the
+// four-wave 32x32x16 kernel (knob 7); 57.1 vs 57.5 ms per training step -> the default (knob 0 / 8).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RT8_TS = 64;
+constexpr int RT8_OPB = 8 * 256 * 16;                      // 32 KiB per operand and stage: [m / 8][col][8 m]
+constexpr int RT8_STAGE = 2 * RT8_OPB;
+
+__device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, char* smem) {
+  constexpr int TS = RT8_TS, OPB = RT8_OPB, STAGE = RT8_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;                 // 2 x 4 waves: 128 n x 64 k each
+  const int s = pair / p.tiles_nk;
+  const int rem = pair - s * p.tiles_nk;
+  const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int mbeg = s * p.Ms;
+  const int mend = min(p.M, mbeg + p.Ms);
+  const int rows = mend - mbeg;
+  const int q = lane >> 4, i = lane & 15;
+  float* part = p.part + (long)s * p.N * p.K;
+  if (rows <= 0) {                                         // empty slice: its partial tile must still be zero
+    for (int nt = 0; nt < 8; ++nt)
+      for (int kt = 0; kt < 4; ++kt)
+        *reinterpret_cast<f32x4*>(part + (long)(n0 + wn * 128 + nt * 16 + i) * p.K + k0 + wk * 64 + kt * 16 + 4 * q) =
+            (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.cpart && tk == 0 && wk == 0 && q == 0)
+      for (int t = 0; t < 8; ++t) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = 0.f;
+    return;
+  }
+  const int nsteps = (rows + TS - 1) / TS;
+
+  // staging role: waves 0-3 bring the P rows of the stage, waves 4-7 the Q rows; lane = one 8-row x 8-column block
+  const bool isq = wave >= 4;
+  const long ld2 = (isq ? p.ldq : p.ldp) * 2;              // row pitch in bytes
+  const int l256 = (wave & 3) * 64 + lane;
+  const int g = l256 >> 5, cg = l256 & 31;                 // 8-row block of the stage, 8-column group
+  const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + (long)mbeg * ld2;
+  const unsigned loff = (unsigned)(8 * g * ld2 + cg * 16);
+  const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
+  auto gload = [&](u32x4* r, int st) {
+    if ((st + 1) * TS <= rows) {
+      const char* b = ubase + (long)st * TS * ld2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[e]) : "v"(b + e * ld2 + loff) : "memory");
+    } else {                                               // ragged or surplus stage: clamp the row, zero what is outside
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = st * TS + 8 * g + e;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (long)min(max(row, 0), rows - 1) * ld2 + cg * 16);
+        const unsigned keep = row < rows ? 0xffffffffu : 0u;
+        r[e] = v & (u32x4){keep, keep, keep, keep};
+      }
+    }
+  };
+  auto wait_set = [&](u32x4* r) {        // ONE register set, one stage (2,048 MFMA cycles per SIMD) ahead: it has landed
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+  };
+  auto twrite = [&](const u32x4* r, int j, char* slot) {   // column j of the lane's 8: gather its 8 m, store 16 B
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      o[d] = __builtin_amdgcn_perm(r[2 * d + 1][j >> 1], r[2 * d][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+    *reinterpret_cast<u32x4*>(slot + (wr ^ (j << 4))) = o;
+  };
+  // fragment t of a K = 32 step: 16-byte chunk (m-block q, column 16 t + i); the slot swizzle has period 4 in t, and the Q
+  // addresses are the P addresses plus a constant, so four offsets serve all twelve fragments
+  int frd[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int slot = (i & 8) | ((i & 7) ^ ((2 * t + (i >> 3)) & 7));
+    frd[t] = q * 4096 + (slot << 4) + t * 256;
+  }
+  const int pbase = wn * 2048, qbase = OPB + wk * 1024;
+  auto rfrag = [&](const char* slot, int off, int h) { return *reinterpret_cast<const bf16x8*>(slot + off + h * 16384); };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_csum = (p.cpart != nullptr) && (tk == 0) && (wk == 0);
+  bf16x2 ones2;
+  ones2[0] = (bf16)1.0f; ones2[1] = (bf16)1.0f;
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  u32x4 ra[8];
+  // one stage: two K = 32 MFMA steps from slot `rs`; the 8 transposed columns of register set r go to slot `ws`
+  auto step = [&](const char* rs, const u32x4* r, char* ws) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 qf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) qf[t] = rfrag(rs + qbase, frd[t], h);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8 pf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pf[t] = rfrag(rs + pbase + half * 1024, frd[t], h);
+        if (do_csum) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              cacc[4 * half + nt] =
+                  __builtin_amdgcn_fdot2_f32_bf16((bf16x2){pf[nt][2 * d], pf[nt][2 * d + 1]}, ones2, cacc[4 * half + nt], false);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            acc[4 * half + nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kt], pf[nt], acc[4 * half + nt][kt], 0, 0, 0);
+          if (nt & 1) twrite(r, 4 * h + 2 * half + (nt >> 1), ws);
+        }
+      }
+    }
+  };
+
+  char* slot0 = smem;
+  char* slot1 = smem + STAGE;
+  gload(ra, 0);
+  wait_set(ra);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) twrite(ra, j, slot0);
+  gload(ra, 1);
+  // invariant at the top of stage st: slot st % 2 is completed by the barrier, ra holds stage st + 1 (in flight)
+  for (int st = 0; st < nsteps; st += 2) {
+    lds_barrier();
+    wait_set(ra);
+    step(slot0, ra, slot1);                                // compute stage st from slot0, stage st + 1 -> slot1
+    gload(ra, st + 2);
+    if (st + 1 >= nsteps) break;
+    lds_barrier();
+    wait_set(ra);
+    step(slot1, ra, slot0);                                // compute stage st + 1 from slot1, stage st + 2 -> slot0
+    gload(ra, st + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int n = n0 + wn * 128 + nt * 16 + i;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k0 + wk * 64 + kt * 16 + 4 * q) = acc[nt][kt];
+  }
+  if (do_csum) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v = cacc[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_rt8_kernel(GemmTN p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT8_STAGE];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int pair = xcd * p.Ms_pairs + jj;
+  if (jj >= p.Ms_pairs || pair >= p.npairs) return;
+  tn_rt8_pair(p, pair, smem);
+}
+
 constexpr int RT32_TS = 32;
 constexpr int RT32_OPB = 4 * 256 * 16;                     // 16 KiB per operand and stage
 constexpr int RT32_STAGE = 2 * RT32_OPB;
@@ -1049,6 +1225,19 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_rt32_grouped_kernel(TnGroup g)
   tn_rt32_pair(p, gp - g.first[q], smem);
 }
 
+__global__ __launch_bounds__(512, 2) void gemm_tn_rt8_grouped_kernel(TnGroup g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT8_STAGE];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int gp = xcd * g.per_xcd + jj;
+  if (jj >= g.per_xcd || gp >= g.total) return;
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < TN_GROUP_MAX; ++t)
+    if (t < g.nprob && gp >= g.first[t]) q = t;
+  const GemmTN p = g.prob[q];
+  tn_rt8_pair(p, gp - g.first[q], smem);
+}
+
 // out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
@@ -1111,12 +1300,12 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnReduceGroup g)
 
 // 0 = heuristic (register-transposed 256x256 kernel when N and K are multiples of 256, else 128x128 register-staged),
 // 1 = 128x128 register-staged, 2 = 128x128 LDS-DMA staged, 3 = 256x256 / 16 waves, 4 = 256x256 / 8 waves,
-// 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed with 16x16x32 MFMAs, 7 = the same with 32x32x16 MFMAs
-// (= what the heuristic picks; benchmark / test knob)
+// 5 = 256x256 LDS-DMA ring, 6 = 256x256 register-transposed 4 waves with 16x16x32 MFMAs, 7 = the same with 32x32x16 MFMAs,
+// 8 = register-transposed 8 waves x 128x64 (= what the heuristic picks; benchmark / test knob)
 int g_tn_tile = 0;
 
 bool tn_use_rt(int64_t N, int64_t K) {
-  return (g_tn_tile == 0 || g_tn_tile == 6 || g_tn_tile == 7) && (N % 256 == 0) && (K % 256 == 0);
+  return (g_tn_tile == 0 || g_tn_tile == 6 || g_tn_tile == 7 || g_tn_tile == 8) && (N % 256 == 0) && (K % 256 == 0);
 }
 
 }  // namespace
@@ -1174,7 +1363,8 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
     p.tiles_nk = (int)(N / 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = cdiv(p.npairs, 8);
-    if (g_tn_tile != 6) hipLaunchKernelGGL(gemm_tn_rt32_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
+    if (g_tn_tile == 0 || g_tn_tile == 8) hipLaunchKernelGGL(gemm_tn_rt8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
+    else if (g_tn_tile != 6) hipLaunchKernelGGL(gemm_tn_rt32_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_rt_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(256), 0, s, p);
   } else if (g_tn_tile == 5 && (N % 256 == 0) && (K % 256 == 0) && (M % 64 == 0)) {
     p.tiles_k = (int)(K / 256);
@@ -1283,7 +1473,8 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
   g.first[nprob] = first;
   g.total = first;
   g.per_xcd = cdiv(first, 8);
-  hipLaunchKernelGGL(gemm_tn_rt32_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(256), 0, s, g);
+  if (g_tn_tile == 0 || g_tn_tile == 8) hipLaunchKernelGGL(gemm_tn_rt8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_rt32_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(256), 0, s, g);
   PVRL_LAUNCH_CHECK();
   static_assert(TN_RED_MAX >= TN_GROUP_MAX, "reduce table too small");
   TnReduceGroup r = {};

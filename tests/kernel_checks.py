@@ -180,7 +180,7 @@ def check_gemm_tn_variants():
             out.append((f"gemm_tn[{name}] dW", rel(dW, ref), 1e-4))
             out.append((f"gemm_tn[{name}] dbias", rel(db, bf(P).sum(0)), 1e-4))
         # the 4-wave 256x256 kernels need M % 64 == 0; slices of 2, 4, ... stages and empty slices
-        for knob, name in ((5, "ring"), (6, "rt"), (7, "rt32")):
+        for knob, name in ((5, "ring"), (6, "rt"), (7, "rt32"), (8, "rt8")):
             L.call("pvrl_debug_set_gemm_tn_tile", knob)
             for (M2, N2, K2, sp) in [(1152, 512, 256, 8), (4160, 256, 768, 16), (128, 256, 256, 8), (6400, 768, 768, 32),
                                      (3200, 768, 256, 9 if knob >= 6 else 8)] + ([(1111, 512, 256, 5), (1569, 256, 256, 3), (40, 256, 512, 4)] if knob >= 6 else []):

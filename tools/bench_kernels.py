@@ -101,9 +101,9 @@ def main():
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
-    for tile in (6, 7, 6, 7):
+    for tile in (7, 8, 7, 8):
         L.call("pvrl_debug_set_gemm_tn_tile", tile)
-        tg = {1: "128x128 tr-read", 0: "default", 6: "rt 16x16x32", 7: "rt 32x32x16"}[tile]
+        tg = {1: "128x128 tr-read", 0: "default", 6: "rt 16x16x32", 7: "rt 32x32x16", 8: "rt 8 waves"}[tile]
         tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
         tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
         tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
