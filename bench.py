@@ -253,17 +253,19 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_i_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
+    (profiles/r1_j_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
     A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
-    path = os.path.join(ROOT, "profiles", "r1_i_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_j_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
     epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
     if kernel.startswith("gemm_tn"):
-        want = "gemm_tn_rt32_grouped_kernel" if "grouped" in kernel else "gemm_tn_rt32_kernel"
-        if want not in t:
+        cands = ([k for k in t if k.startswith("gemm_tn_") and k.endswith("grouped_kernel")] if "grouped" in kernel else
+                 [k for k in t if k.startswith("gemm_tn_") and not k.endswith("grouped_kernel")])
+        if not cands:
             return None
+        want = max(cands, key=lambda k: t[k].get("launches", 0))
         b = t[want]["hbm_bytes_per_launch"]
         red = t.get("tn_reduce_kernel")
         if red:
