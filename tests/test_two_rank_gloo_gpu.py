@@ -1,0 +1,68 @@
+"""The N > 1 training path on ONE GPU: two processes (gloo backend, both on cuda:0) run data-parallel steps through
+GradReducer -- per-block all-reduce from the engine's gradient hook -- for enough steps that the encoder is captured into
+HIP graphs and the backward runs as one graph PER BLOCK with the hook between replays (engine.GraphReplay, staged).  After
+each step the all-reduced gradient buffer of rank 0 must equal the SUM of the two ranks' own single-process gradients, and
+the two ranks must hold identical buffers.  (RCCL itself needs one GPU per rank: an 8-GPU node is only available to the
+driver; this covers everything above the collective.)"""
+import os
+import socket
+
+import pytest
+import torch
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    import e2e_checks as ec
+    from procedurevrl_amd import distributed as du
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.functional import kl_topk_loss
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    cfg = ec.make_cfg(2, 32, 64)
+    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1)).to("cuda:0").train()
+    vt = model.model
+    with torch.no_grad():
+        for blk in vt.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    g = torch.Generator(device="cuda:0").manual_seed(100 + rank)            # a different batch per rank
+    x = torch.randn(4, 3, 8, 32, 32, device="cuda:0", generator=g)
+    teacher = torch.randn(4, 64, device="cuda:0", generator=g) * 3
+
+    def step(reducer):
+        model.zero_grad(set_to_none=True)
+        kl_topk_loss(model(x), teacher, 5).backward()
+        if reducer is not None:
+            reducer.finish()
+        return vt.adopt_grads().flat.clone()
+
+    own = step(None)                                                         # this rank's gradients, no communication
+    reducer = du.GradReducer(vt)
+    assert reducer.enabled and vt.engine.grad_hook is not None
+    res = []
+    for _ in range(vt.engine.GRAPH_WARMUP + 3):                              # eager, eager, capture (staged), replay, replay
+        res.append(step(reducer))
+    staged = any("bwd_staged" in g for g in vt.engine._graphs.values())
+    torch.save(dict(own=own.cpu(), reduced=[r.cpu() for r in res], staged=staged), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_steps_with_staged_graphs(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert r0["staged"] and r1["staged"], "the backward was not captured as per-block graphs"
+    want = r0["own"] + r1["own"]
+    scale = float(want.abs().max())
+    for k, (a, b) in enumerate(zip(r0["reduced"], r1["reduced"])):
+        assert torch.equal(a, b), f"step {k}: ranks disagree after the all-reduce"
+        err = float((a - want).abs().max()) / scale
+        assert err <= 1e-6, f"step {k}: all-reduced gradients differ from the sum of the ranks' gradients ({err:.2e})"
