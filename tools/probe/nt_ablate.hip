@@ -255,6 +255,12 @@ int main() {
                 t5 = run<5>(p, 20);
     printf("N=%d K=%d  full %.1f us (%.0f TF/s) | no-DMA %.1f | no-LDS-read %.1f | no-MFMA %.1f | no-barrier %.1f | MFMA-only %.1f (%.0f TF/s)\n",
            N, K, t0, fl / t0 / 1e6, t1, t2, t3, t4, t5, fl / t5 / 1e6);
+    if (N == 768) {   // how much does the ragged third round cost?  510 tiles (two full rounds of 256 CUs) against 591
+      P pm = p; pm.M = 170 * 256; pm.tiles_m = 170;
+      const float tm = run<0>(pm, 20);
+      printf("   M = 43,520 (510 tiles = 1.99 rounds): %.1f us -> %.3f us per tile; M = 50,208 (591 tiles = 2.31 rounds): %.1f us -> %.3f us per tile\n",
+             tm, tm / 510, t0, t0 / 591);
+    }
     if (N == 768) { for (int sp = 2; sp <= 4; ++sp) { if ((K / 64) % sp) continue; const float ts = run_split(p, 20, sp); printf("%.1f us (full %.1f)\n", ts, t0); } }
     hipFree(A); hipFree(W); hipFree(O); hipFree(WS);
   }
