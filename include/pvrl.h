@@ -62,8 +62,8 @@ int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t 
  * Backward of nn.Linear / the patch-embed conv (loss.backward(), tools/train_net.py:176-181).
  * N % 128 == 0, K % 128 == 0.  M is cut into `splits` slices whose fp32 partial tiles a second kernel sums
  * (deterministic, no atomics): take splits = pvrl_gemm_tn_plan_splits(M, N, K) (the count that fills the 256 CUs
- * for the kernel the shape selects: N, K multiples of 256 -> 256x256 register-transposed kernel, any splits >= 1;
- * otherwise the 128x128 kernel, splits a positive multiple of 8 = one slice per XCD).
+ * for the kernel the shape selects: N * K >= 256 * 256 -> 256x256 register-transposed 8-wave kernel, any splits >= 1, half
+ * tiles staged with zero columns; smaller shapes the 128x128 kernel, splits a positive multiple of 8 = one slice per XCD).
  * workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
 int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K);
 int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
@@ -75,7 +75,7 @@ int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, in
  * loss.backward(), tools/train_net.py:176-181): the (row slice, 256x256 tile) work items of all problems share the 256 CUs,
  * so every problem is cut into the same small number of slices (pvrl_gemm_tn_grouped_plan_splits) instead of the 7-28 a
  * lone dW needs -- longer reduction loops, less fp32 partial traffic.  1 <= nprob <= 8, every N and K a multiple of
- * 256, M >= 1 (else PVRL_EINVAL: use pvrl_gemm_tn_bf16 per problem).  Semantics per problem as pvrl_gemm_tn_bf16;
+ * 128 (half tiles are staged with zero columns), M >= 1 (else PVRL_EINVAL: use pvrl_gemm_tn_bf16 per problem).  Semantics per problem as pvrl_gemm_tn_bf16;
  * deterministic.  workspace >= pvrl_gemm_tn_grouped_workspace_bytes(nprob, problems, splits). */
 typedef struct pvrl_tn_problem {
   const void* P; int64_t ldp;     /* bf16 [M, N] */

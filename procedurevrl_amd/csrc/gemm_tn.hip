@@ -831,17 +831,22 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   const int rem = pair - s * p.tiles_nk;
   const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
+  // N and K are multiples of 128, not necessarily of 256: the last tile along either may be half a tile.  Its missing columns
+  // are staged as zeros and the two (n) or four (k) waves that own them skip their stores.
+  const bool nfull = n0 + 256 <= p.N, kfull = k0 + 256 <= p.K;
+  const bool n_ok = nfull || wn == 0, k_ok = kfull || wk < 2;
   const int mbeg = s * p.Ms;
   const int mend = min(p.M, mbeg + p.Ms);
   const int rows = mend - mbeg;
   const int q = lane >> 4, i = lane & 15;
   float* part = p.part + (long)s * p.N * p.K;
   if (rows <= 0) {                                         // empty slice: its partial tile must still be zero
-    for (int nt = 0; nt < 8; ++nt)
-      for (int kt = 0; kt < 4; ++kt)
-        *reinterpret_cast<f32x4*>(part + (long)(n0 + wn * 128 + nt * 16 + i) * p.K + k0 + wk * 64 + kt * 16 + 4 * q) =
-            (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.cpart && tk == 0 && wk == 0 && q == 0)
+    if (n_ok && k_ok)
+      for (int nt = 0; nt < 8; ++nt)
+        for (int kt = 0; kt < 4; ++kt)
+          *reinterpret_cast<f32x4*>(part + (long)(n0 + wn * 128 + nt * 16 + i) * p.K + k0 + wk * 64 + kt * 16 + 4 * q) =
+              (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.cpart && tk == 0 && wk == 0 && q == 0 && n_ok)
       for (int t = 0; t < 8; ++t) p.cpart[(long)s * p.N + n0 + wn * 128 + t * 16 + i] = 0.f;
     return;
   }
@@ -855,8 +860,10 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + (long)mbeg * ld2;
   const unsigned loff = (unsigned)(8 * g * ld2 + cg * 16);
   const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
+  const bool colok = (isq ? kfull : nfull) || cg < 16;        // this lane's 8 columns exist
+  const bool tile_full = isq ? kfull : nfull;                 // wave-uniform (waves 0-3 stage P, 4-7 stage Q)
   auto gload = [&](u32x4* r, int st) {
-    if ((st + 1) * TS <= rows) {
+    if ((st + 1) * TS <= rows && tile_full) {
       const char* b = ubase + (long)st * TS * ld2;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -865,8 +872,8 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int row = st * TS + 8 * g + e;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (long)min(max(row, 0), rows - 1) * ld2 + cg * 16);
-        const unsigned keep = row < rows ? 0xffffffffu : 0u;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (long)min(max(row, 0), rows - 1) * ld2 + (colok ? cg : 0) * 16);
+        const unsigned keep = (row < rows && colok) ? 0xffffffffu : 0u;
         r[e] = v & (u32x4){keep, keep, keep, keep};
       }
     }
@@ -960,14 +967,16 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if (n_ok && k_ok) {
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    const int n = n0 + wn * 128 + nt * 16 + i;
+    for (int nt = 0; nt < 8; ++nt) {
+      const int n = n0 + wn * 128 + nt * 16 + i;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-      *reinterpret_cast<f32x4*>(part + (long)n * p.K + k0 + wk * 64 + kt * 16 + 4 * q) = acc[nt][kt];
+      for (int kt = 0; kt < 4; ++kt)
+        *reinterpret_cast<f32x4*>(part + (long)n * p.K + k0 + wk * 64 + kt * 16 + 4 * q) = acc[nt][kt];
+    }
   }
-  if (do_csum) {
+  if (do_csum && n_ok) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float v = cacc[t];
@@ -1305,7 +1314,9 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnReduceGroup g)
 int g_tn_tile = 0;
 
 bool tn_use_rt(int64_t N, int64_t K) {
-  return (g_tn_tile == 0 || g_tn_tile == 6 || g_tn_tile == 7 || g_tn_tile == 8) && (N % 256 == 0) && (K % 256 == 0);
+  if ((g_tn_tile == 0 || g_tn_tile == 8) && (N % 128 == 0) && (K % 128 == 0) && N * K >= 256 * 256)
+    return true;     // the 8-wave kernel stages half tiles (N or K = 128 mod 256) with zero columns
+  return (g_tn_tile == 6 || g_tn_tile == 7) && (N % 256 == 0) && (K % 256 == 0);
 }
 
 }  // namespace
@@ -1316,7 +1327,7 @@ extern "C" int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K) {
   if (N <= 0 || K <= 0 || (N % 128) || (K % 128)) return PVRL_EINVAL;
   if (tn_use_rt(N, K)) {
     // one workgroup per CU and ONE round: as many (slice, tile) pairs as fit the 256 CUs, slices of >= 64 rows
-    const int64_t tiles = (N / 256) * (K / 256);
+    const int64_t tiles = cdiv(N, 256) * cdiv(K, 256);
     int64_t s = 256 / tiles;
     const int64_t smax = M / 64;
     if (s > smax) s = smax;
@@ -1359,8 +1370,8 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   // only reachable through the benchmark knob
   const bool big = g_tn_tile == 3 && (N % 256 == 0) && (K % 256 == 0);
   if (use_rt) {
-    p.tiles_k = (int)(K / 256);
-    p.tiles_nk = (int)(N / 256) * p.tiles_k;
+    p.tiles_k = (int)cdiv(K, 256);
+    p.tiles_nk = (int)cdiv(N, 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = cdiv(p.npairs, 8);
     if (g_tn_tile == 0 || g_tn_tile == 8) hipLaunchKernelGGL(gemm_tn_rt8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
@@ -1407,14 +1418,15 @@ bool tn_group_ok(int nprob, const pvrl_tn_problem* pr) {
   if (nprob < 1 || nprob > TN_GROUP_MAX || !pr) return false;
   for (int i = 0; i < nprob; ++i) {
     const pvrl_tn_problem& q = pr[i];
-    if (!q.P || !q.Q || !q.dW || q.M < 1 || q.N <= 0 || q.K <= 0 || (q.N % 256) || (q.K % 256)) return false;
+    if (!q.P || !q.Q || !q.dW || q.M < 1 || q.N <= 0 || q.K <= 0 || (q.N % 128) || (q.K % 128)) return false;
+    if (((q.N % 256) || (q.K % 256)) && g_tn_tile != 0 && g_tn_tile != 8) return false;   // half tiles: 8-wave kernel only
     if ((q.ldp % 8) || (q.ldq % 8) || ((uintptr_t)q.P % 16) || ((uintptr_t)q.Q % 16)) return false;
   }
   return true;
 }
 int64_t tn_group_tiles(int nprob, const pvrl_tn_problem* pr) {
   int64_t t = 0;
-  for (int i = 0; i < nprob; ++i) t += (pr[i].N / 256) * (pr[i].K / 256);
+  for (int i = 0; i < nprob; ++i) t += cdiv(pr[i].N, 256) * cdiv(pr[i].K, 256);
   return t;
 }
 }  // namespace
@@ -1463,8 +1475,8 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
     p.cpart = q.dbias ? w : nullptr;
     w += splits * q.N;
     p.zero_page = nullptr;
-    p.tiles_k = (int)(q.K / 256);
-    p.tiles_nk = (int)(q.N / 256) * p.tiles_k;
+    p.tiles_k = (int)cdiv(q.K, 256);
+    p.tiles_nk = (int)cdiv(q.N, 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = 0;
     g.first[i] = first;

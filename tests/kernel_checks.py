@@ -148,7 +148,8 @@ def check_gemm_tn():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(3)
     out = []
-    for (M, N, K, splits) in [(96, 128, 128, 8), (1000, 768, 768, 16), (5000, 256, 384, None), (333, 128, 256, 24)]:
+    for (M, N, K, splits) in [(96, 128, 128, 8), (1000, 768, 768, 16), (5000, 256, 384, None), (333, 128, 256, 24),
+                              (1569, 384, 1152, None), (700, 640, 128, None), (2000, 1152, 384, 5)]:   # half tiles (N or K = 128 mod 256)
         P = torch.randn(M, N, generator=g)
         Q = torch.randn(M, K, generator=g)
         ref = bf(P).t() @ bf(Q)

@@ -38,7 +38,7 @@ def test_pure_size_queries_run_without_a_gpu():
 def test_grouped_weight_gradient_plan_runs_without_a_gpu():
     """pvrl_gemm_tn_grouped_plan_splits / _workspace_bytes are pure host functions: a transformer block's seven weight
     gradients (153 tiles of 256x256) are cut into 5 row slices = 765 work items = 2.99 rounds of 256 CUs; shapes that are
-    not multiples of 256, an empty list and more than 8 problems are refused."""
+    not multiples of 128, an empty list and more than 8 problems are refused."""
     import ctypes as C
     L = _lib.lib()
     M = 50208
@@ -50,7 +50,9 @@ def test_grouped_weight_gradient_plan_runs_without_a_gpu():
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) == 5
     want = sum(5 * (N * K + N) * 4 for N, K in dims)
     assert L.call("pvrl_gemm_tn_grouped_workspace_bytes", len(dims), ap, 5) == want
-    arr[2].N = 640                                            # not a multiple of 256
+    arr[2].N = 640                                            # half tiles (128 mod 256) are staged with zero columns
+    assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) >= 1
+    arr[2].N = 600                                            # not a multiple of 128
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", len(dims), ap) == -1
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", 0, ap) == -1
     assert L.call("pvrl_gemm_tn_grouped_plan_splits", 9, ap) == -1
