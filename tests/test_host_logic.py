@@ -300,7 +300,7 @@ def test_spatial_sampling_params_properties():
 
 def test_tn_split_plan_properties():
     """pvrl_gemm_tn_plan_splits (a pure host function of the C ABI, callable without a GPU): one round of <= 256 workgroups for
-    the 256x256 kernel, a multiple of 8 slices for the 128x128 kernel, never more slices than 64-row blocks."""
+    the 256x256 kernel (N * K >= 256 * 256), a multiple of 8 slices for the 128x128 kernel, never more slices than 64-row blocks."""
     from hypothesis import given, settings, strategies as st
     from procedurevrl_amd._lib import lib
     L = lib()
@@ -311,8 +311,8 @@ def test_tn_split_plan_properties():
         N, K = 128 * n, 128 * k
         s = L.call("pvrl_gemm_tn_plan_splits", M, N, K)
         assert s >= 1
-        if N % 256 == 0 and K % 256 == 0:
-            tiles = (N // 256) * (K // 256)
+        if N * K >= 256 * 256:                       # 256x256 8-wave kernel; half tiles count as tiles
+            tiles = -(-N // 256) * -(-K // 256)
             assert s == 1 or (s * tiles <= 256 and s <= max(1, M // 64))
         else:
             assert s % 8 == 0 and (s == 8 or M // s >= 256)
