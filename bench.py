@@ -38,9 +38,17 @@ def main():
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks, one process per GPU (the reference's launch_job spawns one
+        # process per GPU the same way, lib/utils/misc.py:272-300 / tools/run_net.py:26-31) by re-executing under
+        # torch.distributed.run exactly as the driver would launch it.
+        return spawn_ranks(args.gpus)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("PVRL_DIST_BACKEND", "nccl")          # "gloo" = functional test of the N > 1 path on one GPU
@@ -120,7 +128,7 @@ def main():
     optimizer = construct_optimizer(model, cfg)
     set_lr(optimizer, cfg.SOLVER.BASE_LR)
     optimizer.grad_scale = 1.0 / world
-    reducer = GradReducer(vt)
+    reducer = GradReducer(vt, find_unused=False)     # every parameter gets a gradient every step: no per-step host sync
 
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -228,6 +236,9 @@ def main():
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "comm": None if world == 1 else {"backend": backend, "ranks": dist.get_world_size(),
+                                             "rccl": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None,
+                                             "grad_allreduce_mb": round(vt.grad_store().flat.numel() * 4 / 2 ** 20, 1)},
             "loss": float(loss.item()), "hip_graphs": bool(graphs), "hbm_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
             "end_to_end": {"tflops_per_gpu": round(value / world * wtrain / 1e12, 2),
@@ -249,6 +260,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic(kernel):
@@ -285,10 +309,15 @@ def pmc_traffic(kernel):
 def cpu_baseline(args):
     """The CPU restatement of the same training step (oracle/, pinned to the reference by golden vectors),
     timed on this host's cores on a bounded sample: the checker timed as a baseline, never the product."""
-    import torch
     from oracle import timesformer_oracle as orc
-    return orc.timed_train_step(clips=max(1, 32 // args.frames), frames=args.frames, classes=args.classes, threads=16, repeats=3)
+    r = orc.timed_train_step(clips=max(1, 32 // args.frames), frames=args.frames, classes=args.classes, threads=16, repeats=3)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count()
+    r["sample"] += f"; {r['cores']} threads of the {avail} host cores visible to this process"
+    return r
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -9,10 +9,23 @@
 
 namespace {
 
+// The scalar constants are formed on the host in double and rounded to fp32 once, which is what torch.optim does (Python
+// floats 1 - lr*wd, 1 - beta1, 1 - beta2, lr / bias_correction1, sqrt(bias_correction2) handed to fp32 tensor ops):
+//   p *= decay (AdamW) | g += wd * p (Adam);  m = m + w1 * (g - m)  [Tensor.lerp_];  v = b2 * v + w2 * g * g;
+//   p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)
+struct AdamConst { float decay, wd, w1, b2, w2, step_size, bc2_sqrt, eps, gscale; int decoupled; };
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamConst& c) {
+  float gg = g * c.gscale;
+  if (c.decoupled) p *= c.decay; else gg += c.wd * p;
+  m = m + c.w1 * (gg - m);
+  v = c.b2 * v + c.w2 * gg * gg;
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p -= c.step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                   float gscale, int decoupled) {
+                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamConst c) {
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
     if (i + 4 <= n) {
       f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
@@ -21,36 +34,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float gg = gv[e] * gscale;
-        if (decoupled) pv[e] *= (1.0f - lr * wd); else gg += wd * pv[e];
-        mv[e] = b1 * mv[e] + (1.0f - b1) * gg;
-        vv[e] = b2 * vv[e] + (1.0f - b2) * gg * gg;
-        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-        pv[e] -= (lr / bc1) * (mv[e] / denom);
+        float pe = pv[e], me = mv[e], ve = vv[e];
+        adam_one(pe, gv[e], me, ve, c);
+        pv[e] = pe; mv[e] = me; vv[e] = ve;
       }
       *reinterpret_cast<f32x4*>(p + i) = pv;
       *reinterpret_cast<f32x4*>(m + i) = mv;
       *reinterpret_cast<f32x4*>(v + i) = vv;
     } else {
-      for (long j = i; j < n; ++j) {
-        float gg = g[j] * gscale, pj = p[j];
-        if (decoupled) pj *= (1.0f - lr * wd); else gg += wd * pj;
-        const float mj = b1 * m[j] + (1.0f - b1) * gg;
-        const float vj = b2 * v[j] + (1.0f - b2) * gg * gg;
-        m[j] = mj; v[j] = vj;
-        p[j] = pj - (lr / bc1) * (mj / (sqrtf(vj) / bc2_sqrt + eps));
-      }
+      for (long j = i; j < n; ++j) adam_one(p[j], g[j], m[j], v[j], c);
     }
   }
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float momentum,
-                                                  float dampening, float wd, int nesterov, int first, float gscale) {
+                                                  float one_minus_damp, float wd, int nesterov, int first, float gscale) {
+  // torch.optim.SGD: g += wd * p;  buf = g (first update) | momentum * buf + (1 - dampening) * g;
+  //                  g = g + momentum * buf (nesterov) | buf;  p -= lr * g
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gg = g[i] * gscale + wd * p[i];
     if (momentum != 0.f) {
-      const float b = first ? gg : momentum * buf[i] + (1.0f - dampening) * gg;
+      const float b = first ? gg : momentum * buf[i] + one_minus_damp * gg;
       buf[i] = b;
       gg = nesterov ? gg + momentum * b : b;
     }
@@ -60,31 +65,35 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 }  // namespace
 
-extern "C" int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int64_t step, float gscale, int decoupled,
+extern "C" int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int64_t step, double gscale, int decoupled,
                               void* stream) {
   if (n <= 0) return PVRL_OK;
   if (!p || !g || !m || !v || step < 1) return PVRL_EINVAL;
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2 = 1.0f - powf(beta2, (float)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  AdamConst c;
+  c.decay = (float)(1.0 - lr * weight_decay); c.wd = (float)weight_decay;
+  c.w1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.w2 = (float)(1.0 - beta2);
+  c.step_size = (float)(lr / bc1); c.bc2_sqrt = (float)sqrt(bc2); c.eps = (float)eps; c.gscale = (float)gscale;
+  c.decoupled = decoupled;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
-                     beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), gscale, decoupled);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, c);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
 
-extern "C" int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                             float dampening, float weight_decay, int nesterov, int first_step, float gscale,
+extern "C" int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum,
+                             double dampening, double weight_decay, int nesterov, int first_step, double gscale,
                              void* stream) {
   if (n <= 0) return PVRL_OK;
-  if (!p || !g || (momentum != 0.f && !buf)) return PVRL_EINVAL;
+  if (!p || !g || (momentum != 0.0 && !buf)) return PVRL_EINVAL;
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, lr,
-                     momentum, dampening, weight_decay, nesterov, first_step, gscale);
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, (float)lr,
+                     (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step, (float)gscale);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -11,6 +11,8 @@ shapes and statistics (SURVEY.md 8d): frames ~ N(0,1); ids = [49406, U{1..49405}
 clip_vis_feat ~ N(0, 0.4^2).  Everything is created directly on `device` (inputs resident in HBM).
 """
 import torch
+import torch.distributed as dist
+from torch.utils.data.distributed import DistributedSampler
 
 
 def synthetic_label_emb(num_classes, dim=512, seed=0):
@@ -50,7 +52,57 @@ class SyntheticHowTo100M(torch.utils.data.Dataset):
         return frames, torch.tensor(0), torch.tensor(index), meta
 
 
+class SyntheticTestClips(torch.utils.data.Dataset):
+    """Multi-view test split: entry `i` is view `i % num_clips` of video `i // num_clips` (the reference's test
+    datasets index clips that way; `TestMeter.update_stats` recovers the video as `clip_id // num_clips`,
+    lib/utils/meters.py:104-131).  Frames of one video share a per-video pattern so the ensemble is meaningful."""
+
+    def __init__(self, cfg, num_videos=8, seed=0):
+        self.cfg = cfg
+        self.num_clips = cfg.TEST.NUM_ENSEMBLE_VIEWS * cfg.TEST.NUM_SPATIAL_CROPS
+        self.n = num_videos * self.num_clips
+        self.seed = seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, index):
+        vid = index // self.num_clips
+        T, S = self.cfg.DATA.NUM_FRAMES, self.cfg.DATA.TEST_CROP_SIZE
+        gv = torch.Generator().manual_seed(self.seed * 100003 + 7919 * vid)
+        base = torch.randn(3, T, S, S, generator=gv)
+        g = torch.Generator().manual_seed(self.seed * 100003 + 31 * index + 1)
+        frames = base + 0.5 * torch.randn(3, T, S, S, generator=g)
+        label = int(torch.randint(0, max(1, int(self.cfg.MODEL.NUM_CLASSES)), (1,), generator=gv))
+        return frames, torch.tensor(label), torch.tensor(index), {}
+
+
+def create_sampler(dataset, shuffle, cfg):
+    """lib/datasets/utils.py:358-370: a DistributedSampler whenever the job has more than one GPU process."""
+    if cfg.NUM_GPUS * max(1, cfg.NUM_SHARDS) > 1 and dist.is_available() and dist.is_initialized():
+        return DistributedSampler(dataset, shuffle=shuffle)
+    return None
+
+
 def construct_loader(cfg, split="train", num_videos=None, batch_size=None):
-    ds = SyntheticHowTo100M(cfg, num_videos or int(cfg.SYNTHETIC.NUM_VIDEOS))
-    bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
-    return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=False, num_workers=0, drop_last=True)
+    """lib/datasets/loader.py:85-138 for the synthetic stand-in datasets: per-process batch = BATCH_SIZE / NUM_GPUS,
+    train shuffles and drops the last ragged batch, test does neither; ranks see disjoint samples through the sampler."""
+    assert split in ("train", "val", "test")
+    n = num_videos or int(cfg.SYNTHETIC.NUM_VIDEOS)
+    if split == "test":
+        ds = SyntheticTestClips(cfg, n)
+        bs = batch_size or max(1, int(cfg.TEST.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
+        shuffle, drop_last = False, False
+    else:
+        ds = SyntheticHowTo100M(cfg, n)
+        bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
+        shuffle, drop_last = split == "train", split == "train"
+    sampler = create_sampler(ds, shuffle, cfg)
+    return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(False if sampler else shuffle), sampler=sampler,
+                                       num_workers=0, drop_last=drop_last)
+
+
+def shuffle_dataset(loader, cur_epoch):
+    """lib/datasets/loader.py:140-157: DistributedSampler reshuffles per epoch through set_epoch."""
+    if isinstance(loader.sampler, DistributedSampler):
+        loader.sampler.set_epoch(cur_epoch)

@@ -127,51 +127,87 @@ def init_distributed_training(cfg):
 class GradReducer:
     """Sum the flat gradient buffer over ranks, overlapped with the encoder backward.
 
-    `attach(vt)` installs `engine.grad_hook`; during loss.backward() the hook fires after each block
-    (last block first) and launches an async all-reduce of that block's contiguous slice.
-    `finish()` reduces whatever is left (embeddings, head, order transformer: they sit outside the
-    block ranges) and waits.  Averaging (1/world) is folded into the optimiser's `grad_scale`.
+    Installs `engine.grad_hook`; during loss.backward() the hook fires after each block (last block first) and
+    launches an async all-reduce of that block's contiguous slice on a dedicated communication stream (ordered behind
+    the main stream and the weight-gradient side stream, and behind nothing later).  `finish()` reduces whatever is
+    left (embeddings, head, order transformer: they sit outside the block ranges) and makes the main stream wait.
+    Averaging (1/world) is folded into the optimiser's `grad_scale`.
+
+    Gradient accumulation (tools/train_net.py:176-192): `sync = False` on the non-final micro-iterations -- DDP's
+    `no_sync()` -- keeps the hook silent so gradients accumulate locally, and the accumulated buffer is reduced ONCE
+    during the final micro-iteration's backward.
+
+    `find_unused` (the reference builds DDP with find_unused_parameters=True, lib/models/build.py:51): a parameter
+    that received no gradient on ANY rank keeps `.grad is None`, so the optimiser skips it exactly as torch.optim
+    does; one that was used on some rank gets the summed gradient on every rank.  The per-parameter "used" flags ride
+    in the tail of the flat buffer (no extra collective); reading them back costs one host sync per step.  With
+    `find_unused=False` (every parameter is known to be used every step) there is no sync.
     """
 
-    def __init__(self, vt, enabled=None):
+    def __init__(self, vt, enabled=None, find_unused=True):
         self.vt = vt
         self.enabled = (get_world_size() > 1) if enabled is None else enabled
+        self.find_unused = find_unused
+        self.sync = True
         self.handles = []
         self.done = []
+        self._comm = None
+        self._masks = {}
         vt.engine.grad_hook = self._hook if self.enabled else None
 
     def _block_range(self, i):
         gs = self.vt.grad_store()
         pre = f"{getattr(self.vt, 'block_prefix', 'blocks.')}{i}."
         idx = [k for k, n in enumerate(gs.names) if n.startswith(pre)]
-        a = gs.offsets[idx[0]]
-        last = idx[-1]
-        b = gs.offsets[last + 1] if last + 1 < len(gs.offsets) else gs.flat.numel()
-        return a, b
+        return gs.span(idx[0])[0], gs.span(idx[-1])[1]
+
+    def _comm_stream(self, device):
+        if self._comm is None or self._comm.device != device:
+            self._comm = torch.cuda.Stream(device=device)
+        return self._comm
+
+    def _reduce(self, t):
+        """async all-reduce of a slice of the flat buffer, ordered after everything enqueued so far on the main stream
+        and on the engine's weight-gradient side stream"""
+        if not t.is_cuda:
+            self.handles.append(dist.all_reduce(t, async_op=True))
+            return
+        comm = self._comm_stream(t.device)
+        comm.wait_event(torch.cuda.current_stream().record_event())
+        side = getattr(self.vt.engine, "_side", None)
+        if side is not None:
+            comm.wait_event(side.record_event())
+        with torch.cuda.stream(comm):
+            self.handles.append(dist.all_reduce(t, async_op=True))
 
     def _hook(self, i):
+        if not self.sync:
+            return
         a, b = self._block_range(i)
-        gs = self.vt.grad_store()
-        side = getattr(self.vt.engine, "_side", None) if getattr(self.vt.engine, "overlap_wgrad", False) else None
-        if side is not None and gs.flat.is_cuda:
-            # block i's weight gradients were produced on the side stream, its LayerNorm gradients on the main one:
-            # order the collective after both
-            side.wait_event(torch.cuda.current_stream().record_event())
-            with torch.cuda.stream(side):
-                self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
-        else:
-            self.handles.append(dist.all_reduce(gs.flat[a:b], async_op=True))
+        self._reduce(self.vt.grad_store().flat[a:b])
         self.done.append((a, b))
 
     def finish(self):
         if not self.enabled:
             return
-        gs = self.vt.adopt_grads()
+        gs0 = self.vt.grad_store()
+        had = [p.grad is not None for p in gs0.params]          # host-side knowledge, before the buffer is adopted
+        gs = self.vt.adopt_grads(keep_none=True)
+        if self.find_unused:
+            key = tuple(had)                 # a pageable host->device copy would block the host until the backward has
+            m = self._masks.get(key)         # drained: the handful of distinct patterns are cached on the device
+            if m is None or m.device != gs.used.device:
+                m = torch.tensor([1.0 if h else 0.0 for h in had], device=gs.used.device)
+                self._masks[key] = m
+            gs.used.copy_(m)
         cur = 0
         for a, b in sorted(self.done) + [(gs.flat.numel(), gs.flat.numel())]:
             if a > cur:
-                self.handles.append(dist.all_reduce(gs.flat[cur:a], async_op=True))
+                self._reduce(gs.flat[cur:a])
             cur = max(cur, b)
         for h in self.handles:
-            h.wait()
+            h.wait()                                            # the current (main) stream waits for the collectives
         self.handles, self.done = [], []
+        used = (gs.used > 0).tolist() if self.find_unused else [True] * len(had)
+        for p, v, u in zip(gs.params, gs.views, used):
+            p.grad = v if u else None

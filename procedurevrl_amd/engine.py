@@ -42,9 +42,17 @@ class GradStore:
         for s in sizes:
             self.offsets.append(off)
             off += (s + 63) // 64 * 64
-        self.flat = torch.zeros(off, device=device, dtype=F32)
+        self.end = off                     # end of the parameter gradients
+        # tail: one float per parameter, "this rank produced a gradient for it" -- summed over ranks inside the last
+        # chunk of the data-parallel all-reduce (distributed.GradReducer, DDP's find_unused_parameters bookkeeping)
+        self.flat = torch.zeros(off + (len(sizes) + 63) // 64 * 64, device=device, dtype=F32)
+        self.used = self.flat[off:off + len(sizes)]
         self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
+
+    def span(self, i):
+        """[a, b) of parameter i in the flat buffer, padding included"""
+        return self.offsets[i], (self.offsets[i + 1] if i + 1 < len(self.offsets) else self.end)
 
     def target(self, p):
         """-> (grad tensor to write into, beta).  beta = 0 overwrites, 1 accumulates."""

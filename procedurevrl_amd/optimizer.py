@@ -32,8 +32,9 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.flat_p = None
         self.buf1 = None   # exp_avg / momentum buffer
         self.buf2 = None   # exp_avg_sq
-        self.steps = 0
-        self.grad_scale = 1.0
+        self.steps = 0             # optimiser steps taken (informational; the arithmetic uses the per-parameter counts)
+        self.param_steps = None    # per parameter of the flat store: updates applied so far (torch.optim's state["step"];
+        self.grad_scale = 1.0      # a parameter without a gradient is skipped and its count does not advance)
 
     # -- flat storage -----------------------------------------------------------------------
     def _ensure_flat(self):
@@ -54,16 +55,23 @@ class FusedOptimizer(torch.optim.Optimizer):
                          else old2.to(gs.flat.device)) if self.method != "sgd" else None
         return gs
 
+    def _steps(self, gs):
+        if self.param_steps is None or len(self.param_steps) != len(gs.params):
+            self.param_steps = [0] * len(gs.params)
+        return self.param_steps
+
     def _runs(self, gs, params, had_grad):
+        """-> [[a, b, step]]: maximal contiguous ranges of the flat buffers whose parameters all have a gradient and have
+        all been updated `step` times before (one kernel launch each; normally ONE range per parameter group)"""
+        ps = self._steps(gs)
         idx = sorted(gs.index[id(p)] for p in params if id(p) in gs.index and had_grad[gs.index[id(p)]])
         runs = []
         for i in idx:
-            a = gs.offsets[i]
-            b = gs.offsets[i + 1] if i + 1 < len(gs.offsets) else gs.flat.numel()
-            if runs and runs[-1][1] == a:
+            a, b = gs.span(i)
+            if runs and runs[-1][1] == a and runs[-1][2] == ps[i]:
                 runs[-1][1] = b
             else:
-                runs.append([a, b])
+                runs.append([a, b, ps[i]])
         return runs
 
     @torch.no_grad()
@@ -79,18 +87,23 @@ class FusedOptimizer(torch.optim.Optimizer):
         base_1 = self.buf1.data_ptr()
         base_2 = self.buf2.data_ptr() if self.buf2 is not None else 0
         vp = ctypes.c_void_p
+        ps = self._steps(gs)
         for g in self.param_groups:
-            for a, b in self._runs(gs, g["params"], had_grad):
+            for a, b, done in self._runs(gs, g["params"], had_grad):
                 n, o = b - a, 4 * a
                 if self.method == "sgd":
                     L.call("pvrl_sgd_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), n, float(g["lr"]),
                            float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]),
-                           1 if g["nesterov"] else 0, 1 if self.steps == 1 else 0, float(self.grad_scale), stream)
+                           1 if g["nesterov"] else 0, 1 if done == 0 else 0, float(self.grad_scale), stream)
                 else:
                     L.call("pvrl_adam_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), vp(base_2 + o), n,
                            float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                           float(g["weight_decay"]), self.steps, float(self.grad_scale),
+                           float(g["weight_decay"]), done + 1, float(self.grad_scale),
                            1 if self.method == "adamw" else 0, stream)
+            for p in g["params"]:
+                i = gs.index.get(id(p))
+                if i is not None and had_grad[i]:
+                    ps[i] += 1
         self._bump(gs)
         return None
 
@@ -110,10 +123,13 @@ class FusedOptimizer(torch.optim.Optimizer):
                 if gs is not None and id(p) in gs.index:
                     i = gs.index[id(p)]
                     a, n = gs.offsets[i], p.numel()
+                    done = self._steps(gs)[i]
+                    if done == 0:
+                        continue                       # torch.optim creates a parameter's state on its first update
                     if self.method == "sgd":
                         sd["state"][k + j] = {"momentum_buffer": self.buf1[a:a + n].view(p.shape).clone()}
                     else:
-                        sd["state"][k + j] = {"step": torch.tensor(float(self.steps)),
+                        sd["state"][k + j] = {"step": torch.tensor(float(done)),
                                               "exp_avg": self.buf1[a:a + n].view(p.shape).clone(),
                                               "exp_avg_sq": self.buf2[a:a + n].view(p.shape).clone()}
             k += len(g["params"])
@@ -123,6 +139,9 @@ class FusedOptimizer(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         gs = self._ensure_flat()
         self.steps = int(sd.get("fused", {}).get("steps", 0))
+        ps = self._steps(gs)
+        for i in range(len(ps)):
+            ps[i] = 0
         k = 0
         for g, pg in zip(self.param_groups, sd["param_groups"]):
             for key, val in pg.items():
@@ -136,10 +155,12 @@ class FusedOptimizer(torch.optim.Optimizer):
                 a, n = gs.offsets[i], p.numel()
                 if "momentum_buffer" in st and st["momentum_buffer"] is not None:
                     self.buf1[a:a + n].copy_(st["momentum_buffer"].reshape(-1))
+                    ps[i] = max(1, self.steps)         # a loaded buffer is never overwritten by the "first step" branch
                 if "exp_avg" in st:
                     self.buf1[a:a + n].copy_(st["exp_avg"].reshape(-1))
                     self.buf2[a:a + n].copy_(st["exp_avg_sq"].reshape(-1))
-                    self.steps = max(self.steps, int(float(st.get("step", 0))))
+                    ps[i] = int(float(st.get("step", 0)))
+                    self.steps = max(self.steps, ps[i])
             k += len(g["params"])
 
 

@@ -56,18 +56,28 @@ def perform_test(test_loader, model, test_meter, cfg):
         labels = labels.to(dev).view(-1)
         video_idx = video_idx.to(dev).view(-1)
         preds = model(inputs)
-        if du.get_world_size() > 1:
+        # gather every rank's predictions for the ensemble (test_net.py:112-113)
+        if du.get_world_size() > 1 and not (cfg.TRAIN.LABEL_EMB == "" and cfg.TRAIN.TEXT != ""):
             preds, labels, video_idx = du.all_gather([preds, labels, video_idx])
         test_meter.update_stats(preds, labels, video_idx)
-    return test_meter.finalize_metrics()
+    test_meter.finalize_metrics(ks=(1, 5))
+    return test_meter
 
 
-def test(cfg, test_loader):
+def test(cfg, test_loader=None):
+    """tools/test_net.py:161-221: `test(cfg)` builds the model, loads the test checkpoint, constructs its own "test"
+    loader and multi-view meter and runs `perform_test`.  (`test_loader` may be injected by tests.)"""
     du.init_distributed_training(cfg)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg)
     cu.load_test_checkpoint(cfg, model)
+    if test_loader is None:
+        from .datasets import construct_loader
+        test_loader = construct_loader(cfg, "test")
     num_clips = cfg.TEST.NUM_ENSEMBLE_VIEWS * cfg.TEST.NUM_SPATIAL_CROPS
-    meter = TestMeter(len(test_loader.dataset) // num_clips, num_clips, cfg.MODEL.NUM_CLASSES,
-                      len(test_loader), ensemble_method=cfg.DATA.ENSEMBLE_METHOD)
-    return perform_test(test_loader, model, meter, cfg)
+    assert len(test_loader.dataset) % num_clips == 0
+    num_cls = cfg.MODEL.NUM_CLASSES if cfg.TRAIN.LABEL_EMB == "" or cfg.TRAIN.TEXT == "" else 1059     # test_net.py:203
+    meter = TestMeter(len(test_loader.dataset) // num_clips, num_clips, num_cls,
+                      len(test_loader), cfg.DATA.MULTI_LABEL, cfg.DATA.ENSEMBLE_METHOD)
+    perform_test(test_loader, model, meter, cfg)
+    return meter

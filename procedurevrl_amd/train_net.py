@@ -17,7 +17,7 @@ from . import checkpoint as cu
 from . import distributed as du
 from . import optimizer as optim
 from .build import build_model
-from .datasets import construct_loader
+from .datasets import construct_loader, shuffle_dataset
 from .vit import pretrain_loss
 
 
@@ -63,8 +63,10 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
         loss, loss1, loss2 = pretrain_loss(pred, teacher_pred, mse, cfg)
         if not accumulate or cur_iter % num_iters == 0:
             optimizer.zero_grad(set_to_none=True)
+        last_micro = not accumulate or (cur_iter + 1) % num_iters == 0
+        reducer.sync = last_micro          # DDP no_sync() on the other micro-iterations: accumulate locally, reduce once
         loss.backward()
-        if not accumulate or (cur_iter + 1) % num_iters == 0:
+        if last_micro:
             reducer.finish()
             optimizer.step()
         with torch.no_grad():
@@ -74,17 +76,17 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
             stats = du.all_reduce_scalars([loss.detach(), (1.0 - c1 / pred.size(0)) * 100.0, (1.0 - c5 / pred.size(0)) * 100.0])
         window.append(stats)
         if (cur_iter + 1) % cfg.LOG_PERIOD == 0 or cur_iter + 1 == data_size:
-            vals = torch.stack(window).median(0).values.tolist()          # one host sync per LOG_PERIOD
-            if any(math.isnan(v) or math.isinf(v) for v in vals):
-                raise RuntimeError("ERROR: Got NaN losses {}".format(time.time()))   # misc.check_nan_losses
+            w = torch.stack(window)
+            vals = torch.cat([w.median(0).values, w[:, 0].isfinite().all().float().view(1)]).tolist()   # one host sync per LOG_PERIOD
+            if vals[3] == 0.0 or any(math.isnan(v) or math.isinf(v) for v in vals):
+                raise RuntimeError("ERROR: Got NaN losses {}".format(time.time()))   # misc.check_nan_losses, on EVERY loss of the window
             now = time.perf_counter()
             dt = (now - t_last) / len(window)
             t_last = now
-            mb = inputs.size(0) * max(cfg.NUM_GPUS, 1)
             log_json_stats({"_type": "train_iter", "epoch": "{}/{}".format(cur_epoch + 1, cfg.SOLVER.MAX_EPOCH),
                             "iter": "{}/{}".format(cur_iter + 1, data_size), "dt": dt, "loss": vals[0],
                             "top1_err": vals[1], "top5_err": vals[2], "lr": lr,
-                            "clips_per_s": mb * inputs.size(1) * world / dt})
+                            "clips_per_s": inputs.size(0) * inputs.size(1) * world / dt})
             window = []
     return None
 
@@ -98,6 +100,7 @@ def train(cfg, max_iters=None):
     reducer = du.GradReducer(model.model)
     train_loader = construct_loader(cfg, "train")
     for cur_epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
+        shuffle_dataset(train_loader, cur_epoch)               # train_net.py:503
         train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_iters)
         if cu.is_checkpoint_epoch(cfg, cur_epoch):
             cu.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch, cfg)

@@ -134,7 +134,7 @@ class VisionTransformer(nn.Module):
             self.order_tfm = OrderTransformer(num_seg=self.order_max_len - 1, tfm_layers=self.order_tfm_layers,
                                               dropout=cfg.MODEL.DROP_E, hidden_size=self.head.weight.shape[0], cfg=cfg)
         else:                 # fine-tuning / zero-shot (vit.py:238-255)
-            emb = torch.load(cfg.DEV.TEST_LANG_EMB)
+            emb = torch.load(cfg.DEV.TEST_LANG_EMB) if isinstance(cfg.DEV.TEST_LANG_EMB, str) else cfg.DEV.TEST_LANG_EMB
             if cfg.DEV.MATCH_LANG_EMB:
                 self.label_emb = emb
                 self.head = nn.Linear(embed_dim, emb.shape[1])
@@ -194,14 +194,17 @@ class VisionTransformer(nn.Module):
     def anchor(self):
         return self.cls_token
 
-    def adopt_grads(self):
+    def adopt_grads(self, keep_none=False):
         """Move gradients that autograd allocated itself (head, small embeddings) into the flat buffer so
-        that every trainable parameter's .grad is a view of one allocation (all-reduce / fused optimiser)."""
+        that every trainable parameter's .grad is a view of one allocation (all-reduce / fused optimiser).
+        A parameter without a gradient gets a zeroed view; with `keep_none` its .grad stays None (the optimiser then
+        skips it, as torch.optim does) and only the buffer is zeroed."""
         gs = self.grad_store()
         for p, v in zip(gs.params, gs.views):
             if p.grad is None:
                 v.zero_()
-                p.grad = v
+                if not keep_none:
+                    p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v

@@ -59,6 +59,55 @@ def _worker(rank, world, port, results):
     used = torch.cat([v.reshape(-1) for v in gs.views])
     out["reducer_all_3"] = bool(torch.all(used == 3.0))
     out["head_adopted"] = vt.head.weight.grad.data_ptr() == gs.views[gs.index[id(vt.head.weight)]].data_ptr()
+    # --- gradient accumulation (tools/train_net.py:176-192) with world > 1: block gradients accumulate locally over the
+    # micro-iterations (reducer.sync = False silences the hook, like DDP.no_sync) and are summed over ranks exactly once
+    for p in gs.params:
+        p.grad = None
+    for p, view in zip(gs.params, gs.views):
+        p.grad = view
+    micro = [1.0 + rank, 10.0 * (1 + rank), 100.0 * (1 + rank)]         # this rank's gradient of three micro-iterations
+    gs.flat.zero_()
+    for k, g in enumerate(micro):
+        red.sync = k == len(micro) - 1
+        gs.flat[:gs.end].add_(g)                                          # loss.backward() accumulating into .grad
+        for i in reversed(range(len(vt.blocks))):
+            vt.engine.grad_hook(i)
+        if red.sync:
+            red.finish()
+    used = torch.cat([v.reshape(-1) for v in gs.views])
+    out["accum_sum"] = sorted(set(used.tolist()))                         # (1+10+100) * (1 + 2) everywhere
+    # --- unused parameters (DDP find_unused_parameters=True, lib/models/build.py:51): a parameter without a gradient on
+    # every rank keeps .grad None; one used on rank 0 only gets the sum on both ranks
+    for p in gs.params:
+        p.grad = None
+    names = gs.names
+    i_none, i_half = names.index("time_embed"), names.index("cls_token")
+    for k, (p, view) in enumerate(zip(gs.params, gs.views)):
+        if k == i_none or (k == i_half and rank == 1):
+            continue
+        view.fill_(float(rank + 1))
+        p.grad = view
+    red.sync = True
+    for i in reversed(range(len(vt.blocks))):
+        vt.engine.grad_hook(i)
+    red.finish()
+    out["unused_none"] = gs.params[i_none].grad is None
+    out["half_used"] = sorted(set(gs.params[i_half].grad.reshape(-1).tolist()))    # rank 0's 1.0 + rank 1's zeros
+    out["others_3"] = all(bool(torch.all(p.grad == 3.0)) for k, p in enumerate(gs.params) if k not in (i_none, i_half))
+    # --- per-rank data sharding (lib/datasets/utils.py:358-370 DistributedSampler, loader.py:140-157 set_epoch)
+    from procedurevrl_amd.config import get_cfg
+    from procedurevrl_amd import datasets as ds
+    cfg = get_cfg()
+    cfg.NUM_GPUS, cfg.TRAIN.BATCH_SIZE, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE = 2, 4, 2, 16
+    cfg.SYNTHETIC.NUM_VIDEOS = 8
+    torch.manual_seed(cfg.RNG_SEED)
+    loader = ds.construct_loader(cfg, "train")
+    seen = []
+    for epoch in range(2):
+        ds.shuffle_dataset(loader, epoch)
+        seen.append([int(i) for _, _, idx, _ in loader for i in idx])
+    out["seen"] = seen
+    out["batch"] = loader.batch_size
     results[rank] = out
     dist.destroy_process_group()
 
@@ -75,3 +124,10 @@ def test_two_rank_gloo():
         assert r["all_reduce_avg"] == 1.5
         assert r["scalars"] == [1.0, 4.0, 1.0]
         assert r["reducer_all_3"] and r["head_adopted"], r
+        assert r["accum_sum"] == [333.0], r["accum_sum"]
+        assert r["unused_none"] and r["half_used"] == [1.0] and r["others_3"], r
+        assert r["batch"] == 2
+    for epoch in range(2):      # the two ranks see disjoint videos that together cover the dataset; epochs are shuffled differently
+        a, b = results[0]["seen"][epoch], results[1]["seen"][epoch]
+        assert not set(a) & set(b) and sorted(a + b) == list(range(8)), (a, b)
+    assert results[0]["seen"][0] != results[0]["seen"][1]

@@ -1,0 +1,104 @@
+"""The fused optimiser step (csrc/optim.hip through optimizer.FusedOptimizer) against torch.optim on CPU fp32.
+
+Reference: lib/models/optimizer.py:91-114 builds torch.optim.SGD(nesterov) / Adam / AdamW over parameter groups with an
+`lr_mult`; tools/train_net.py:123-124 sets the LR every iteration; :176-192 accumulates `num_iters` micro-batches and
+divides the gradients (`p.grad /= num_iters`) before the step.  Here: identical parameters and gradients go through both
+implementations for five steps -- two parameter groups (different lr_mult and weight decay), a changing LR, the
+accumulation division as `grad_scale`, and one parameter whose gradient is missing on one step (torch.optim skips it and
+does not advance its `step`) -- and parameters + optimiser moments must agree to 1e-6 (relative to the tensor's max)."""
+import pytest
+import torch
+
+TOL = 1e-6
+
+
+def _run(method):
+    import e2e_checks as ec
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+    torch.manual_seed(0)
+    cfg = ec.make_cfg(2, 32, 64)
+    cfg.SOLVER.OPTIMIZING_METHOD = method
+    cfg.SOLVER.WEIGHT_DECAY = 1e-2
+    cfg.BN.WEIGHT_DECAY = 3e-3
+    cfg.TRAIN.MULT = 0.1                       # fine-tuning grouping: encoder (lr_mult 0.1) / head + order transformer
+    cfg.SOLVER.MOMENTUM, cfg.SOLVER.DAMPENING, cfg.SOLVER.NESTEROV = 0.9, 0.0, True
+    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1))
+    with torch.no_grad():
+        for p in model.parameters():           # no parameter sits at exactly zero
+            p.add_(torch.randn_like(p) * 0.02)
+    opt = construct_optimizer(model, cfg)
+    assert len([g for g in opt.param_groups if g["params"]]) == 2
+
+    # the same thing on the CPU with torch.optim
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    cpu = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in named}
+    by_id = {id(p): n for n, p in named}
+    groups = []
+    for g in opt.param_groups:
+        ps = [cpu[by_id[id(p)]] for p in g["params"] if id(p) in by_id]
+        groups.append({"params": ps, "weight_decay": g["weight_decay"], "lr_mult": g["lr_mult"]})
+    s = cfg.SOLVER
+    if method == "sgd":
+        ref = torch.optim.SGD(groups, lr=s.BASE_LR, momentum=s.MOMENTUM, weight_decay=s.WEIGHT_DECAY, dampening=s.DAMPENING,
+                              nesterov=s.NESTEROV)
+    else:
+        cls = torch.optim.Adam if method == "adam" else torch.optim.AdamW
+        ref = cls(groups, lr=s.BASE_LR, betas=(0.9, 0.999), eps=1e-8, weight_decay=s.WEIGHT_DECAY)
+
+    gen = torch.Generator().manual_seed(5)
+    skip_name = "model.time_embed"
+    num_iters = 4
+    opt.grad_scale = 1.0 / num_iters
+    worst = {}
+    for step in range(5):
+        lr = 1e-3 * (1.0 + 0.37 * step)
+        set_lr(opt, lr)
+        for g in ref.param_groups:
+            g["lr"] = lr * g["lr_mult"]
+        opt.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        for n, p in named:
+            if n == skip_name and step == 2:
+                continue                                   # no gradient this step: both sides must skip the parameter
+            micro = [torch.randn(p.shape, generator=gen) * 0.05 for _ in range(num_iters)]
+            acc = micro[0].clone()
+            for m in micro[1:]:
+                acc += m                                   # loss.backward() accumulating num_iters micro-batches
+            p.grad = acc.to(p.device)
+            cpu[n].grad = acc.clone()
+            cpu[n].grad /= num_iters                       # tools/train_net.py:187-189
+        opt.step()
+        ref.step()
+        torch.cuda.synchronize()
+        for n, p in named:
+            d = float((p.detach().cpu() - cpu[n].detach()).abs().max() / cpu[n].detach().abs().max())
+            worst["param"] = max(worst.get("param", 0.0), d)
+    sd = opt.state_dict()
+    k = 0
+    idx = {}
+    for g in opt.param_groups:
+        for j, p in enumerate(g["params"]):
+            if id(p) in by_id:
+                idx[by_id[id(p)]] = k + j
+        k += len(g["params"])
+    for n, _ in named:
+        st_ref = ref.state[cpu[n]]
+        st = sd["state"][idx[n]]
+        keys = ["momentum_buffer"] if method == "sgd" else ["exp_avg", "exp_avg_sq"]
+        for key in keys:
+            a, b = st[key].cpu(), st_ref[key]
+            worst[key] = max(worst.get(key, 0.0), float((a - b).abs().max() / b.abs().max()))
+        if method != "sgd":
+            want = 4.0 if n == skip_name else 5.0
+            assert float(st["step"]) == float(st_ref["step"]) == want, (n, st["step"], st_ref["step"])
+    return worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["adamw", "adam", "sgd"])
+def test_fused_step_matches_torch_optim(method):
+    worst = _run(method)
+    print(method, worst)
+    for k, v in worst.items():
+        assert v <= TOL, (method, k, v, worst)

@@ -38,8 +38,9 @@ def load_config(args):
 def _run(local_rank, num_proc, func, init_method, shard_id, num_shards, backend, cfg):
     import torch
     from procedurevrl_amd import distributed as du
+    single = bool(os.environ.get("PVRL_SINGLE_DEVICE"))     # functional test of the N-process path on one GPU (gloo)
     du.init_process_group(local_rank, num_proc, shard_id, num_shards, init_method, backend)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if single else local_rank)
     func(cfg)
 
 
@@ -56,11 +57,18 @@ def main():
     args = parse_args()
     cfg = load_config(args)
     from procedurevrl_amd.train_net import train
-    if cfg.TRAIN.ENABLE:
-        if isinstance(cfg.TRAIN.LABEL_EMB, str) and cfg.SYNTHETIC.ENABLE:
-            from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.test_net import test
+    if cfg.SYNTHETIC.ENABLE:        # offline stand-ins for the embedding files the yaml names (TRAIN.LABEL_EMB, DEV.TEST_LANG_EMB)
+        from procedurevrl_amd.datasets import synthetic_label_emb
+        if cfg.TRAIN.ENABLE and isinstance(cfg.TRAIN.LABEL_EMB, str) and not os.path.exists(cfg.TRAIN.LABEL_EMB):
             cfg.TRAIN.LABEL_EMB = synthetic_label_emb(cfg.MODEL.NUM_CLASSES)
+        if isinstance(cfg.DEV.TEST_LANG_EMB, str) and not os.path.exists(cfg.DEV.TEST_LANG_EMB):
+            cfg.DEV.TEST_LANG_EMB = synthetic_label_emb(cfg.MODEL.NUM_CLASSES, seed=1)
+    # tools/run_net.py:25-31: train, then multi-clip testing
+    if cfg.TRAIN.ENABLE:
         launch_job(cfg=cfg, init_method=args.init_method, func=train)
+    if cfg.TEST.ENABLE:
+        launch_job(cfg=cfg, init_method=args.init_method, func=test)
 
 
 if __name__ == "__main__":
