@@ -31,7 +31,6 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--host-profile", action="store_true", help="cProfile the host side of the timed steps (stderr)")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
-    ap.add_argument("--tn-tile", type=int, default=0, help="pvrl_debug_set_gemm_tn_tile knob (A/B of weight-gradient kernels)")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of HIP-graph replay of the encoder")
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient instead of one per block")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
@@ -74,9 +73,6 @@ def main():
     from procedurevrl_amd.losses import MILNCELoss
     from procedurevrl_amd.optimizer import construct_optimizer, set_lr
 
-    if args.tn_tile:
-        from procedurevrl_amd._lib import lib as _pl
-        _pl().call("pvrl_debug_set_gemm_tn_tile", args.tn_tile)
     cfg = get_cfg()
     cfg.MODEL.MODEL_NAME = "vit_base_patch16_224_develop"
     cfg.MODEL.ARCH = "vit"

@@ -35,6 +35,11 @@ extern "C" {
 #define PVRL_EPI_DGELU 5     /* out0 bf16 = rowscale * acc * GELU_erf'(aux_bf16)   (MLP backward)     */
 #define PVRL_EPI_DQGELU 6    /* out0 bf16 = rowscale * acc * QuickGELU'(aux_bf16)                     */
 
+/* The 16-bit operand type this library was built with: 0 = bf16 (libpvrl_hip.so), 1 = fp16 (libpvrl_hip_f16.so, built
+ * with -DPVRL_OPERAND_F16).  Wherever an entry point below says "bf16" (names, PVRL_EPI_BF16, comments) read "the
+ * library's 16-bit operand type": same layouts, same MFMA rate; fp16 gradients need the caller's loss scaling. */
+int pvrl_operand_dtype(void);
+
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.
  * Replaces nn.Linear forward (vit.py:54-60,75-92,133; tfm_model.py:35-41) and, with the
  * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M.  bias2 (fp32 [N] or null,
@@ -43,11 +48,6 @@ int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, in
                       int epilogue, const float* bias, const float* rowscale, const void* aux, int64_t aux_ld,
                       int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, const float* bias2,
                       void* stream);
-
-/* Benchmark knob: force the GEMM tile (0 heuristic, 1 128x128, 2 256x128, 3 256x256). Not used by the model. */
-int pvrl_debug_set_gemm_tile(int tile);
-int pvrl_debug_set_gemm_gm(int gm);   /* rasterisation group height (tile rows per XCD panel group), default 2 */
-int pvrl_debug_set_gemm_tn_tile(int tile);
 
 /* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits
  * `x @ label_emb.t() / temp` vit.py:307,334,340,432).  Long reductions with few output tiles are split over K into fp32

@@ -10,7 +10,18 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, "..", "include", "pvrl.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so")
+
+# The 16-bit operand type is fixed per library at build time (csrc/common.h): bf16 = libpvrl_hip.so (default),
+# fp16 = libpvrl_hip_f16.so.  PVRL_OPERAND selects which one this process loads (one per process).
+OPERAND = os.environ.get("PVRL_OPERAND", "bf16").lower()
+if OPERAND not in ("bf16", "f16"):
+    raise RuntimeError(f"PVRL_OPERAND={OPERAND!r}: expected 'bf16' or 'f16'")
+LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so" if OPERAND == "bf16" else "libpvrl_hip_f16.so")
+
+
+def operand_torch_dtype():
+    import torch
+    return torch.bfloat16 if OPERAND == "bf16" else torch.float16
 
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
@@ -79,6 +90,9 @@ class _Lib:
             self._fn[name] = (fn, ret == "int")
         for k, v in header_constants().items():
             setattr(self, k, v)
+        built = self.cdll.pvrl_operand_dtype()
+        if built != (0 if OPERAND == "bf16" else 1):
+            raise PvrlError(f"{LIB_PATH} was built for operand code {built}, PVRL_OPERAND={OPERAND}")
 
     def call(self, name, *args):
         fn, is_status = self._fn[name]

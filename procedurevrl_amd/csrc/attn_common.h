@@ -42,21 +42,21 @@ __device__ __forceinline__ int bl_off(int row, int col) {
 // 8 consecutive columns (16-byte chunk `chunk` of 8) of one row, from the SAME blocked image: with the (cb ^ (rb & 1))
 // block swizzle the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots, so one LDS copy of a tile
 // serves both the row-wise (a-operand) and the transposed (ds_read_b64_tr_b16) fragment reads.
-__device__ __forceinline__ bf16x8 bl_row_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + bl_off(row, chunk * 8));
+__device__ __forceinline__ opx8 bl_row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const opx8*>(tile + bl_off(row, chunk * 8));
 }
 
-__device__ __forceinline__ bf16x8 tr_frag8(const char* tile, int off0, int off1) {
+__device__ __forceinline__ opx8 tr_frag8(const char* tile, int off0, int off1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off1));
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  union { struct { s16x4 a, b; } s; opx8 v; } u;
   u.s.a = lo; u.s.b = hi;
   return u.v;
 }
 
 // Transposed fragment for a K=32 MFMA step `ks2` (rows 32*ks2 .. 32*ks2+31 of a blocked tile):
 // lane (i = lane&15, q = lane>>4) receives column 16*ct + i at rows {32ks2+4q+0..3, 32ks2+16+4q+0..3}.
-__device__ __forceinline__ bf16x8 bl_frag(const char* tile, int ks2, int ct, int lane) {
+__device__ __forceinline__ opx8 bl_frag(const char* tile, int ks2, int ct, int lane) {
   const int q = lane >> 4, i = lane & 15;
   const int rb0 = 8 * ks2 + q, rb1 = rb0 + 4;
   const int o0 = (rb0 * 4 + (ct ^ (rb0 & 1))) * 128 + i * 8;
@@ -87,8 +87,8 @@ __device__ __forceinline__ long row_of(const SeqRows& r, int j) { return j == 0 
 // (7 x 16 B in flight per thread for S = 197).  `src0` (optional) overrides the source row of token 0
 // (side buffer of the per-(b,t) cls rows).  rm / bl may each be null.  Rows >= S are zero-filled.
 constexpr int ATT_LOAD_ITERS = (ATT_ROWS_PAD * 8) / 256;   // 7
-__device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int col0, const SeqRows& sr, int S,
-                                               const bf16* src0, char* rm, int rm_rows, char* bl, int bl_rows,
+__device__ __forceinline__ void load_head_tile(const op_t* base, long ld, int col0, const SeqRows& sr, int S,
+                                               const op_t* src0, char* rm, int rm_rows, char* bl, int bl_rows,
                                                int tid) {
   const int maxrows = rm_rows > bl_rows ? rm_rows : bl_rows;
   u32x4 v[ATT_LOAD_ITERS];
@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int co
     const int row = idx >> 3, c = idx & 7;
     v[it] = (u32x4){0u, 0u, 0u, 0u};
     if (row < S && row < maxrows) {
-      const bf16* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
+      const op_t* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
       v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
     }
   }
@@ -111,8 +111,8 @@ __device__ __forceinline__ void load_head_tile(const bf16* base, long ld, int co
   }
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  union { bf16x2 v; unsigned u; } x;
-  x.v[0] = (bf16)a; x.v[1] = (bf16)b;
+__device__ __forceinline__ unsigned pack_opx2(float a, float b) {
+  union { opx2 v; unsigned u; } x;
+  x.v[0] = (op_t)a; x.v[1] = (op_t)b;
   return x.u;
 }

@@ -23,19 +23,19 @@
 namespace {
 
 struct AttnArgs {
-  const bf16* qkv; long ld;   // packed [rows][3*H*64]: q | k | v, head h at columns h*64
+  const op_t* qkv; long ld;   // packed [rows][3*H*64]: q | k | v, head h at columns h*64
   int H, nseq;
   SeqMap mp;
   float scale;
   int causal;
   const unsigned char* kpm;   // [nseq][S], 1 = key masked, or null
   // forward
-  bf16* o; bf16* o_cls; long ldo;
+  op_t* o; op_t* o_cls; long ldo;
   float* lse;                 // [nseq][H][S]
   // backward
-  const bf16* d_o; const bf16* d_o_cls; const bf16* ofw; const bf16* ofw_cls;
+  const op_t* d_o; const op_t* d_o_cls; const op_t* ofw; const op_t* ofw_cls;
   float* dvec;                // [nseq][H][S]  rowsum(dO * O)
-  bf16* dqkv; bf16* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
+  op_t* dqkv; op_t* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
 };
 
 // row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
@@ -69,8 +69,8 @@ template <int NT>
 struct TileRegs { u32x4 v[(ATT_ROWS_PAD * 8 + NT - 1) / NT]; };
 
 template <int NT>
-__device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const bf16* base, long ld, int col0, const SeqRows& sr, int S,
-                                           const bf16* src0, int rows, int tid) {
+__device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const op_t* base, long ld, int col0, const SeqRows& sr, int S,
+                                           const op_t* src0, int rows, int tid) {
   constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const bf16* base, lo
     const int row = idx >> 3, c = idx & 7;
     t.v[it] = (u32x4){0u, 0u, 0u, 0u};
     if (row < S && row < rows) {
-      const bf16* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
+      const op_t* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
       t.v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
     }
   }
@@ -118,14 +118,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
   const int q4 = lane >> 4, i = lane & 15;
   const int nqt = (S + 15) >> 4;
   // every global load of the workgroup goes out before the first wait: this wave's query fragments, then K and V
-  bf16x8 qf[MAXT][2];
+  opx8 qf[MAXT][2];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     const int query = (wave + t * NW) * 16 + i;
     const int qrow = query < S ? query : S - 1;
-    const bf16* qp = p.qkv + row_of(sr, qrow) * p.ld + h * 64 + q4 * 8;
-    qf[t][0] = *reinterpret_cast<const bf16x8*>(qp);
-    qf[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+    const op_t* qp = p.qkv + row_of(sr, qrow) * p.ld + h * 64 + q4 * 8;
+    qf[t][0] = *reinterpret_cast<const opx8*>(qp);
+    qf[t][1] = *reinterpret_cast<const opx8*>(qp + 32);
   }
   {
     TileRegs<64 * NW> kr, vr;
@@ -142,17 +142,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
     const int qt = wave + t * NW;
     if (qt >= nqt) break;
     const int query = qt * 16 + i;
-    const bf16x8 qf0 = qf[t][0], qf1 = qf[t][1];
+    const opx8 qf0 = qf[t][0], qf1 = qf[t][1];
 
     f32x4 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int krow = kt * 16 + i;
-      const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
-      const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
+      const opx8 k0 = bl_row_frag(Kb, krow, q4);
+      const opx8 k1 = bl_row_frag(Kb, krow, 4 + q4);
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
-      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+      a = MFMA_16x16x32(k0, qf0, a, 0, 0, 0);
+      sc[kt] = MFMA_16x16x32(k1, qf1, a, 0, 0, 0);
       if (NKT > 5 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the fragment look-ahead (and VGPRs) bounded
     }
     // softmax over the lane's 4*NKT keys.  exp(scale*s - max) is evaluated as exp2(fma(s, c, -max*c)) with
@@ -194,28 +194,28 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks2 = 0; ks2 < NKS2; ++ks2) {
-      bf16x8 pf;
+      opx8 pf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pf[r] = (bf16)sc[2 * ks2][r];
-        if (2 * ks2 + 1 < NKT) pf[4 + r] = (bf16)sc[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r];
-        else pf[4 + r] = (bf16)0.f;
+        pf[r] = (op_t)sc[2 * ks2][r];
+        if (2 * ks2 + 1 < NKT) pf[4 + r] = (op_t)sc[(2 * ks2 + 1 < NKT) ? 2 * ks2 + 1 : 0][r];
+        else pf[4 + r] = (op_t)0.f;
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 vf = bl_frag(Vb, ks2, dt, lane);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        const opx8 vf = bl_frag(Vb, ks2, dt, lane);
+        oacc[dt] = MFMA_16x16x32(vf, pf, oacc[dt], 0, 0, 0);
       }
       if (NKT > 5) __builtin_amdgcn_sched_barrier(0);
     }
     if (query < S) {
-      bf16* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, sr, seq, query) + h * 64 + 4 * q4;
+      op_t* op = tok_ptr(p.o, p.o_cls, p.ldo, p.mp, sr, seq, query) + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 ov;
+        opx4 ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16)(oacc[dt][r] * inv);
-        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+        for (int r = 0; r < 4; ++r) ov[r] = (op_t)(oacc[dt][r] * inv);
+        *reinterpret_cast<opx4*>(op + 16 * dt) = ov;
       }
       if (q4 == 0 && p.lse) p.lse[((long)seq * p.H + h) * S + query] = mref * p.scale + __logf(sum);
     }
@@ -248,23 +248,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
   const float c = p.scale * 1.4426950408889634f;
   // every global load of the workgroup goes out before the first wait: q / dO / O / lse of this wave's query tiles,
   // then the K and V head slices
-  bf16x8 qf[MAXT][2], df[MAXT][2];
+  opx8 qf[MAXT][2], df[MAXT][2];
   float lse2[MAXT], dss[MAXT];
   {
-    bf16x8 of[MAXT][2];
+    opx8 of[MAXT][2];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int query = (wave + t * NW) * 16 + i;
       const int qj = query < S ? query : S - 1;
-      const bf16* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
-      qf[t][0] = *reinterpret_cast<const bf16x8*>(qp);
-      qf[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
-      const bf16* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
-      df[t][0] = *reinterpret_cast<const bf16x8*>(dop);
-      df[t][1] = *reinterpret_cast<const bf16x8*>(dop + 32);
-      const bf16* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
-      of[t][0] = *reinterpret_cast<const bf16x8*>(ofp);
-      of[t][1] = *reinterpret_cast<const bf16x8*>(ofp + 32);
+      const op_t* qp = p.qkv + row_of(sr, qj) * p.ld + h * 64 + q4 * 8;
+      qf[t][0] = *reinterpret_cast<const opx8*>(qp);
+      qf[t][1] = *reinterpret_cast<const opx8*>(qp + 32);
+      const op_t* dop = tok_ptr(p.d_o, p.d_o_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
+      df[t][0] = *reinterpret_cast<const opx8*>(dop);
+      df[t][1] = *reinterpret_cast<const opx8*>(dop + 32);
+      const op_t* ofp = tok_ptr(p.ofw, p.ofw_cls, p.ldo, p.mp, sr, seq, qj) + h * 64 + q4 * 8;
+      of[t][0] = *reinterpret_cast<const opx8*>(ofp);
+      of[t][1] = *reinterpret_cast<const opx8*>(ofp + 32);
       lse2[t] = p.lse[((long)seq * p.H + h) * S + qj] * 1.4426950408889634f;
     }
     TileRegs<64 * NW> kr, vr;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
     const int qt = wave + t * NW;
     if (qt >= nqt) break;
     const int query = qt * 16 + i;
-    const bf16x8 qf0 = qf[t][0], qf1 = qf[t][1], df0 = df[t][0], df1 = df[t][1];
+    const opx8 qf0 = qf[t][0], qf1 = qf[t][1], df0 = df[t][0], df1 = df[t][1];
     const float lse2_t = lse2[t], dss_t = dss[t];
 
     // dS for two 16-key tiles at a time, consumed at once by the dQ MFMAs: nothing but dq[] lives across iterations
@@ -301,26 +301,26 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks2 = 0; ks2 < NKS2; ++ks2) {
-      bf16x8 sf;
+      opx8 sf;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int kt = 2 * ks2 + half;
         if (kt >= NKT) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sf[4 * half + r] = (bf16)0.f;
+          for (int r = 0; r < 4; ++r) sf[4 * half + r] = (op_t)0.f;
           continue;
         }
         const int krow = kt * 16 + i;
-        const bf16x8 k0 = bl_row_frag(Kb, krow, q4);
-        const bf16x8 k1 = bl_row_frag(Kb, krow, 4 + q4);
-        const bf16x8 v0 = bl_row_frag(Vb, krow, q4);
-        const bf16x8 v1 = bl_row_frag(Vb, krow, 4 + q4);
+        const opx8 k0 = bl_row_frag(Kb, krow, q4);
+        const opx8 k1 = bl_row_frag(Kb, krow, 4 + q4);
+        const opx8 v0 = bl_row_frag(Vb, krow, q4);
+        const opx8 v1 = bl_row_frag(Vb, krow, 4 + q4);
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
+        s = MFMA_16x16x32(k0, qf0, s, 0, 0, 0);
+        s = MFMA_16x16x32(k1, qf1, s, 0, 0, 0);
         f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df1, dp, 0, 0, 0);
+        dp = MFMA_16x16x32(v0, df0, dp, 0, 0, 0);
+        dp = MFMA_16x16x32(v1, df1, dp, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * q4 + r;
@@ -330,24 +330,24 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
             if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
             if (msk) pr = 0.f;
           }
-          sf[4 * half + r] = (bf16)(pr * fmaf(dp[r], p.scale, -dss_t));
+          sf[4 * half + r] = (op_t)(pr * fmaf(dp[r], p.scale, -dss_t));
         }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 kf = bl_frag(Kb, ks2, dt, lane);
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, dq[dt], 0, 0, 0);
+        const opx8 kf = bl_frag(Kb, ks2, dt, lane);
+        dq[dt] = MFMA_16x16x32(kf, sf, dq[dt], 0, 0, 0);
       }
       if (NKT > 5) __builtin_amdgcn_sched_barrier(0);
     }
     if (query < S) {
-      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, query) + h * 64 + 4 * q4;
+      op_t* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, query) + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 ov;
+        opx4 ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16)dq[dt][r];
-        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+        for (int r = 0; r < 4; ++r) ov[r] = (op_t)dq[dt][r];
+        *reinterpret_cast<opx4*>(op + 16 * dt) = ov;
       }
     }
   }
@@ -382,19 +382,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
   const float c = p.scale * 1.4426950408889634f;
   const int nkt_rt = (S + 15) >> 4;
   // every global load of the workgroup goes out before the first wait: this wave's K / V fragments, then Q and dO
-  bf16x8 kf[MAXT][2], vf[MAXT][2];
+  opx8 kf[MAXT][2], vf[MAXT][2];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     const int key = (wave + t * NW) * 16 + i;
     const int kj = key < S ? key : S - 1;
-    const bf16* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
-    kf[t][0] = *reinterpret_cast<const bf16x8*>(kp);
-    kf[t][1] = *reinterpret_cast<const bf16x8*>(kp + 32);
-    vf[t][0] = *reinterpret_cast<const bf16x8*>(kp + HD);
-    vf[t][1] = *reinterpret_cast<const bf16x8*>(kp + HD + 32);
+    const op_t* kp = p.qkv + row_of(sr, kj) * p.ld + HD + h * 64 + q4 * 8;
+    kf[t][0] = *reinterpret_cast<const opx8*>(kp);
+    kf[t][1] = *reinterpret_cast<const opx8*>(kp + 32);
+    vf[t][0] = *reinterpret_cast<const opx8*>(kp + HD);
+    vf[t][1] = *reinterpret_cast<const opx8*>(kp + HD + 32);
   }
   {
-    const bf16* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
+    const op_t* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
     TileRegs<64 * NW> qr, dr;
     tile_issue<64 * NW>(qr, p.qkv, p.ld, h * 64, sr, S, nullptr, ROWS, tid);
     tile_issue<64 * NW>(dr, p.d_o, p.ldo, h * 64, sr, S, src0, ROWS, tid);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
     if (kt >= nkt_rt) break;
     const int key = kt * 16 + i;
     const int kj = key < S ? key : S - 1;
-    const bf16x8 kf0 = kf[t][0], kf1 = kf[t][1], vf0 = vf[t][0], vf1 = vf[t][1];
+    const opx8 kf0 = kf[t][0], kf1 = kf[t][1], vf0 = vf[t][0], vf1 = vf[t][1];
     bool kbad = key >= S;
     if constexpr (GEN) kbad = kbad || (p.kpm ? (p.kpm[(long)seq * S + kj] != 0) : false);
 
@@ -424,20 +424,20 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
 
 #pragma unroll 1
     for (int u = 0; u < NKS2; ++u) {
-      bf16x8 pf, sf;
+      opx8 pf, sf;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qrow = (2 * u + half) * 16 + i;   // a-operand row: query
-        const bf16x8 a0 = bl_row_frag(Qb, qrow, q4);
-        const bf16x8 a1 = bl_row_frag(Qb, qrow, 4 + q4);
-        const bf16x8 d0 = bl_row_frag(Db, qrow, q4);
-        const bf16x8 d1 = bl_row_frag(Db, qrow, 4 + q4);
+        const opx8 a0 = bl_row_frag(Qb, qrow, q4);
+        const opx8 a1 = bl_row_frag(Qb, qrow, 4 + q4);
+        const opx8 d0 = bl_row_frag(Db, qrow, q4);
+        const opx8 d1 = bl_row_frag(Db, qrow, 4 + q4);
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf1, s, 0, 0, 0);
+        s = MFMA_16x16x32(a0, kf0, s, 0, 0, 0);
+        s = MFMA_16x16x32(a1, kf1, s, 0, 0, 0);
         f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf1, dp, 0, 0, 0);
+        dp = MFMA_16x16x32(d0, vf0, dp, 0, 0, 0);
+        dp = MFMA_16x16x32(d1, vf1, dp, 0, 0, 0);
         // s[r] = S[query = (2u+half)*16 + 4*q4 + r][key]
         const int qb = (2 * u + half) * 16 + 4 * q4;
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);   // lse * log2(e)
@@ -448,27 +448,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
           bool msk = query >= S || kbad;
           if constexpr (GEN) msk = msk || (p.causal && key > query);
           const float pr = msk ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[r]));
-          pf[half * 4 + r] = (bf16)pr;
-          sf[half * 4 + r] = (bf16)(pr * fmaf(dp[r], p.scale, -d4[r]));
+          pf[half * 4 + r] = (op_t)pr;
+          sf[half * 4 + r] = (op_t)(pr * fmaf(dp[r], p.scale, -d4[r]));
         }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 qtf = bl_frag(Qb, u, dt, lane);
-        const bf16x8 dtf = bl_frag(Db, u, dt, lane);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sf, dk[dt], 0, 0, 0);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pf, dv[dt], 0, 0, 0);
+        const opx8 qtf = bl_frag(Qb, u, dt, lane);
+        const opx8 dtf = bl_frag(Db, u, dt, lane);
+        dk[dt] = MFMA_16x16x32(qtf, sf, dk[dt], 0, 0, 0);
+        dv[dt] = MFMA_16x16x32(dtf, pf, dv[dt], 0, 0, 0);
       }
     }
     if (key < S) {
-      bf16* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, key) + HD + h * 64 + 4 * q4;
+      op_t* op = tok_ptr(p.dqkv, p.dqkv_cls, p.ldd, p.mp, sr, seq, key) + HD + h * 64 + 4 * q4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 ok, ov;
+        opx4 ok, ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)dk[dt][r]; ov[r] = (bf16)dv[dt][r]; }
-        *reinterpret_cast<bf16x4*>(op + 16 * dt) = ok;
-        *reinterpret_cast<bf16x4*>(op + HD + 16 * dt) = ov;
+        for (int r = 0; r < 4; ++r) { ok[r] = (op_t)dk[dt][r]; ov[r] = (op_t)dv[dt][r]; }
+        *reinterpret_cast<opx4*>(op + 16 * dt) = ok;
+        *reinterpret_cast<opx4*>(op + HD + 16 * dt) = ov;
       }
     }
   }
@@ -512,10 +512,10 @@ extern "C" int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
                              int64_t cls_base, float scale, int causal, const void* key_padding_mask, void* o,
                              void* o_cls, int64_t ldo, float* lse, void* stream) {
   AttnArgs p = {};
-  p.qkv = (const bf16*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
+  p.qkv = (const op_t*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
   p.mp.mode = mode; p.mp.S = (int)S; p.mp.T = (int)T; p.mp.cls_base = cls_base;
   p.scale = scale; p.causal = causal; p.kpm = (const unsigned char*)key_padding_mask;
-  p.o = (bf16*)o; p.o_cls = (bf16*)o_cls; p.ldo = ldo; p.lse = lse;
+  p.o = (op_t*)o; p.o_cls = (op_t*)o_cls; p.ldo = ldo; p.lse = lse;
   if (nseq == 0) return PVRL_OK;
   if (int e = check_common(p)) return e;
   if (!o || (ldo % 4) || (mode == 1 && !o_cls)) return PVRL_EINVAL;
@@ -532,12 +532,12 @@ extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
                              const void* o_cls, const void* d_o, const void* d_o_cls, int64_t ldo, const float* lse,
                              float* dvec, void* dqkv, void* dqkv_cls, int64_t ldd, void* stream) {
   AttnArgs p = {};
-  p.qkv = (const bf16*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
+  p.qkv = (const op_t*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
   p.mp.mode = mode; p.mp.S = (int)S; p.mp.T = (int)T; p.mp.cls_base = cls_base;
   p.scale = scale; p.causal = causal; p.kpm = (const unsigned char*)key_padding_mask;
-  p.ofw = (const bf16*)o; p.ofw_cls = (const bf16*)o_cls; p.d_o = (const bf16*)d_o; p.d_o_cls = (const bf16*)d_o_cls;
+  p.ofw = (const op_t*)o; p.ofw_cls = (const op_t*)o_cls; p.d_o = (const op_t*)d_o; p.d_o_cls = (const op_t*)d_o_cls;
   p.ldo = ldo; p.lse = const_cast<float*>(lse); p.dvec = dvec;
-  p.dqkv = (bf16*)dqkv; p.dqkv_cls = (bf16*)dqkv_cls; p.ldd = ldd;
+  p.dqkv = (op_t*)dqkv; p.dqkv_cls = (op_t*)dqkv_cls; p.ldd = ldd;
   if (nseq == 0) return PVRL_OK;
   if (int e = check_common(p)) return e;
   if (!o || !d_o || !lse || !dvec || !dqkv || (ldo % 8) || (ldd % 4)) return PVRL_EINVAL;

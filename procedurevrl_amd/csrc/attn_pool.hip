@@ -23,13 +23,13 @@ constexpr int MAXKEYS = 1664;           // 8*14*14 + 1 = 1569 keys, rounded
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct PA {
-  const bf16* q; const bf16* k; const bf16* v;   // [BH][L+1][96]
+  const op_t* q; const op_t* k; const op_t* v;   // [BH][L+1][96]
   const float* rel;                              // [BH][Lq][J]
-  bf16* o; long ldo;                             // token-major [B*Lq + B][ldo], column h*96 + d
+  op_t* o; long ldo;                             // token-major [B*Lq + B][ldo], column h*96 + d
   float* lse;                                    // [BH][Lq+1]   (log2 domain)
-  const bf16* d_o;                               // same layout as o
+  const op_t* d_o;                               // same layout as o
   float* delta;                                  // [BH][Lq+1]
-  bf16* dq; bf16* dk; bf16* dv;                  // [BH][L+1][96]
+  op_t* dq; op_t* dk; op_t* dv;                  // [BH][L+1][96]
   float* drel;                                   // [BH][Lq][J]
   float* kv_part;                                // [nsplit][2][BH][Lk+1][96] fp32 partial dK / dV
   int B, H, Lq, Lk, kt, kh, kw, J;
@@ -41,11 +41,11 @@ __device__ __forceinline__ int pb_off(int row, int col) {
   const int rb = row >> 2;
   return (rb * NCB + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
 }
-__device__ __forceinline__ bf16x8 pb_row_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + pb_off(row, chunk * 8));
+__device__ __forceinline__ opx8 pb_row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const opx8*>(tile + pb_off(row, chunk * 8));
 }
 // transposed fragment over the tile's 32 rows: lane (i, q) receives column 16*ct + i at rows {4q..4q+3, 16+4q..16+4q+3}
-__device__ __forceinline__ bf16x8 pb_tr_frag(const char* tile, int ct, int lane) {
+__device__ __forceinline__ opx8 pb_tr_frag(const char* tile, int ct, int lane) {
   const int q = lane >> 4, i = lane & 15;
   const int rb0 = q, rb1 = q + 4;
   return tr_frag8(tile, (rb0 * NCB + (ct ^ (rb0 & 1))) * 128 + i * 8, (rb1 * NCB + (ct ^ (rb1 & 1))) * 128 + i * 8);
@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x8 pb_tr_frag(const char* tile, int ct, int lane)
 
 // cooperative tile load: 32 rows x 12 chunks of 16 B = 384 chunks, rows >= nrows zero
 struct TileRegs { u32x4 v[2]; };
-__device__ __forceinline__ void tile_gload(TileRegs& t, const bf16* base, long ld, int row0, int nrows, int tid) {
+__device__ __forceinline__ void tile_gload(TileRegs& t, const op_t* base, long ld, int row0, int nrows, int tid) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int c = tid + 256 * e;
@@ -96,18 +96,18 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int query = blockIdx.x * 64 + wave * 16 + i;
   const int qc = query < Lq1 ? query : Lq1 - 1;
-  const bf16* qrow = p.q + ((long)bh * Lq1 + qc) * D;
-  bf16x8 qf[3];
+  const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
+  opx8 qf[3];
 #pragma unroll
-  for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + q4 * 8);
+  for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const opx8*>(qrow + ks * 32 + q4 * 8);
   for (int j = tid; j < MAXKEYS; j += 256) kdec_s[j] = key_dec(p, j);
   for (int e = lane; e < 16 * p.J; e += 64) {
     const int qi = e / p.J, j = e - qi * p.J;
     const int qq = blockIdx.x * 64 + wave * 16 + qi;
     rel_s[wave][qi][j] = qq < p.Lq ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
   }
-  const bf16* kb = p.k + (long)bh * Lk1 * D;
-  const bf16* vb = p.v + (long)bh * Lk1 * D;
+  const op_t* kb = p.k + (long)bh * Lk1 * D;
+  const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
   TileRegs rk, rv;
   tile_gload(rk, kb, D, 0, Lk1, tid);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks)
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
+        s = MFMA_16x16x32(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * KT + u * 16 + 4 * q4 + r;
@@ -160,13 +160,13 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { pr[e] = __builtin_amdgcn_exp2f(val[e] - mn); ps += pr[e]; }
     l = l * alpha + ps;
-    union { unsigned u[4]; bf16x8 v; } pf;
+    union { unsigned u[4]; opx8 v; } pf;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(pr[2 * e], pr[2 * e + 1]);
+    for (int e = 0; e < 4; ++e) pf.u[e] = pack_opx2(pr[2 * e], pr[2 * e + 1]);
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
       oacc[dt] *= alpha;
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
+      oacc[dt] = MFMA_16x16x32(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
     }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
@@ -179,15 +179,15 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
   l += __shfl_xor(l, 32, 64);
   if (query < Lq1) {
     const float inv = 1.f / l;
-    bf16* op = p.o + tok_row(p, b, query) * p.ldo + h * D + 4 * q4;
+    op_t* op = p.o + tok_row(p, b, query) * p.ldo + h * D + 4 * q4;
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      bf16x4 ov;
-      bf16x4 qv = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      if (qpatch) qv = *reinterpret_cast<const bf16x4*>(qrow + 16 * dt + 4 * q4);
+      opx4 ov;
+      opx4 qv = (opx4){(op_t)0.f, (op_t)0.f, (op_t)0.f, (op_t)0.f};
+      if (qpatch) qv = *reinterpret_cast<const opx4*>(qrow + 16 * dt + 4 * q4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ov[r] = (bf16)(oacc[dt][r] * inv + (float)qv[r]);
-      *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+      for (int r = 0; r < 4; ++r) ov[r] = (op_t)(oacc[dt][r] * inv + (float)qv[r]);
+      *reinterpret_cast<opx4*>(op + 16 * dt) = ov;
     }
     if (q4 == 0) p.lse[(long)bh * Lq1 + query] = m + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
   }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   __shared__ float rel_s[4][16][JMAX];
   // E^T tile: [48 rel columns][32 keys] 0/1 indicators (bf16) of the key tile, double buffered: d rel = dS . E by MFMA
-  __shared__ __attribute__((aligned(16))) bf16 et_s[2][48][KT];
+  __shared__ __attribute__((aligned(16))) op_t et_s[2][48][KT];
   __shared__ unsigned kdec_s[MAXKEYS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
@@ -207,15 +207,15 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   const int query = blockIdx.x * 64 + wave * 16 + i;
   const int qc = query < Lq1 ? query : Lq1 - 1;
   const bool qpatch = query < p.Lq;
-  const bf16* qrow = p.q + ((long)bh * Lq1 + qc) * D;
+  const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
   const long orow = tok_row(p, b, qc) * p.ldo + h * D;
-  bf16x8 qf[3], df[3];
+  opx8 qf[3], df[3];
   float dl = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + q4 * 8);
-    df[ks] = *reinterpret_cast<const bf16x8*>(p.d_o + orow + ks * 32 + q4 * 8);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(p.o + orow + ks * 32 + q4 * 8);
+    qf[ks] = *reinterpret_cast<const opx8*>(qrow + ks * 32 + q4 * 8);
+    df[ks] = *reinterpret_cast<const opx8*>(p.d_o + orow + ks * 32 + q4 * 8);
+    const opx8 of = *reinterpret_cast<const opx8*>(p.o + orow + ks * 32 + q4 * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dl += (float)df[ks][e] * ((float)of[e] - (qpatch ? (float)qf[ks][e] : 0.f));
   }
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
     const int qq = blockIdx.x * 64 + wave * 16 + qi;
     rel_s[wave][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
   }
-  const bf16* kb = p.k + (long)bh * Lk1 * D;
-  const bf16* vb = p.v + (long)bh * Lk1 * D;
+  const op_t* kb = p.k + (long)bh * Lk1 * D;
+  const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
   TileRegs rk, rv;
   tile_gload(rk, kb, D, 0, Lk1, tid);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
       const int key = t * KT + kk;
       const unsigned kd = key < MAXKEYS ? kdec_s[key] : 0xffffffffu;
       const bool hit = kd != 0xffffffffu && (j == (int)(kd & 255) || j == (int)((kd >> 8) & 255) || j == (int)((kd >> 16) & 255));
-      et_s[t & 1][j][kk] = (bf16)(hit ? 1.f : 0.f);
+      et_s[t & 1][j][kk] = (op_t)(hit ? 1.f : 0.f);
     }
   };
   const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Vb, u * 16 + i, ks * 4 + q4), df[ks], dp, 0, 0, 0);
+        s = MFMA_16x16x32(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
+        dp = MFMA_16x16x32(pb_row_frag(Vb, u * 16 + i, ks * 4 + q4), df[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -289,20 +289,20 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
         (void)hasb;
       }
     }
-    union { unsigned u[4]; bf16x8 v; } sf;
+    union { unsigned u[4]; opx8 v; } sf;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sf.u[e] = pack_bf16x2(ds[2 * e], ds[2 * e + 1]);
+    for (int e = 0; e < 4; ++e) sf.u[e] = pack_opx2(ds[2 * e], ds[2 * e + 1]);
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt)
-      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
+      dq[dt] = MFMA_16x16x32(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
     if (qpatch_any) {
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) {
         // A = E^T rows j = 16 jt + i, k-slots = the tile's keys in the same permuted order as sf (4q4+e | 16+4q4+e)
-        union { struct { u32x2 a, b; } s2; bf16x8 v; } ef;
+        union { struct { u32x2 a, b; } s2; opx8 v; } ef;
         ef.s2.a = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][4 * q4]);
         ef.s2.b = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][16 + 4 * q4]);
-        dracc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef.v, sf.v, dracc[jt], 0, 0, 0);
+        dracc[jt] = MFMA_16x16x32(ef.v, sf.v, dracc[jt], 0, 0, 0);
       }
     }
     if (t + 1 < ntiles) {
@@ -314,16 +314,16 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
     __syncthreads();
   }
   if (query < Lq1) {
-    bf16* op = p.dq + ((long)bh * Lq1 + query) * D + 4 * q4;
-    const bf16* dop = p.d_o + orow + 4 * q4;
+    op_t* op = p.dq + ((long)bh * Lq1 + query) * D + 4 * q4;
+    const op_t* dop = p.d_o + orow + 4 * q4;
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      bf16x4 ov;
-      bf16x4 dv = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      if (qpatch) dv = *reinterpret_cast<const bf16x4*>(dop + 16 * dt);     // residual pooling: d out / d q = 1
+      opx4 ov;
+      opx4 dv = (opx4){(op_t)0.f, (op_t)0.f, (op_t)0.f, (op_t)0.f};
+      if (qpatch) dv = *reinterpret_cast<const opx4*>(dop + 16 * dt);     // residual pooling: d out / d q = 1
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ov[r] = (bf16)(dq[dt][r] * p.scale + (float)dv[r]);
-      *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+      for (int r = 0; r < 4; ++r) ov[r] = (op_t)(dq[dt][r] * p.scale + (float)dv[r]);
+      *reinterpret_cast<opx4*>(op + 16 * dt) = ov;
     }
   }
   // dracc[jt][r] = d rel[query][16 jt + 4 q4 + r] (cls-query rows hold the un-biased scores' dS: not part of rel)
@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int key = blockIdx.x * 64 + wave * 16 + i;
   const int kc = key < Lk1 ? key : Lk1 - 1;
-  bf16x8 kf[3], vf[3];
+  opx8 kf[3], vf[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
+    kf[ks] = *reinterpret_cast<const opx8*>(p.k + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
+    vf[ks] = *reinterpret_cast<const opx8*>(p.v + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
   }
   const unsigned kd = key_dec(p, key);
   const bool kpatch = kd != 0xffffffffu;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
   const int ntiles_all = (Lq1 + KT - 1) / KT;
   const int per = (ntiles_all + gridDim.z - 1) / gridDim.z;          // query tiles of this z-slice
   const int tbeg = blockIdx.z * per, ntiles = min(ntiles_all, tbeg + per);
-  const bf16* qb = p.q + (long)bh * Lq1 * D;
+  const op_t* qb = p.q + (long)bh * Lq1 * D;
 
   // the dO tile is gathered from the token-major activation: rows (b, query) / cls row, columns h*96 ..
   auto load_do = [&](TileRegs& t, int row0) {
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Qb, u * 16 + i, ks * 4 + q4), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_row_frag(Db, u * 16 + i, ks * 4 + q4), vf[ks], dp, 0, 0, 0);
+        s = MFMA_16x16x32(pb_row_frag(Qb, u * 16 + i, ks * 4 + q4), kf[ks], s, 0, 0, 0);
+        dp = MFMA_16x16x32(pb_row_frag(Db, u * 16 + i, ks * 4 + q4), vf[ks], dp, 0, 0, 0);
       }
       // s[r] = S[query = t*32 + 16u + 4*q4 + r][key]
 #pragma unroll
@@ -448,16 +448,16 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
         ds[u * 4 + r] = pv * (dp[r] - dl_s[buf][ql]);
       }
     }
-    union { unsigned u[4]; bf16x8 v; } pf, sf;
+    union { unsigned u[4]; opx8 v; } pf, sf;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      pf.u[e] = pack_bf16x2(pr[2 * e], pr[2 * e + 1]);
-      sf.u[e] = pack_bf16x2(ds[2 * e], ds[2 * e + 1]);
+      pf.u[e] = pack_opx2(pr[2 * e], pr[2 * e + 1]);
+      sf.u[e] = pack_opx2(ds[2 * e], ds[2 * e + 1]);
     }
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Db, dt, lane), pf.v, dv[dt], 0, 0, 0);
-      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb_tr_frag(Qb, dt, lane), sf.v, dk[dt], 0, 0, 0);
+      dv[dt] = MFMA_16x16x32(pb_tr_frag(Db, dt, lane), pf.v, dv[dt], 0, 0, 0);
+      dk[dt] = MFMA_16x16x32(pb_tr_frag(Qb, dt, lane), sf.v, dk[dt], 0, 0, 0);
     }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
 
 // dK = scale * sum_z partial, dV = sum_z partial  (bf16 out)
 __global__ __launch_bounds__(256) void pattn_kv_reduce_kernel(const float* __restrict__ part, int nsplit, long nkv,
-                                                              float scale, bf16* __restrict__ dk, bf16* __restrict__ dv) {
+                                                              float scale, op_t* __restrict__ dk, op_t* __restrict__ dv) {
   const long n4 = nkv >> 2;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < 2 * n4; idx += (long)gridDim.x * 256) {
     const int which = idx >= n4;
@@ -489,10 +489,10 @@ __global__ __launch_bounds__(256) void pattn_kv_reduce_kernel(const float* __res
     f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < nsplit; ++z) a += *reinterpret_cast<const f32x4*>(part + ((long)z * 2 + which) * nkv + e);
     const float sc = which ? 1.f : scale;
-    bf16x4 o;
+    opx4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (bf16)(a[r] * sc);
-    *reinterpret_cast<bf16x4*>((which ? dv : dk) + e) = o;
+    for (int r = 0; r < 4; ++r) o[r] = (op_t)(a[r] * sc);
+    *reinterpret_cast<opx4*>((which ? dv : dk) + e) = o;
   }
 }
 
@@ -501,7 +501,7 @@ int fill(PA& p, const void* q, const void* k, const void* v, const float* rel, i
   if (!q || !k || !v || !rel || B <= 0 || H <= 0 || Lq <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || (ldo % 8) || ldo < H * D)
     return PVRL_EINVAL;
   if (kh + kw + kt > JMAX || kt * kh * kw + 1 > MAXKEYS || kh + kw + kt > 255) return PVRL_EINVAL;
-  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.rel = rel;
+  p.q = (const op_t*)q; p.k = (const op_t*)k; p.v = (const op_t*)v; p.rel = rel;
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)(kt * kh * kw);
   p.kt = (int)kt; p.kh = (int)kh; p.kw = (int)kw; p.J = (int)(kh + kw + kt);
   p.scale = scale; p.ldo = ldo;
@@ -515,7 +515,7 @@ extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, c
                                   float* lse, void* stream) {
   PA p = {};
   if (!o || !lse || fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo)) return PVRL_EINVAL;
-  p.o = (bf16*)o; p.lse = lse;
+  p.o = (op_t*)o; p.lse = lse;
   hipLaunchKernelGGL(pattn_fwd_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, p);
   PVRL_LAUNCH_CHECK();
@@ -541,8 +541,8 @@ extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, c
     return PVRL_EINVAL;
   if (workspace_bytes < pvrl_mvit_attn_bwd_workspace_bytes(B, H, Lq, kt, kh, kw)) return PVRL_EINVAL;
   p.kv_part = (float*)workspace;
-  p.o = (bf16*)o; p.d_o = (const bf16*)d_o; p.lse = (float*)lse; p.delta = delta;
-  p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.drel = drel;
+  p.o = (op_t*)o; p.d_o = (const op_t*)d_o; p.lse = (float*)lse; p.delta = delta;
+  p.dq = (op_t*)dq; p.dk = (op_t*)dk; p.dv = (op_t*)dv; p.drel = drel;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pattn_bwd_q_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();

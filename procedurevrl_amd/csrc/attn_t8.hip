@@ -16,18 +16,18 @@ namespace {
 constexpr int PITCH = 144;  // 128 B row + 16 B pad: conflict-free ds_read_b128 across rows
 constexpr int TILE = 8 * PITCH;
 
-__device__ __forceinline__ float dot8(const bf16x8 a, const bf16x8 b) {
+__device__ __forceinline__ float dot8(const opx8 a, const opx8 b) {
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) s = fmaf((float)a[e], (float)b[e], s);
   return s;
 }
-__device__ __forceinline__ bf16x8 lds8(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ opx8 lds8(const char* p) { return *reinterpret_cast<const opx8*>(p); }
 
 template <bool BWD>
-__global__ __launch_bounds__(256) void attn_t8_kernel(const bf16* __restrict__ qkv, long ld, int ntask, int H, float scale,
-                                                      bf16* __restrict__ o, const bf16* __restrict__ d_o, long ldo,
-                                                      bf16* __restrict__ dqkv, long ldd) {
+__global__ __launch_bounds__(256) void attn_t8_kernel(const op_t* __restrict__ qkv, long ld, int ntask, int H, float scale,
+                                                      op_t* __restrict__ o, const op_t* __restrict__ d_o, long ldo,
+                                                      op_t* __restrict__ dqkv, long ldd) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 4 * TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   char* sq = smem + wave * 4 * TILE;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const bf16* __restrict__ q
   const int r8 = lane >> 3, c8 = lane & 7;
   const long grow = (long)seq * 8 + r8;
   {
-    const bf16* src = qkv + grow * ld + h * 64 + c8 * 8;
+    const op_t* src = qkv + grow * ld + h * 64 + c8 * 8;
     const u32x4 a = *reinterpret_cast<const u32x4*>(src);
     const u32x4 b = *reinterpret_cast<const u32x4*>(src + HD);
     const u32x4 c = *reinterpret_cast<const u32x4*>(src + 2 * HD);
@@ -76,15 +76,15 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const bf16* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float pj = __shfl(pr, (lane & ~7) | j, 64);
-      const bf16x8 v = lds8(sv + j * PITCH + c8 * 16);
+      const opx8 v = lds8(sv + j * PITCH + c8 * 16);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)v[e], acc[e]);
     }
     if (valid) {
-      bf16x8 ov;
+      opx8 ov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = (bf16)acc[e];
-      *reinterpret_cast<bf16x8*>(o + grow * ldo + h * 64 + c8 * 8) = ov;
+      for (int e = 0; e < 8; ++e) ov[e] = (op_t)acc[e];
+      *reinterpret_cast<opx8*>(o + grow * ldo + h * 64 + c8 * 8) = ov;
     }
   } else {
     float dp = 0.f;
@@ -102,12 +102,12 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const bf16* __restrict__ q
     for (int t = 0; t < 8; ++t) {
       // dq[i = r8][chunk c8] += dS[r8][t] * k[t]
       const float ds_it = __shfl(ds, (lane & ~7) | t, 64);
-      const bf16x8 kv = lds8(sk + t * PITCH + c8 * 16);
+      const opx8 kv = lds8(sk + t * PITCH + c8 * 16);
       // dk[j = r8][chunk c8] += dS[t][r8] * q[t] ; dv[j = r8] += P[t][r8] * dO[t]
       const float ds_tj = __shfl(ds, t * 8 + r8, 64);
       const float p_tj = __shfl(pr, t * 8 + r8, 64);
-      const bf16x8 qv = lds8(sq + t * PITCH + c8 * 16);
-      const bf16x8 dv = lds8(sd + t * PITCH + c8 * 16);
+      const opx8 qv = lds8(sq + t * PITCH + c8 * 16);
+      const opx8 dv = lds8(sd + t * PITCH + c8 * 16);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         aq[e] = fmaf(ds_it, (float)kv[e], aq[e]);
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const bf16* __restrict__ q
       }
     }
     if (valid) {
-      bf16x8 oq, ok, ov;
+      opx8 oq, ok, ov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { oq[e] = (bf16)aq[e]; ok[e] = (bf16)ak[e]; ov[e] = (bf16)av[e]; }
-      bf16* dst = dqkv + grow * ldd + h * 64 + c8 * 8;
-      *reinterpret_cast<bf16x8*>(dst) = oq;
-      *reinterpret_cast<bf16x8*>(dst + HD) = ok;
-      *reinterpret_cast<bf16x8*>(dst + 2 * HD) = ov;
+      for (int e = 0; e < 8; ++e) { oq[e] = (op_t)aq[e]; ok[e] = (op_t)ak[e]; ov[e] = (op_t)av[e]; }
+      op_t* dst = dqkv + grow * ldd + h * 64 + c8 * 8;
+      *reinterpret_cast<opx8*>(dst) = oq;
+      *reinterpret_cast<opx8*>(dst + HD) = ok;
+      *reinterpret_cast<opx8*>(dst + 2 * HD) = ov;
     }
   }
 }
@@ -135,8 +135,8 @@ extern "C" int pvrl_attn_t8_fwd(const void* qkv, int64_t ld, int64_t nseq, int64
   if (!qkv || !o || H <= 0 || (ld % 8) || (ldo % 8)) return PVRL_EINVAL;
   const int ntask = (int)(nseq * H);
   hipLaunchKernelGGL((attn_t8_kernel<false>), dim3((unsigned)cdiv(ntask, 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)qkv, (long)ld, ntask, (int)H, scale, (bf16*)o, (const bf16*)nullptr, (long)ldo,
-                     (bf16*)nullptr, 0L);
+                     (const op_t*)qkv, (long)ld, ntask, (int)H, scale, (op_t*)o, (const op_t*)nullptr, (long)ldo,
+                     (op_t*)nullptr, 0L);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -147,8 +147,8 @@ extern "C" int pvrl_attn_t8_bwd(const void* qkv, int64_t ld, int64_t nseq, int64
   if (!qkv || !d_o || !dqkv || H <= 0 || (ld % 8) || (ldo % 8) || (ldd % 8)) return PVRL_EINVAL;
   const int ntask = (int)(nseq * H);
   hipLaunchKernelGGL((attn_t8_kernel<true>), dim3((unsigned)cdiv(ntask, 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)qkv, (long)ld, ntask, (int)H, scale, (bf16*)nullptr, (const bf16*)d_o, (long)ldo,
-                     (bf16*)dqkv, (long)ldd);
+                     (const op_t*)qkv, (long)ld, ntask, (int)H, scale, (op_t*)nullptr, (const op_t*)d_o, (long)ldo,
+                     (op_t*)dqkv, (long)ldd);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

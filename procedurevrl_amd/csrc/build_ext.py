@@ -12,6 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libpvrl_hip.so")
+# (library, object directory, extra flags): the same sources built for each 16-bit operand type (common.h)
+FLAVOURS = {"bf16": (LIB, "build", []), "f16": (os.path.join(HERE, "libpvrl_hip_f16.so"), "build_f16", ["-DPVRL_OPERAND_F16"])}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -33,8 +35,16 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(force=False, verbose=True):
-    objdir = os.path.join(HERE, "build")
+def build(force=False, verbose=True, flavours=("bf16", "f16")):
+    """compile every flavour's library; returns the default (bf16) library path"""
+    for fl in flavours:
+        _build_one(fl, force, verbose)
+    return LIB
+
+
+def _build_one(flavour, force, verbose):
+    LIB, objname, extra = FLAVOURS[flavour]
+    objdir = os.path.join(HERE, objname)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _deps_mtime()
@@ -49,7 +59,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         sp, op = job
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+        cmd = [hipcc] + FLAGS + extra + ["-c", sp, "-o", op]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stderr}")

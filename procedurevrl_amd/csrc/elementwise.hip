@@ -11,7 +11,7 @@
 namespace {
 
 // frames fp32 [B][3][T][HI][WI]  ->  out bf16 [(b, n, t)][c*256 + py*16 + px]
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ frames, bf16* __restrict__ out, int B,
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ frames, op_t* __restrict__ out, int B,
                                                        int T, int HI, int WI, long ldo) {
   const int xg = WI >> 3;  // groups of 8 pixels per image row
   const long total = (long)B * 3 * T * HI * xg;
@@ -26,13 +26,13 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const float* src = frames + idx * 8;
     const f32x4 a = *reinterpret_cast<const f32x4*>(src);
     const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
-    bf16x8 o;
+    opx8 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = (bf16)a[e]; o[4 + e] = (bf16)d[e]; }
+    for (int e = 0; e < 4; ++e) { o[e] = (op_t)a[e]; o[4 + e] = (op_t)d[e]; }
     const int n = (y >> 4) * PW + (x8 >> 1);
     const long row = ((long)b * PH * PW + n) * T + t;
     const int col = c * 256 + (y & 15) * 16 + (x8 & 1) * 8;
-    *reinterpret_cast<bf16x8*>(out + row * ldo + col) = o;
+    *reinterpret_cast<opx8*>(out + row * ldo + col) = o;
   }
 }
 
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 //   ->  out bf16 [(b, n, t)][c*256 + py*16 + px] of the (crop x crop) clip, normalised (v/255 - mean)/std.
 // One thread = 8 consecutive output pixels of one row, all 3 channels (interleaved source bytes are read once).
 __global__ __launch_bounds__(256) void frames_u8_patchify_kernel(const unsigned char* __restrict__ frames,
-                                                                 const int* __restrict__ prm, bf16* __restrict__ out,
+                                                                 const int* __restrict__ prm, op_t* __restrict__ out,
                                                                  int B, int T, int H0, int W0, int crop, float m0,
                                                                  float m1, float m2, float s0, float s1, float s2,
                                                                  long ldo) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void frames_u8_patchify_kernel(const unsigned 
     const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
     const unsigned char* f0 = frames + (((long)b * T + t) * H0 + y0) * W0 * 3;
     const unsigned char* f1 = frames + (((long)b * T + t) * H0 + y1) * W0 * 3;
-    bf16x8 o[3];
+    opx8 o[3];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int x = x8 * 8 + e;
@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void frames_u8_patchify_kernel(const unsigned 
       for (int c = 0; c < 3; ++c) {
         const float v = ly0 * (lx0 * (float)f0[x0 * 3 + c] + lx1 * (float)f0[x1 * 3 + c]) +
                         ly1 * (lx0 * (float)f1[x0 * 3 + c] + lx1 * (float)f1[x1 * 3 + c]);
-        o[c][e] = (bf16)((v / 255.0f - mean[c]) * istd[c]);
+        o[c][e] = (op_t)((v / 255.0f - mean[c]) * istd[c]);
       }
     }
     const int n = (y >> 4) * PW + (x8 >> 1);
     const long row = ((long)b * (crop >> 4) * PW + n) * T + t;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      *reinterpret_cast<bf16x8*>(out + row * ldo + c * 256 + (y & 15) * 16 + (x8 & 1) * 8) = o[c];
+      *reinterpret_cast<opx8*>(out + row * ldo + c * 256 + (y & 15) * 16 + (x8 & 1) * 8) = o[c];
   }
 }
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 
 // out bf16[m][c] = rowscale[m] * in fp32[m][c]
 __global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict__ in, long ldi,
-                                                         const float* __restrict__ rowscale, bf16* __restrict__ out,
+                                                         const float* __restrict__ rowscale, op_t* __restrict__ out,
                                                          long ldo, long M, int C) {
   const int c8n = C >> 3;
   const long total = M * c8n;
@@ -170,15 +170,15 @@ __global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict
     const float* src = in + m * ldi + c8 * 8;
     const f32x4 a = *reinterpret_cast<const f32x4*>(src);
     const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
-    bf16x8 o;
+    opx8 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = (bf16)(rs * a[e]); o[4 + e] = (bf16)(rs * d[e]); }
-    *reinterpret_cast<bf16x8*>(out + m * ldo + c8 * 8) = o;
+    for (int e = 0; e < 4; ++e) { o[e] = (op_t)(rs * a[e]); o[4 + e] = (op_t)(rs * d[e]); }
+    *reinterpret_cast<opx8*>(out + m * ldo + c8 * 8) = o;
   }
 }
 
 // W fp32 [R][C] -> Wt bf16 [C][R]   (32x32 LDS tiles)
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, bf16* __restrict__ out, int R,
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, op_t* __restrict__ out, int R,
                                                              int C) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -192,14 +192,14 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + ty + 8 * k, r = r0 + tx;
-    if (r < R && c < C) out[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+    if (r < R && c < C) out[(long)c * R + r] = (op_t)tile[tx][ty + 8 * k];
   }
 }
 
 // W fp32 [R][C] -> Wb bf16 [R][C] and Wt bf16 [C][R] in one pass (both GEMM operand copies of a weight matrix)
 // (ldo / ldt: leading dimensions of the two copies -- larger than C / R when the copies live in zero-padded buffers)
-__global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                          bf16* __restrict__ out_t, int R, int C, long ldo, long ldt) {
+__global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ in, op_t* __restrict__ out,
+                                                          op_t* __restrict__ out_t, int R, int C, long ldo, long ldt) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     const int r = r0 + ty + 8 * k, c = c0 + tx;
     const float v = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
     tile[ty + 8 * k][tx] = v;
-    if (r < R && c < C) out[(long)r * ldo + c] = (bf16)v;
+    if (r < R && c < C) out[(long)r * ldo + c] = (op_t)v;
   }
   __syncthreads();
   if (out_t) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < R && c < C) out_t[(long)c * ldt + r] = (bf16)tile[tx][ty + 8 * k];
+      if (r < R && c < C) out_t[(long)c * ldt + r] = (op_t)tile[tx][ty + 8 * k];
     }
   }
 }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const TW* __restrict__ W
 
 // The same for up to 96 weight matrices in ONE launch (a ViT-B encoder has 85: one 6-us launch each otherwise).
 constexpr int CAST_MULTI_MAX = 96;
-struct CastItem { const float* in; bf16* out; bf16* out_t; int R, C, first, tiles_c; };
+struct CastItem { const float* in; op_t* out; op_t* out_t; int R, C, first, tiles_c; };
 struct CastMulti { int n; CastItem it[CAST_MULTI_MAX]; };
 __global__ __launch_bounds__(256) void cast_weight_multi_kernel(CastMulti g) {
   __shared__ float tile[32][33];
@@ -254,14 +254,14 @@ __global__ __launch_bounds__(256) void cast_weight_multi_kernel(CastMulti g) {
     const int r = r0 + ty + 8 * k, c = c0 + tx;
     const float v = (r < w.R && c < w.C) ? w.in[(long)r * w.C + c] : 0.f;
     tile[ty + 8 * k][tx] = v;
-    if (r < w.R && c < w.C) w.out[(long)r * w.C + c] = (bf16)v;
+    if (r < w.R && c < w.C) w.out[(long)r * w.C + c] = (op_t)v;
   }
   __syncthreads();
   if (w.out_t) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + ty + 8 * k, r = r0 + tx;
-      if (r < w.R && c < w.C) w.out_t[(long)c * w.R + r] = (bf16)tile[tx][ty + 8 * k];
+      if (r < w.R && c < w.C) w.out_t[(long)c * w.R + r] = (op_t)tile[tx][ty + 8 * k];
     }
   }
 }
@@ -290,13 +290,13 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict
 // out bf16[g*G + t][c] = alpha * scale[g*G + t] * in fp32[g][c]
 __global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ in, long ldi, int groups, int G, int C,
                                                           const float* __restrict__ scale, float alpha,
-                                                          bf16* __restrict__ out, long ldo) {
+                                                          op_t* __restrict__ out, long ldo) {
   const long total = (long)groups * G * C;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % C);
     const long r = idx / C;
     const long g = r / G;
-    out[r * ldo + c] = (bf16)(alpha * (scale ? scale[r] : 1.f) * in[g * ldi + c]);
+    out[r * ldo + c] = (op_t)(alpha * (scale ? scale[r] : 1.f) * in[g * ldi + c]);
   }
 }
 
@@ -314,7 +314,7 @@ extern "C" int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t 
   if (B <= 0) return PVRL_OK;
   if (!frames || !out || (HI % 16) || (WI % 16) || (ldo % 8) || ldo < 768) return PVRL_EINVAL;
   const long total = B * 3 * T * HI * (WI >> 3);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out,
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (op_t*)out,
                      (int)B, (int)T, (int)HI, (int)WI, (long)ldo);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -330,7 +330,7 @@ extern "C" int pvrl_frames_u8_patchify(const void* frames, const int32_t* params
   if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return PVRL_EINVAL;
   const long total = B * T * crop * (crop >> 3);
   hipLaunchKernelGGL(frames_u8_patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned char*)frames, (const int*)params, (bf16*)out, (int)B, (int)T, (int)H0, (int)W0,
+                     (const unsigned char*)frames, (const int*)params, (op_t*)out, (int)B, (int)T, (int)H0, (int)W0,
                      (int)crop, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (long)ldo);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -371,7 +371,7 @@ extern "C" int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* r
   if (M <= 0) return PVRL_OK;
   if (!in || !out || (C % 8) || (ldi % 4) || (ldo % 8)) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_scale_kernel, dim3(grid_for(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, in, (long)ldi,
-                     rowscale, (bf16*)out, (long)ldo, (long)M, (int)C);
+                     rowscale, (op_t*)out, (long)ldo, (long)M, (int)C);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -379,7 +379,7 @@ extern "C" int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* r
 extern "C" int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, int64_t C, void* stream) {
   if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (bf16*)out, (int)R, (int)C);
+                     (hipStream_t)stream, in, (op_t*)out, (int)R, (int)C);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -387,7 +387,7 @@ extern "C" int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, i
 extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream) {
   if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)C, (long)R);
+                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)C, (long)R);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -398,7 +398,7 @@ extern "C" int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int6
   if (!W || !x || !y || C <= 0 || ld < C) return PVRL_EINVAL;
   const dim3 grid((unsigned)cdiv(R, 4)), blk(256);
   if (w_is_bf16)
-    hipLaunchKernelGGL(gemv_rows_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)W, (long)ld, (int)R, (int)C,
+    hipLaunchKernelGGL(gemv_rows_kernel<op_t>, grid, blk, 0, (hipStream_t)stream, (const op_t*)W, (long)ld, (int)R, (int)C,
                        x, beta, y);
   else
     hipLaunchKernelGGL(gemv_rows_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)W, (long)ld, (int)R, (int)C,
@@ -417,7 +417,7 @@ extern "C" int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* prob
       const pvrl_cast_problem& q = problems[i0 + i];
       if (!q.in || !q.out || q.R <= 0 || q.C <= 0) return PVRL_EINVAL;
       CastItem& w = g.it[i];
-      w.in = q.in; w.out = (bf16*)q.out; w.out_t = (bf16*)q.out_t; w.R = (int)q.R; w.C = (int)q.C;
+      w.in = q.in; w.out = (op_t*)q.out; w.out_t = (op_t*)q.out_t; w.R = (int)q.R; w.C = (int)q.C;
       w.first = blocks; w.tiles_c = (int)cdiv(q.C, 32);
       blocks += w.tiles_c * (int)cdiv(q.R, 32);
     }
@@ -431,7 +431,7 @@ extern "C" int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo
                                          int64_t C, void* stream) {
   if (!in || !out || R <= 0 || C <= 0 || ldo < C || (out_t && ldt < R)) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (bf16*)out, (bf16*)out_t, (int)R, (int)C, (long)ldo, (long)ldt);
+                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)ldo, (long)ldt);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -447,9 +447,9 @@ extern "C" int pvrl_group_reduce(const void* in, int in_is_f32, int64_t ldi, int
   hipLaunchKernelGGL((group_reduce_kernel<TI, TO>), grid, blk, 0, s, (const TI*)in, (long)ldi, (int)groups, (int)G, \
                      (int)C, scale, alpha, resid, (long)ldr, (TO*)out, (long)ldo)
   if (in_is_f32 && out_is_f32) GR(float, float);
-  else if (in_is_f32) GR(float, bf16);
-  else if (out_is_f32) GR(bf16, float);
-  else GR(bf16, bf16);
+  else if (in_is_f32) GR(float, op_t);
+  else if (out_is_f32) GR(op_t, float);
+  else GR(op_t, op_t);
 #undef GR
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -460,7 +460,9 @@ extern "C" int pvrl_group_bcast_bf16(const float* in, int64_t ldi, int64_t group
   if (groups <= 0) return PVRL_OK;
   if (!in || !out) return PVRL_EINVAL;
   hipLaunchKernelGGL(group_bcast_kernel, dim3(grid_for(groups * G * C)), dim3(256), 0, (hipStream_t)stream, in,
-                     (long)ldi, (int)groups, (int)G, (int)C, scale, alpha, (bf16*)out, (long)ldo);
+                     (long)ldi, (int)groups, (int)G, (int)C, scale, alpha, (op_t*)out, (long)ldo);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
+
+extern "C" int pvrl_operand_dtype(void) { return PVRL_OPERAND_CODE; }

@@ -27,7 +27,7 @@ struct Conv3dGeom {
 };
 
 // out bf16 [(b, to, ho, wo)][ldo]; column k = ((c*kt + a)*kh + y)*kw + x (the flatten order of Conv3d.weight), zero for k >= K
-__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ frames, bf16* __restrict__ out,
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ frames, op_t* __restrict__ out,
                                                        Conv3dGeom g, long ldo) {
   const int chunks = (int)(ldo >> 3);
   const long rows = (long)g.B * g.To * g.Ho * g.Wo;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
     const int ho = (int)(r % g.Ho); r /= g.Ho;
     const int to = (int)(r % g.To);
     const int b = (int)(r / g.To);
-    bf16x8 o;
+    opx8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = ch * 8 + e;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
         if (ti >= 0 && ti < g.T && yi >= 0 && yi < g.H && xi >= 0 && xi < g.W)
           v = frames[((((long)b * g.Cin + c) * g.T + ti) * g.H + yi) * g.W + xi];
       }
-      o[e] = (bf16)v;
+      o[e] = (op_t)v;
     }
-    *reinterpret_cast<bf16x8*>(out + (idx / chunks) * ldo + ch * 8) = o;
+    *reinterpret_cast<opx8*>(out + (idx / chunks) * ldo + ch * 8) = o;
   }
 }
 
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
 constexpr int LNG_MAX = 12;   // 64 lanes x 12 = 768
 
 __device__ __forceinline__ void st_val(float* p, float v) { *p = v; }
-__device__ __forceinline__ void st_val(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ void st_val(op_t* p, float v) { *p = (op_t)v; }
 __device__ __forceinline__ float ld_val(const float* p) { return *p; }
-__device__ __forceinline__ float ld_val(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ float ld_val(const op_t* p) { return (float)*p; }
 
 template <typename TO>
 __global__ __launch_bounds__(256) void ln_g_fwd_kernel(const float* __restrict__ x, long ldx,
@@ -208,21 +208,20 @@ struct PoolGeom {
   int col0;                 // first column of this tensor (q / k / v) in the packed activation; head h adds h*96
 };
 
-__device__ __forceinline__ void ld6(const bf16* p, float* v) {
+__device__ __forceinline__ void ld6(const op_t* p, float* v) {
   const unsigned* u = reinterpret_cast<const unsigned*>(p);   // 4-byte aligned (6-channel groups of 2-byte values)
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
     const unsigned w = u[e];
-    v[2 * e] = __uint_as_float(w << 16);
-    v[2 * e + 1] = __uint_as_float(w & 0xffff0000u);
+    op_unpack2(w, v[2 * e], v[2 * e + 1]);
   }
 }
-__device__ __forceinline__ void st6(bf16* p, const float* v) {
+__device__ __forceinline__ void st6(op_t* p, const float* v) {
   unsigned* u = reinterpret_cast<unsigned*>(p);
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    union { bf16x2 h; unsigned w; } x;
-    x.h[0] = (bf16)v[2 * e]; x.h[1] = (bf16)v[2 * e + 1];
+    union { opx2 h; unsigned w; } x;
+    x.h[0] = (op_t)v[2 * e]; x.h[1] = (op_t)v[2 * e + 1];
     u[e] = x.w;
   }
 }
@@ -233,10 +232,10 @@ __device__ __forceinline__ float sum16(float v) {   // over the 16 lanes that sh
 
 // y[bh][lo][96] = LayerNorm_96(conv3d_depthwise(x)[lo]) for lo < Lo, = LayerNorm_96(x_cls) for lo = Lo; conv output kept
 // (bf16) for the backward.  16 lanes per output token, 6 channels per lane.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ qkv, PoolGeom g,
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const op_t* __restrict__ qkv, PoolGeom g,
                                                        const float* __restrict__ w, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, bf16* __restrict__ y,
-                                                       bf16* __restrict__ cbuf) {
+                                                       const float* __restrict__ beta, float eps, op_t* __restrict__ y,
+                                                       op_t* __restrict__ cbuf) {
   __shared__ float ws[27 * HD];
   for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];   // [tap][c]
   __syncthreads();
@@ -295,9 +294,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ 
 
 // LayerNorm backward of the pooled tensor: dc = dLN(dy | c) (bf16, same layout), dgamma / dbeta accumulated atomically;
 // the cls token's dc goes straight to its row of the packed activation gradient (it bypassed the conv).
-__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ cbuf,
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const op_t* __restrict__ dy, const op_t* __restrict__ cbuf,
                                                           PoolGeom g, const float* __restrict__ gamma, float eps,
-                                                          bf16* __restrict__ dc, bf16* __restrict__ dqkv,
+                                                          op_t* __restrict__ dc, op_t* __restrict__ dqkv,
                                                           float* __restrict__ part) {
   __shared__ float red[2][16][HD];
   const int sub = threadIdx.x & 15, c0 = sub * 6, tl = threadIdx.x >> 4;
@@ -357,8 +356,8 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const bf16* __restrict
 // S > 0: spatial stride S (a power of two) with temporal stride 1 -- every shipped MViT config -- so the 39 stride
 // divisions / remainders per token become shifts and masks and the token decomposition is 32-bit; S = 0: any strides.
 template <int S>
-__global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict__ dc, PoolGeom g,
-                                                         const float* __restrict__ w, bf16* __restrict__ dqkv) {
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(const op_t* __restrict__ dc, PoolGeom g,
+                                                         const float* __restrict__ w, op_t* __restrict__ dqkv) {
   __shared__ float ws[27 * HD];
   for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];
   __syncthreads();
@@ -405,13 +404,16 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const bf16* __restrict_
 // block = 8 token lanes x 24 channel quads (8-byte loads); each thread keeps 27 x 4 sums in registers (no atomics).  The 27 neighbour
 // loads of a token are unconditional (clamped address, 0/1 mask) so they are all in flight together.
 constexpr int PW_LANES = 8, PW_CQ = HD / 4;
-__device__ __forceinline__ f32x4 ld4bf(const bf16* p) {
+__device__ __forceinline__ f32x4 ld4bf(const op_t* p) {
   const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-  return (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
-                 __uint_as_float(w[1] & 0xffff0000u)};
+  f32x4 r;
+  float a, b;
+  op_unpack2(w[0], a, b); r[0] = a; r[1] = b;
+  op_unpack2(w[1], a, b); r[2] = a; r[3] = b;
+  return r;
 }
-__global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16* __restrict__ dc,
-                                                                      const bf16* __restrict__ qkv, PoolGeom g,
+__global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const op_t* __restrict__ dc,
+                                                                      const op_t* __restrict__ qkv, PoolGeom g,
                                                                       float* __restrict__ part) {
   __shared__ float red[27][HD];
   const int cq = threadIdx.x % PW_CQ, tl = threadIdx.x / PW_CQ, c0 = cq * 4;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const bf16
     const int h = (int)(bh % g.H), b = (int)(bh / g.H);
     const int xo = lo % g.Wo, yo = (lo / g.Wo) % g.Ho, to = lo / (g.Wo * g.Ho);
     const f32x4 d = ld4bf(dc + (bh * (Lo + 1) + lo) * HD + c0);
-    const bf16* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c0;
+    const op_t* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c0;
     f32x4 xv[27];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -589,7 +591,7 @@ struct RelGeom {
 };
 
 // rel[bh][q][j] = sum_c Q[bh][q][c] * R_j(q)[c],  R_j(q) = rel_pos_h[idx_h[qh(q)][j]] etc. (attention.py:97-115,139-151)
-__global__ __launch_bounds__(256) void rel_fwd_kernel(const bf16* __restrict__ Q, RelGeom g, const float* __restrict__ Rh,
+__global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q, RelGeom g, const float* __restrict__ Rh,
                                                       const float* __restrict__ Rw, const float* __restrict__ Rt,
                                                       const int* __restrict__ ih, const int* __restrict__ iw,
                                                       const int* __restrict__ it, float* __restrict__ rel) {
@@ -606,11 +608,11 @@ __global__ __launch_bounds__(256) void rel_fwd_kernel(const bf16* __restrict__ Q
     if (j < g.kh) R = Rh + (long)ih[y * g.kh + j] * HD;
     else if (j < g.kh + g.kw) R = Rw + (long)iw[x * g.kw + (j - g.kh)] * HD;
     else R = Rt + (long)it[t * g.kt + (j - g.kh - g.kw)] * HD;
-    const bf16* qp = Q + (bh * (Lq + 1) + q) * HD;
+    const op_t* qp = Q + (bh * (Lq + 1) + q) * HD;
     float a = 0.f;
 #pragma unroll 4
     for (int c8 = 0; c8 < HD / 8; ++c8) {                       // 16-byte loads: 8 bf16 of q, 2 x 4 floats of R
-      const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + c8 * 8);
+      const opx8 qv = *reinterpret_cast<const opx8*>(qp + c8 * 8);
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(R + c8 * 8), r1 = *reinterpret_cast<const f32x4*>(R + c8 * 8 + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) a = fmaf((float)qv[e], r0[e], fmaf((float)qv[4 + e], r1[e], a));
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
                                                         const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                         const float* __restrict__ Rt, const int* __restrict__ ih,
                                                         const int* __restrict__ iw, const int* __restrict__ it,
-                                                        bf16* __restrict__ dQ) {
+                                                        op_t* __restrict__ dQ) {
   const int J = g.kh + g.kw + g.kt;
   const int Lq = g.qt * g.qh * g.qw;
   const long total = (long)g.BH * Lq * (HD / 4);
@@ -640,10 +642,10 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
     for (int j = 0; j < g.kh; ++j) a += d[j] * *reinterpret_cast<const f32x4*>(Rh + (long)ih[y * g.kh + j] * HD + c);
     for (int j = 0; j < g.kw; ++j) a += d[g.kh + j] * *reinterpret_cast<const f32x4*>(Rw + (long)iw[x * g.kw + j] * HD + c);
     for (int j = 0; j < g.kt; ++j) a += d[g.kh + g.kw + j] * *reinterpret_cast<const f32x4*>(Rt + (long)it[t * g.kt + j] * HD + c);
-    bf16x4* p = reinterpret_cast<bf16x4*>(dQ + (bh * (Lq + 1) + q) * HD + c);
-    bf16x4 v = *p;
+    opx4* p = reinterpret_cast<opx4*>(dQ + (bh * (Lq + 1) + q) * HD + c);
+    opx4 v = *p;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (bf16)((float)v[e] + a[e]);
+    for (int e = 0; e < 4; ++e) v[e] = (op_t)((float)v[e] + a[e]);
     *p = v;
   }
 }
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
 // dR_axis[idx[coord][j]][c] += sum over all (bh, q with that axis coordinate) drel[bh][q][off + j] * Q[bh][q][c]
 // grid (q_n, chunks of the (bh, other) range); block = 96 channels x 2 slices; a thread keeps all k_n <= 16 sums of its channel.
 constexpr int REL_KMAX = 16;
-__global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const bf16* __restrict__ Q,
+__global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const op_t* __restrict__ Q,
                                                             RelGeom g, int axis, float* __restrict__ part) {
   __shared__ float red[REL_KMAX][HD];
   const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
@@ -743,7 +745,7 @@ extern "C" int pvrl_im2col3d_bf16(const float* frames, int64_t B, int64_t Cin, i
   g.K = (int)(Cin * kt * kh * kw);
   if (ldo < g.K) return PVRL_EINVAL;
   const long total = (long)B * g.To * g.Ho * g.Wo * (ldo >> 3);
-  hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (bf16*)out, g,
+  hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (op_t*)out, g,
                      (long)ldo);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -760,8 +762,8 @@ extern "C" int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* ga
     hipLaunchKernelGGL(ln_g_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
                        eps, (float*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
   else
-    hipLaunchKernelGGL(ln_g_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
-                       eps, (bf16*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
+    hipLaunchKernelGGL(ln_g_fwd_kernel<op_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
+                       eps, (op_t*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -789,8 +791,8 @@ extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32,
                        (const float*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
                        (int)C, (int)Cpad, part, (long)M);
   else
-    hipLaunchKernelGGL(ln_g_bwd_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
+    hipLaunchKernelGGL(ln_g_bwd_kernel<op_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const op_t*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
                        (int)C, (int)Cpad, part, (long)M);
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(partials_add_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
@@ -818,8 +820,8 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   if (!qkv || !w || !gamma || !beta || !y || !conv_out || pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0)) return PVRL_EINVAL;
   const long ntok = (long)B * H * ((long)g.To * g.Ho * g.Wo + 1);
   if (ntok >= (1L << 27)) return PVRL_EINVAL;         // 16 lanes per token, 32-bit token arithmetic in the kernel
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, g,
-                     w, gamma, beta, eps, (bf16*)y, (bf16*)conv_out);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
+                     w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -844,8 +846,8 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   long blocks = (ntok * 16 + 255) / 256;
   if (blocks > PLN_MAX_WG) blocks = PLN_MAX_WG;
   float* lnpart = (float*)workspace + (long)PW_MAX_WG * 27 * HD;
-  hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)conv_out,
-                     g, gamma, eps, (bf16*)dc_scratch, (bf16*)dqkv, lnpart);
+  hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const op_t*)dy, (const op_t*)conv_out,
+                     g, gamma, eps, (op_t*)dc_scratch, (op_t*)dqkv, lnpart);
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(partials_add_kernel, dim3((2 * HD + 15) / 16), dim3(256), 0, s, (const float*)lnpart, (int)blocks,
                      2 * HD, dgamma, dbeta, HD);
@@ -855,7 +857,7 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   {
     const dim3 dg(grid_for(nin * 16)), db(256);
     const int S = (st == 1 && sh == sw && (sh == 1 || sh == 2 || sh == 4 || sh == 8)) ? (int)sh : 0;
-#define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const bf16*)dc_scratch, g, w, (bf16*)dqkv)
+#define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const op_t*)dc_scratch, g, w, (op_t*)dqkv)
     if (S == 1) DGRAD(1); else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
 #undef DGRAD
   }
@@ -863,8 +865,8 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
   if (wb > PW_MAX_WG) wb = PW_MAX_WG;
   if (wb < 1) wb = 1;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const bf16*)dc_scratch,
-                     (const bf16*)qkv, g, (float*)workspace);
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const op_t*)dc_scratch,
+                     (const op_t*)qkv, g, (float*)workspace);
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_wgrad_reduce_kernel, dim3(27 * HD / 16), dim3(256), 0, s, (const float*)workspace,
                      (int)wb, dw);
@@ -918,7 +920,7 @@ extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t 
   RelGeom g;
   if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !rel || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
   const long total = (long)BH * qt * qh * qw * (kh + kw + kt);
-  hipLaunchKernelGGL(rel_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)Q, g, Rh, Rw,
+  hipLaunchKernelGGL(rel_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const op_t*)Q, g, Rh, Rw,
                      Rt, idx_h, idx_w, idx_t, rel);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -954,7 +956,7 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)BH * qt * qh * qw * (HD / 4);
   hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
-                     (bf16*)dQ);
+                     (op_t*)dQ);
   PVRL_LAUNCH_CHECK();
   float* w = (float*)workspace;
   auto axis = [&](int ax, int64_t qn, int64_t kn, int64_t n_other, const int32_t* idx, int64_t nrows, float* dR) {
@@ -963,7 +965,7 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
     float* part = w;
     float* p2 = w + (long)ch * n;
     w = p2 + n;
-    hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qn, ch), dim3(192), 0, s, drel, (const bf16*)Q, g, ax, part);
+    hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qn, ch), dim3(192), 0, s, drel, (const op_t*)Q, g, ax, part);
     hipLaunchKernelGGL(rel_table_reduce1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)part,
                        (int)ch, n, p2);
     hipLaunchKernelGGL(rel_table_reduce2_kernel, dim3((unsigned)nrows), dim3(HD), 0, s, (const float*)p2, idx,

@@ -18,15 +18,15 @@ template <> struct Vec4IO<float> {
   static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 };
-template <> struct Vec4IO<bf16> {
-  static __device__ __forceinline__ f32x4 load(const bf16* p) {
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+template <> struct Vec4IO<op_t> {
+  static __device__ __forceinline__ f32x4 load(const op_t* p) {
+    const opx4 b = *reinterpret_cast<const opx4*>(p);
     return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
   }
-  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
-    bf16x4 b;
-    b[0] = (bf16)v[0]; b[1] = (bf16)v[1]; b[2] = (bf16)v[2]; b[3] = (bf16)v[3];
-    *reinterpret_cast<bf16x4*>(p) = b;
+  static __device__ __forceinline__ void store(op_t* p, f32x4 v) {
+    opx4 b;
+    b[0] = (op_t)v[0]; b[1] = (op_t)v[1]; b[2] = (op_t)v[2]; b[3] = (op_t)v[3];
+    *reinterpret_cast<opx4*>(p) = b;
   }
 };
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      long ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dx_in, long ldi, float* __restrict__ dx_out,
-                                                     long ldo, float* __restrict__ part, int M, bf16* __restrict__ dxs,
+                                                     long ldo, float* __restrict__ part, int M, op_t* __restrict__ dxs,
                                                      long ldxs, const float* __restrict__ dxs_scale, int dxs_rows,
                                                      int want_sum) {
   constexpr int NV = C / 256;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
       if (want_sum && row < dxs_rows) ds[j] += o;      // unscaled column sums of the rows that feed the next stage
       if (dxs && row < dxs_rows) {   // bf16 (optionally DropPath-scaled) copy: the GEMM operand of the next backward stage
         const float sc = dxs_scale ? dxs_scale[row] : 1.f;
-        Vec4IO<bf16>::store(dxs + (long)row * ldxs + c, sc * o);
+        Vec4IO<op_t>::store(dxs + (long)row * ldxs + c, sc * o);
       }
     }
   }
@@ -196,7 +196,7 @@ extern "C" int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
     hipLaunchKernelGGL((ln_fwd_kernel<CC, float>), grid, blk, 0, s, x, (long)ldx, gamma, beta, eps, (float*)y,       \
                        (long)ldy, mean, rstd, (int)M);                                                              \
   else                                                                                                              \
-    hipLaunchKernelGGL((ln_fwd_kernel<CC, bf16>), grid, blk, 0, s, x, (long)ldx, gamma, beta, eps, (bf16*)y,         \
+    hipLaunchKernelGGL((ln_fwd_kernel<CC, op_t>), grid, blk, 0, s, x, (long)ldx, gamma, beta, eps, (op_t*)y,         \
                        (long)ldy, mean, rstd, (int)M);
   if (C == 768) { LN_FWD(768) } else if (C == 512) { LN_FWD(512) } else return PVRL_EINVAL;
 #undef LN_FWD
@@ -228,11 +228,11 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
   if (dy_is_f32)                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, float>), dim3(nblk), dim3(256), 0, s, (const float*)dy, (long)lddy, x,      \
                        (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
-                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);                               \
+                       (op_t*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);                               \
   else                                                                                                               \
-    hipLaunchKernelGGL((ln_bwd_kernel<CC, bf16>), dim3(nblk), dim3(256), 0, s, (const bf16*)dy, (long)lddy, x,        \
+    hipLaunchKernelGGL((ln_bwd_kernel<CC, op_t>), dim3(nblk), dim3(256), 0, s, (const op_t*)dy, (long)lddy, x,        \
                        (long)ldx, mean, rstd, gamma, dx_in, (long)ldi, dx_out, (long)ldo, part, (int)M,              \
-                       (bf16*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);
+                       (op_t*)dxs_bf16, (long)ldxs, dxs_scale, (int)dxs_rows, want_sum);
   if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();

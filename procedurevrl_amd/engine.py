@@ -23,8 +23,9 @@ from . import ops
 from ._lib import lib
 from .transform import DecodedClips
 
-BF16 = torch.bfloat16
+OP16 = ops.OP16
 F32 = torch.float32
+SCALED_GRADS = OP16 == torch.float16     # fp16-operand flavour: engines scale their internal gradients (GradStore.begin_scaled)
 
 
 class GradStore:
@@ -49,6 +50,8 @@ class GradStore:
         self.used = self.flat[off:off + len(sizes)]
         self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.scale = None       # fp16 flavour: device scalar S while an engine's backward runs with S-scaled gradients
+        self._touched = []
 
     def span(self, i):
         """[a, b) of parameter i in the flat buffer, padding included"""
@@ -60,11 +63,65 @@ class GradStore:
         v = self.views[i]
         if p.grad is None:
             p.grad = v
-            return v, 0.0
-        if p.grad.data_ptr() == v.data_ptr():
-            return v, 1.0
-        # a foreign .grad tensor (someone else allocated it): accumulate into it
-        return p.grad, 1.0
+            t, beta = v, 0.0
+        elif p.grad.data_ptr() == v.data_ptr():
+            t, beta = v, 1.0
+        else:       # a foreign .grad tensor (someone else allocated it): accumulate into it
+            t, beta = p.grad, 1.0
+        if self.scale is not None:
+            key = i if t is v else t
+            seen = self._seen_idx if t is v else self._seen_ptr
+            tag = i if t is v else t.data_ptr()
+            if tag not in seen:
+                seen.add(tag)
+                if beta == 1.0:
+                    t.mul_(self.scale)      # what is already there joins the S-scaled units until the engine is done
+            self._touched.append(key)
+        return t, beta
+
+    # ---- fp16-operand flavour: gradient scaling inside an engine's backward -------------------------------------------
+    # fp16 has 5 exponent bits: the 16-bit gradient operands of the backward GEMMs (rms 1e-6 .. 1e-4 at the benchmark
+    # shapes) would underflow.  An engine therefore multiplies the gradient it receives by a power of two S, chosen on the
+    # DEVICE from that gradient's magnitude (no host sync, capturable in a HIP graph), runs its whole backward in S-scaled
+    # units -- exact in fp32, and the 16-bit operands sit mid-range -- and multiplies every parameter gradient it produced
+    # by 1/S before anyone outside the engine sees it.  Nothing outside the engine ever holds a scaled value.
+    SCALE_TARGET = 256.0          # S * max|incoming gradient|; the largest internal operand stays ~100x below fp16's 65504
+
+    def begin_scaled(self, g):
+        """g: the fp32 gradient entering the engine -> g * S; registers S for target() / unscale()"""
+        amax = g.detach().abs().max().clamp_min(1e-30)
+        self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)))
+        self._touched, self._seen_idx, self._seen_ptr = [], set(), set()
+        return g * self.scale
+
+    def unscale(self):
+        """multiply every gradient written since the last call by 1/S (contiguous runs of the flat buffer in one op each)"""
+        if self.scale is None or not self._touched:
+            return
+        inv = 1.0 / self.scale
+        idx = sorted(set(k for k in self._touched if isinstance(k, int)))
+        runs = []
+        for i in idx:
+            a, b = self.span(i)
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        for a, b in runs:
+            self.flat[a:b].mul_(inv)
+        done = set()
+        for k in self._touched:
+            if not isinstance(k, int) and k.data_ptr() not in done:
+                done.add(k.data_ptr())
+                k.mul_(inv)
+        self._touched = []
+
+    def end_scaled(self):
+        """-> 1/S (device scalar) for gradients the engine hands back to autograd (StackEngine's dx)"""
+        self.unscale()
+        inv = 1.0 / self.scale
+        self.scale = None
+        return inv
 
 
 class _W:
@@ -312,10 +369,10 @@ class EncoderEngine(GraphReplay):
             if not w2.is_contiguous():
                 continue                       # left to _weight()
             if e.w is None or e.w.device != p.device:
-                e.w = torch.empty(w2.shape, device=p.device, dtype=BF16)
+                e.w = torch.empty(w2.shape, device=p.device, dtype=OP16)
                 e.t = None
             if need_t and e.t is None:
-                e.t = torch.empty((w2.shape[1], w2.shape[0]), device=p.device, dtype=BF16)
+                e.t = torch.empty((w2.shape[1], w2.shape[0]), device=p.device, dtype=OP16)
             todo.append((w2, e.w, e.t if need_t else None, e, ver))
         if todo:
             ops.cast_weights_multi([(w2, w, t) for w2, w, t, _, _ in todo])
@@ -393,9 +450,9 @@ class EncoderEngine(GraphReplay):
         overlap_wgrad, ordered after everything the current stream has produced so far."""
         q, self._wq = self._wq, []
         post, self._wpost = self._wpost, []
-        if not q:
+        if not q and not post:
             return
-        side = self.side_stream(q[0][0].device)
+        side = self.side_stream(q[0][0].device if q else torch.device("cuda", torch.cuda.current_device()))
         if side is None:
             ops.gemm_tn_grouped(q, ws_tag="tn")
             for f in post:
@@ -545,7 +602,7 @@ class EncoderEngine(GraphReplay):
         # ---- spatial branch (vit.py:137-151), all rows; cls of clip b is token 0 of its T sequences ----
         h_s, mean_s, rstd_s = ops.layernorm_fwd(x1, P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
         qkv_s = ops.gemm_nt(h_s, self._weight(blk.attn.qkv.weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
-        o_s = torch.empty((R + B * T, C), device=dev, dtype=BF16)
+        o_s = torch.empty((R + B * T, C), device=dev, dtype=OP16)
         _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
         x2 = torch.empty_like(x0)
         wproj = self._weight(blk.attn.proj.weight).w
@@ -616,11 +673,14 @@ class EncoderEngine(GraphReplay):
         assert sv is not None, "backward() without a saved forward()"
         gs = self.grad_store()
         R, M = sv["R"], sv["M"]
+        if SCALED_GRADS:
+            dfeat = gs.begin_scaled(dfeat)
         dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
         mean, rstd = sv["norm_stats"]
         (dg, bg), (db, bb) = gs.target(m.norm.weight), gs.target(m.norm.bias)
         ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
                           dx_out=dx[R:], beta_acc=bg)
+        gs.unscale()
         # dy = bf16(DropPath-scale * dx) is the operand of each block's first backward GEMMs; after the first block it is
         # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
         last = len(m.blocks) - 1
@@ -654,8 +714,12 @@ class EncoderEngine(GraphReplay):
                                       "resizes at inference only, vit.py:374)")
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
+        if gs.scale is not None:
+            self._wpost.append(gs.unscale)      # behind the patch-embed weight gradient, on its stream
         self.flush_wgrads()
         self.join_side_stream()
+        if gs.scale is not None:
+            gs.end_scaled()
         self.saved = None
 
     @staticmethod
@@ -693,14 +757,14 @@ class EncoderEngine(GraphReplay):
         wgrad(du, s["h_m"], blk.mlp.fc1)
         dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
         del du
-        dps = torch.empty((R + B * T, C), device=dev, dtype=BF16)
+        dps = torch.empty((R + B * T, C), device=dev, dtype=OP16)
         lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx, dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
 
         # ---- spatial ----
         ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
         wgrad(dps, s["o_s"], blk.attn.proj)
         do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
-        dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=BF16)
+        dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=OP16)
         ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
                      mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
         ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
@@ -708,7 +772,7 @@ class EncoderEngine(GraphReplay):
         dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
         del dqkv, do, dps
         # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
-        dz = torch.empty((R, C), device=dev, dtype=BF16)
+        dz = torch.empty((R, C), device=dev, dtype=OP16)
         dbf, bbf = gs.target(blk.temporal_fc.bias)
         lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz, dxs_scale=s1_tok, dxsum=dbf, dxsum_beta=bbf)
 
@@ -727,9 +791,11 @@ class EncoderEngine(GraphReplay):
         # the block's input gradient is final after this kernel: it also emits the bf16 operand of the next stage
         # (previous block's MLP backward with that block's DropPath scale, or the patch-embed weight gradient)
         s3p = prev_dp["s3_all"] if (has_prev and prev_dp) else None
-        dy_next = torch.empty((M if has_prev else R, C), device=dev, dtype=BF16)
+        dy_next = torch.empty((M if has_prev else R, C), device=dev, dtype=OP16)
         lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R], dxs=dy_next[:R], dxs_scale=s3p)
         if has_prev:
             ops.cast_scale(dx[R:], s3p[R:] if s3p is not None else None, out=dy_next[R:])
+        if gs.scale is not None:
+            self._wpost.append(gs.unscale)      # this block's gradients are final behind the grouped launch + chain
         self.flush_wgrads()
         return dy_next

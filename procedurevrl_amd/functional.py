@@ -39,12 +39,18 @@ class StackFn(torch.autograd.Function):
         eng = StackEngine(resblocks, owner.weight_cache, owner.grad_target, heads=heads)
         need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[8])
         y, saved = eng.forward(x.contiguous(), nseq, S, causal=causal, kpm=kpm, save=need)
-        ctx.eng, ctx.saved_acts = eng, saved
+        ctx.eng, ctx.saved_acts, ctx.owner_ref = eng, saved, owner
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .engine import SCALED_GRADS
+        gs = ctx.owner_ref.grad_store() if SCALED_GRADS else None
+        if gs is not None:
+            dy = gs.begin_scaled(dy)                 # fp16-operand flavour: the stack's backward runs in S-scaled units
         dx = ctx.eng.backward(dy.contiguous(), ctx.saved_acts)
+        if gs is not None:
+            dx = dx * gs.end_scaled()
         ctx.saved_acts = None
         return dx, None, None, None, None, None, None, None, None
 

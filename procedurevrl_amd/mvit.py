@@ -23,7 +23,7 @@ from .build import MODEL_REGISTRY
 from .engine import EncoderEngine, GradStore, GraphReplay
 from .vit import VisionTransformer as _StepMatchingModel, trunc_normal_
 
-BF16 = torch.bfloat16
+OP16 = ops.OP16
 F32 = torch.float32
 HD = 96
 
@@ -273,8 +273,8 @@ class MViTEngine(GraphReplay):
             Kp = om.pad128(K) if Kp is None else Kp
             if e is None or e.w.device != weight.device or tuple(e.w.shape) != (Np, Kp):
                 e = _PW()
-                e.w = torch.zeros((Np, Kp), device=weight.device, dtype=BF16)
-                e.t = torch.zeros((Kp, Np), device=weight.device, dtype=BF16)
+                e.w = torch.zeros((Np, Kp), device=weight.device, dtype=OP16)
+                e.t = torch.zeros((Kp, Np), device=weight.device, dtype=OP16)
                 e.b = torch.zeros(Np, device=weight.device, dtype=F32)
                 self._pw[id(weight)] = e
             lib().call("pvrl_cast_weight_pad_bf16", ops._ptr(w2), ops._ptr(e.w), Kp, ops._ptr(e.t), Np, N, K, ops._stream())
@@ -418,12 +418,18 @@ class MViTEngine(GraphReplay):
         Cl = enc.plan[-1]["dim_out"]
         Rl = xf.shape[0] - B
         dx = torch.zeros_like(xf)
+        from .engine import SCALED_GRADS
+        gs = self.m.grad_store() if SCALED_GRADS else None
+        if gs is not None:
+            dfeat = gs.begin_scaled(dfeat.float())     # fp16-operand flavour: backward in S-scaled units (GradStore.begin_scaled)
         dgn, dbn = self._acc_target(enc.norm.weight), self._acc_target(enc.norm.bias)
         dx[Rl:] = om.ln_bwd(dfeat.contiguous().float(), xf[Rl:], Cl, sv["f_mean"], sv["f_rstd"], enc.norm.weight.detach(),
                             dgn, dbn, Cpad=xf.shape[1])
         for i in range(len(enc.blocks) - 1, -1, -1):
             dx = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B)
             sv["blocks"][i] = None
+            if gs is not None:
+                gs.unscale()
             if self.grad_hook is not None:
                 self.grad_hook(i)
         # patch embed (weight gradient only: the input needs none) and cls token
@@ -436,6 +442,8 @@ class MViTEngine(GraphReplay):
         gc, bc = self._grad(enc.cls_token)
         s = ops.batch_sum(dx[R:], B, 1)
         om.copy2d(s.view(1, -1), gc.view(1, -1), 1, e0, beta=bc)
+        if gs is not None:
+            gs.end_scaled()
 
     def _block_bwd(self, i, blk, pl, s, dx2, B):
         L = lib()

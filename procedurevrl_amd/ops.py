@@ -8,9 +8,9 @@ import ctypes
 
 import torch
 
-from ._lib import lib, PvrlError
+from ._lib import lib, PvrlError, operand_torch_dtype
 
-BF16 = torch.bfloat16
+OP16 = operand_torch_dtype()     # the library flavour's 16-bit operand type: torch.bfloat16 (default) or torch.float16
 F32 = torch.float32
 
 # When set to a list, gemm launches are bracketed with events on the launch stream (bench.py roofline leg).
@@ -84,16 +84,16 @@ def _ld(t):
 def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=None, out1=None, bias2=None):
     """epilogue(A[M,K] @ W[N,K]^T).  Returns out0 (and out1 for the GELU epilogues)."""
     L = lib()
-    _chk2d(A, BF16); _chk2d(W, BF16)
+    _chk2d(A, OP16); _chk2d(W, OP16)
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K
     f32_out = epi in (L.PVRL_EPI_RESID_F32, L.PVRL_EPI_F32)
     if out0 is None:
-        out0 = torch.empty((M, N), device=A.device, dtype=F32 if f32_out else BF16)
+        out0 = torch.empty((M, N), device=A.device, dtype=F32 if f32_out else OP16)
     two = epi in (L.PVRL_EPI_GELU, L.PVRL_EPI_QGELU)
     if two and out1 is None:
-        out1 = torch.empty((M, N), device=A.device, dtype=BF16)
+        out1 = torch.empty((M, N), device=A.device, dtype=OP16)
     _timed("gemm_nt_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
         _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
@@ -141,7 +141,7 @@ def tn_splits(M, N, K):
 def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
     """dW[N,K] = beta*dW + P[M,N]^T @ Q[M,K]; dbias = beta*dbias + colsum(P)."""
     L = lib()
-    _chk2d(P, BF16); _chk2d(Q, BF16)
+    _chk2d(P, OP16); _chk2d(Q, OP16)
     M, N = P.shape
     K = Q.shape[1]
     assert Q.shape[0] == M and dW.shape == (N, K) and dW.is_contiguous() and dW.dtype == F32
@@ -175,7 +175,7 @@ def gemm_tn_grouped(problems, ws_tag="tn_group"):
     arr = (TnProblem * len(problems))()
     flops = 0.0
     for a, (P, Q, dW, dbias, beta) in zip(arr, problems):
-        _chk2d(P, BF16); _chk2d(Q, BF16)
+        _chk2d(P, OP16); _chk2d(Q, OP16)
         M, N = P.shape
         K = Q.shape[1]
         assert Q.shape[0] == M and dW.shape == (N, K) and dW.is_contiguous() and dW.dtype == F32
@@ -194,7 +194,7 @@ def gemm_tn_grouped(problems, ws_tag="tn_group"):
 # ----------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, out_dtype=BF16, out=None, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True):
     L = lib()
     _chk2d(x, F32)
     M, C = x.shape
@@ -240,18 +240,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
 # ----------------------------------------------------------------------------------------
 def attn_t8_fwd(qkv, nseq, H, scale, out=None):
     L = lib()
-    _chk2d(qkv, BF16)
+    _chk2d(qkv, OP16)
     if out is None:
-        out = torch.empty((nseq * 8, H * 64), device=qkv.device, dtype=BF16)
+        out = torch.empty((nseq * 8, H * 64), device=qkv.device, dtype=OP16)
     L.call("pvrl_attn_t8_fwd", _ptr(qkv), _ld(qkv), nseq, H, float(scale), _ptr(out), _ld(out), _stream())
     return out
 
 
 def attn_t8_bwd(qkv, d_o, nseq, H, scale, dqkv=None):
     L = lib()
-    _chk2d(qkv, BF16); _chk2d(d_o, BF16)
+    _chk2d(qkv, OP16); _chk2d(d_o, OP16)
     if dqkv is None:
-        dqkv = torch.empty((nseq * 8, 3 * H * 64), device=qkv.device, dtype=BF16)
+        dqkv = torch.empty((nseq * 8, 3 * H * 64), device=qkv.device, dtype=OP16)
     L.call("pvrl_attn_t8_bwd", _ptr(qkv), _ld(qkv), nseq, H, float(scale), _ptr(d_o), _ld(d_o), _ptr(dqkv), _ld(dqkv),
            _stream())
     return dqkv
@@ -260,11 +260,11 @@ def attn_t8_bwd(qkv, d_o, nseq, H, scale, dqkv=None):
 def attn_fwd(qkv, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=None, o=None, o_cls=None, lse=None):
     """o / o_cls must share a leading dimension (o_cls may be a row-slice of the same buffer)."""
     L = lib()
-    _chk2d(qkv, BF16)
+    _chk2d(qkv, OP16)
     if o is None:
-        o = torch.empty((nseq * S if mode == 0 else cls_base, H * 64), device=qkv.device, dtype=BF16)
+        o = torch.empty((nseq * S if mode == 0 else cls_base, H * 64), device=qkv.device, dtype=OP16)
     if mode == 1 and o_cls is None:
-        o_cls = torch.empty((nseq, H * 64), device=qkv.device, dtype=BF16)
+        o_cls = torch.empty((nseq, H * 64), device=qkv.device, dtype=OP16)
     if lse is None:
         lse = torch.empty((nseq, H, S), device=qkv.device, dtype=F32)
     if o_cls is not None:
@@ -277,11 +277,11 @@ def attn_fwd(qkv, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=
 def attn_bwd(qkv, o, o_cls, d_o, d_o_cls, lse, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=None,
              dqkv=None, dqkv_cls=None):
     L = lib()
-    _chk2d(qkv, BF16)
+    _chk2d(qkv, OP16)
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     if mode == 1 and dqkv_cls is None:
-        dqkv_cls = torch.empty((nseq, qkv.shape[1]), device=qkv.device, dtype=BF16)
+        dqkv_cls = torch.empty((nseq, qkv.shape[1]), device=qkv.device, dtype=OP16)
     if dqkv_cls is not None:
         assert _ld(dqkv_cls) == _ld(dqkv)
     if o_cls is not None:
@@ -305,7 +305,7 @@ def patchify(frames, out=None):
     B, _, T, HI, WI = frames.shape
     rows = B * (HI // 16) * (WI // 16) * T
     if out is None:
-        out = torch.empty((rows, 768), device=frames.device, dtype=BF16)
+        out = torch.empty((rows, 768), device=frames.device, dtype=OP16)
     L.call("pvrl_patchify", _ptr(frames), B, T, HI, WI, _ptr(out), _ld(out), _stream())
     return out
 
@@ -324,7 +324,7 @@ def frames_u8_patchify(clips, out=None):
         raise ValueError("crop window leaves the rescaled frame")
     rows = B * (crop // 16) * (crop // 16) * T
     if out is None:
-        out = torch.empty((rows, 768), device=fr.device, dtype=BF16)
+        out = torch.empty((rows, 768), device=fr.device, dtype=OP16)
     mean = (ctypes.c_float * 3)(*clips.mean)
     std = (ctypes.c_float * 3)(*clips.std)
     L.call("pvrl_frames_u8_patchify", _ptr(fr), _ptr(clips.params), B, T, H0, W0, crop,
@@ -372,7 +372,7 @@ def cast_scale(x, rowscale=None, out=None):
     _chk2d(x, F32)
     M, C = x.shape
     if out is None:
-        out = torch.empty((M, C), device=x.device, dtype=BF16)
+        out = torch.empty((M, C), device=x.device, dtype=OP16)
     L.call("pvrl_cast_scale_bf16", _ptr(x), _ld(x), _ptr(rowscale), _ptr(out), _ld(out), M, C, _stream())
     return out
 
@@ -382,7 +382,7 @@ def cast_transpose(w, out=None):
     assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous()
     R, C = w.shape
     if out is None:
-        out = torch.empty((C, R), device=w.device, dtype=BF16)
+        out = torch.empty((C, R), device=w.device, dtype=OP16)
     L.call("pvrl_cast_transpose_bf16", _ptr(w), _ptr(out), R, C, _stream())
     return out
 
@@ -393,9 +393,9 @@ def cast_weight(w, out=None, out_t=None, need_t=True):
     assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous()
     R, C = w.shape
     if out is None:
-        out = torch.empty((R, C), device=w.device, dtype=BF16)
+        out = torch.empty((R, C), device=w.device, dtype=OP16)
     if need_t and out_t is None:
-        out_t = torch.empty((C, R), device=w.device, dtype=BF16)
+        out_t = torch.empty((C, R), device=w.device, dtype=OP16)
     L.call("pvrl_cast_weight_bf16", _ptr(w), _ptr(out), _ptr(out_t) if need_t else None, R, C, _stream())
     return out, (out_t if need_t else None)
 
@@ -408,7 +408,7 @@ def gemv_rows(W, x, out=None, beta=0.0):
     if out is None:
         out = torch.empty(R, device=W.device, dtype=F32)
     assert out.dtype == F32 and out.is_contiguous() and out.numel() == R
-    lib().call("pvrl_gemv_rows_f32", _ptr(W), 1 if W.dtype == BF16 else 0, _ld(W), R, C, _ptr(x), float(beta), _ptr(out),
+    lib().call("pvrl_gemv_rows_f32", _ptr(W), 1 if W.dtype == OP16 else 0, _ld(W), R, C, _ptr(x), float(beta), _ptr(out),
                _stream())
     return out
 
@@ -420,8 +420,8 @@ def cast_weights_multi(items):
         return
     arr = (CastProblem * len(items))()
     for a, (w, out, out_t) in zip(arr, items):
-        assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous() and out.is_contiguous() and out.dtype == BF16
-        assert out_t is None or (out_t.is_contiguous() and out_t.dtype == BF16)
+        assert w.dtype == F32 and w.dim() == 2 and w.is_contiguous() and out.is_contiguous() and out.dtype == OP16
+        assert out_t is None or (out_t.is_contiguous() and out_t.dtype == OP16)
         a.inp, a.out, a.out_t = w.data_ptr(), out.data_ptr(), (None if out_t is None else out_t.data_ptr())
         a.R, a.C = w.shape
     lib().call("pvrl_cast_weights_multi_bf16", len(items), ctypes.addressof(arr), _stream())
@@ -444,7 +444,7 @@ def group_bcast(x, groups, G, scale=None, alpha=1.0, out=None):
     _chk2d(x, F32)
     C = x.shape[1]
     if out is None:
-        out = torch.empty((groups * G, C), device=x.device, dtype=BF16)
+        out = torch.empty((groups * G, C), device=x.device, dtype=OP16)
     L.call("pvrl_group_bcast_bf16", _ptr(x), _ld(x), groups, G, C, _ptr(scale), float(alpha), _ptr(out), _ld(out),
            _stream())
     return out

@@ -4,7 +4,7 @@ no PyTorch compute fallback.  Pooled per-head tensors are [B*H, L+1, 96] bf16 wi
 import torch
 
 from ._lib import lib
-from .ops import BF16, F32, _ptr, _stream
+from .ops import OP16, F32, _ptr, _stream
 
 I32 = torch.int32
 HD = 96
@@ -20,12 +20,12 @@ def im2col3d(frames, kernel, stride, padding, ldo):
     assert frames.is_cuda and frames.dtype == F32 and frames.is_contiguous()
     B, Cin, T, H, W = frames.shape
     out_thw = tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip((T, H, W), kernel, stride, padding))
-    out = torch.empty((B * out_thw[0] * out_thw[1] * out_thw[2], ldo), device=frames.device, dtype=BF16)
+    out = torch.empty((B * out_thw[0] * out_thw[1] * out_thw[2], ldo), device=frames.device, dtype=OP16)
     L.call("pvrl_im2col3d_bf16", _ptr(frames), B, Cin, T, H, W, *kernel, *stride, *padding, _ptr(out), ldo, _stream())
     return out, out_thw
 
 
-def ln_fwd(x, C, gamma, beta, eps, out_dtype=BF16, Cpad=None, stats=True):
+def ln_fwd(x, C, gamma, beta, eps, out_dtype=OP16, Cpad=None, stats=True):
     """x fp32 [M, ld>=C] -> (y [M, Cpad] (zeros beyond C), mean, rstd)"""
     L = lib()
     assert x.is_cuda and x.dtype == F32 and x.stride(1) == 1
@@ -45,7 +45,7 @@ def ln_bwd(dy, x, C, mean, rstd, gamma, dgamma, dbeta, dres=None, Cpad=None):
     M = x.shape[0]
     Cpad = C if Cpad is None else Cpad
     dx = torch.empty((M, Cpad), device=x.device, dtype=F32)
-    assert dy.dtype in (F32, BF16) and dy.stride(1) == 1 and dgamma.dtype == F32 and dgamma.is_contiguous()
+    assert dy.dtype in (F32, OP16) and dy.stride(1) == 1 and dgamma.dtype == F32 and dgamma.is_contiguous()
     from .ops import workspace
     ws = workspace(L.call("pvrl_layernorm_g_bwd_workspace_bytes", M, C), x.device, "mvit_ln_g")
     L.call("pvrl_layernorm_g_bwd", _ptr(dy), dy.stride(0), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean),
@@ -63,7 +63,7 @@ def pool_fwd(qkv, col0, B, H, thw, stride, w, gamma, beta, eps):
     L = lib()
     To, Ho, Wo = pool_out_thw(thw, stride)
     n = B * H * (To * Ho * Wo + 1)
-    y = torch.empty((B * H, To * Ho * Wo + 1, HD), device=qkv.device, dtype=BF16)
+    y = torch.empty((B * H, To * Ho * Wo + 1, HD), device=qkv.device, dtype=OP16)
     c = torch.empty_like(y)
     L.call("pvrl_mvit_pool_fwd", _ptr(qkv), qkv.stride(0), col0, B, H, *thw, *stride, _ptr(w), _ptr(gamma), _ptr(beta),
            float(eps), _ptr(y), _ptr(c), _stream())
@@ -73,7 +73,7 @@ def pool_fwd(qkv, col0, B, H, thw, stride, w, gamma, beta, eps):
 def pool_bwd(dy, conv_out, qkv, dqkv, col0, B, H, thw, stride, w, gamma, eps, dw, dgamma, dbeta):
     L = lib()
     scratch = torch.empty_like(conv_out)
-    assert dy.dtype == BF16 and dy.is_contiguous() and dw.is_contiguous() and dw.dtype == F32
+    assert dy.dtype == OP16 and dy.is_contiguous() and dw.is_contiguous() and dw.dtype == F32
     from .ops import workspace
     ws = workspace(L.call("pvrl_mvit_pool_bwd_workspace_bytes"), dy.device, "mvit_pool_bwd")
     L.call("pvrl_mvit_pool_bwd", _ptr(dy), _ptr(conv_out), _ptr(qkv), _ptr(dqkv), qkv.stride(0), col0, B, H, *thw,
@@ -126,8 +126,8 @@ def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt
 def attn_fwd(q, k, v, rel, B, H, Lq, k_thw, scale, ldo):
     """-> (o bf16 [B*Lq + B, ldo] token-major (zeros beyond H*96), lse fp32 [B*H, Lq+1])"""
     L = lib()
-    o = torch.zeros((B * Lq + B, ldo), device=q.device, dtype=BF16) if ldo > H * HD else \
-        torch.empty((B * Lq + B, ldo), device=q.device, dtype=BF16)
+    o = torch.zeros((B * Lq + B, ldo), device=q.device, dtype=OP16) if ldo > H * HD else \
+        torch.empty((B * Lq + B, ldo), device=q.device, dtype=OP16)
     lse = torch.empty((B * H, Lq + 1), device=q.device, dtype=F32)
     L.call("pvrl_mvit_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), ldo,
            _ptr(lse), _stream())
@@ -137,7 +137,7 @@ def attn_fwd(q, k, v, rel, B, H, Lq, k_thw, scale, ldo):
 def attn_bwd(q, k, v, rel, B, H, Lq, k_thw, scale, o, d_o, lse):
     """-> (dq, dk, dv bf16 like q / k / v, drel fp32 like rel)"""
     L = lib()
-    assert d_o.dtype == BF16 and d_o.stride(0) == o.stride(0)
+    assert d_o.dtype == OP16 and d_o.stride(0) == o.stride(0)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     drel = torch.empty_like(rel)
     delta = torch.empty_like(lse)

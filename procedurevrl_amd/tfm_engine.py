@@ -17,7 +17,7 @@ import torch
 from . import ops
 from ._lib import lib
 
-BF16 = torch.bfloat16
+OP16 = ops.OP16
 F32 = torch.float32
 LN_EPS = 1e-5
 

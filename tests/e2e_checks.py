@@ -2,23 +2,31 @@
  (a) the golden vectors produced by the unmodified reference (tests/golden/*.pt) and
  (b) the CPU oracle (oracle/timesformer_oracle.py) on freshly seeded inputs.
 
-Tolerances.  The reference is fp32; the HIP path rounds GEMM operands / inter-GEMM activations to bf16
-(2^-9 relative per rounding, fp32 accumulation, fp32 residual stream, fp32 head / logits / loss).  Measured
-relative-L2 errors are 2-4e-3 per tensor; the checks allow 1e-2 on activations / logits, 2e-2 on
-gradients (two chained bf16 passes) and 2e-3 on scalar losses.  Logits are unit-norm dot products x 1/0.02, so
-a 1e-3 relative *embedding* error maps to ~1e-3 relative-L2 on logits; the north-star's 1e-3 fp32 figure is met
-by the oracle itself (tests/test_oracle_golden.py), not by a bf16 datapath.
+Tolerances: see TOL_* below (per library flavour, ~1.5x the observed maxima).
 """
 import os
 
 import torch
 
 from oracle import timesformer_oracle as orc
+from oracle import rounded_oracle as rorc
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL_ACT = 1e-2
-TOL_GRAD = 2e-2
-TOL_LOSS = 2e-3
+from procedurevrl_amd._lib import OPERAND
+
+# Tolerances per library flavour (relative L2 unless stated), set to ~1.5x the largest value observed on MI355X so that a
+# regression that doubles an error fails.  north star: step logits and loss values within 1e-3 -- that is the fp16-operand
+# flavour's bar (PVRL_OPERAND=f16, tests/test_f16_flavour_gpu.py); the bf16 flavour's error is operand rounding (8x larger
+# unit roundoff), demonstrated by the oracle with the datapath's rounding points (oracle/rounded_oracle.py).
+if OPERAND == "bf16":
+    TOL_ACT, TOL_GRAD, TOL_LOSS = 9e-3, 1.5e-2, 2.5e-3
+    OPERAND_DTYPE = torch.bfloat16
+else:
+    TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-3, 2.5e-3, 1e-3
+    OPERAND_DTYPE = torch.float16
+TOL_GSUM = 2 * TOL_GRAD      # worst relative error of a parameter's sum |grad| over ALL parameters
+TOL_RATIO = 1.3              # HIP logits error / error of the oracle with the datapath's rounding points (observed 0.93-1.08)
+TOL_RATIO_GRAD = 1.6         # ... worst parameter gradient (observed 1.0-1.42: the model's backward sites are approximate)
 DEV = "cuda:0"
 
 
@@ -107,7 +115,7 @@ def check_block_golden():
     for k, s in f["grad_sums"].items():
         got = float(named[k].grad.double().abs().sum())
         worst = max(worst, abs(got - s) / max(s, 1e-9))
-    out.append(("block grad |sum| over all 20 params (worst rel)", worst, 3e-2))
+    out.append(("block grad |sum| over all 20 params (worst rel)", worst, TOL_GSUM))
     return out
 
 
@@ -137,14 +145,14 @@ def check_e2e_golden():
            ("e2e mse target vs reference", rel(mse[0], f["mse0"]), TOL_ACT),
            ("e2e mse pred vs reference", rel(mse[1], f["mse1"]), TOL_ACT)]
     loss, l1, l2 = pretrain_loss(pred, teacher, mse, cfg)
-    out.append(("e2e loss1 (KL)", abs(float(l1) - f["loss1"]) / abs(f["loss1"]), 2e-2))
-    out.append(("e2e loss2 (MSE)", abs(float(l2) - f["loss2"]) / abs(f["loss2"]), 2e-2))
+    out.append(("e2e loss1 (KL)", abs(float(l1) - f["loss1"]) / abs(f["loss1"]), TOL_LOSS))
+    out.append(("e2e loss2 (MSE)", abs(float(l2) - f["loss2"]) / abs(f["loss2"]), TOL_LOSS))
     for p in model.parameters():
         p.grad = None
     loss.backward()
     named = dict(model.named_parameters())
     for k, g in f["grads"].items():
-        out.append((f"e2e grad {k[6:]}", rel(named[k].grad, g), 4e-2))
+        out.append((f"e2e grad {k[6:]}", rel(named[k].grad, g), TOL_GRAD))
     worst, wk = 0.0, ""
     for k, s in f["grad_sums"].items():
         if named[k].grad is None:
@@ -154,7 +162,7 @@ def check_e2e_golden():
         e = abs(got - s) / max(s, 1e-9)
         if e > worst:
             worst, wk = e, k
-    out.append((f"e2e grad |sum| all params (worst: {wk[6:]})", worst, 6e-2))
+    out.append((f"e2e grad |sum| all params (worst: {wk[6:]})", worst, TOL_GSUM))
     # eval-mode encoder features on 2 clips
     ff = load("features")
     model.eval()
@@ -164,16 +172,21 @@ def check_e2e_golden():
     return out
 
 
-def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None):
+def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=None):
+    """`rounded` = torch.bfloat16 / torch.float16: the oracle with the HIP datapath's rounding points (oracle/rounded_oracle.py)"""
     params = {k: v.clone().requires_grad_(True) for k, v in sd_cpu.items()}
-    feat = orc.forward_features(params, frames, depth, droppath=droppath)
+    if rounded is None:
+        feat = orc.forward_features(params, frames, depth, droppath=droppath)
+    else:
+        with rorc.operand(rounded):
+            feat = rorc.forward_features(params, frames, depth, droppath=droppath)
     emb, logits = orc.head_logits(params, feat, label, 0.02)
     loss, _, _ = orc.pretrain_loss(logits, teacher, None, 5)
     loss.backward()
     return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
 
 
-def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag=""):
+def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -204,16 +217,30 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag=""):
     loss = kl_topk_loss(pred, teacher.to(DEV), 5)
     loss.backward()
     out = [(f"{tag}logits vs oracle", rel(pred, logits_ref), TOL_ACT),
-           (f"{tag}loss vs oracle", abs(float(loss) - loss_ref) / abs(loss_ref), 2e-2)]
+           (f"{tag}loss vs oracle", abs(float(loss) - loss_ref) / abs(loss_ref), TOL_LOSS)]
     named = dict(vt.named_parameters())
     worst, wk = 0.0, ""
     for k, gref in grads_ref.items():
         e = rel(named[k].grad, gref)
         if e > worst:
             worst, wk = e, k
-    out.append((f"{tag}all parameter gradients vs oracle (worst: {wk})", worst, 5e-2))
+    out.append((f"{tag}all parameter gradients vs oracle (worst: {wk})", worst, TOL_GRAD))
     for k in ("patch_embed.proj.weight", "pos_embed", "time_embed", "cls_token", "head.weight", "blocks.0.mlp.fc2.weight"):
-        out.append((f"{tag}grad {k}", rel(named[k].grad, grads_ref[k]), 4e-2))
+        out.append((f"{tag}grad {k}", rel(named[k].grad, grads_ref[k]), TOL_GRAD))
+    if rounding_model:
+        # The same step through the oracle WITH the HIP datapath's rounding points (oracle/rounded_oracle.py).  Rounding is a
+        # chaotic map, so after a few serial roundings two implementations of the same datapath decorrelate element by
+        # element: what must agree is the SIZE of the error -- if a kernel added anything beyond operand rounding, the HIP
+        # path's distance from the fp32 oracle would exceed the rounding model's.
+        lg_r, loss_r, grads_r = _oracle_step(sd, x, label, teacher, depth, dp_ref, rounded=OPERAND_DTYPE)
+        e_model = rel(lg_r, logits_ref)
+        out.append((f"{tag}logits error / rounding-model error ({rel(pred, logits_ref):.2e} / {e_model:.2e})",
+                    rel(pred, logits_ref) / e_model, TOL_RATIO))
+        out.append((f"{tag}logits: HIP closer to the rounding model than to the fp32 oracle",
+                    rel(pred, lg_r) / rel(pred, logits_ref), 1.0))
+        wm = max(rel(grads_r[k], grads_ref[k]) for k in grads_ref)
+        wh = max(rel(named[k].grad, grads_ref[k]) for k in grads_ref)
+        out.append((f"{tag}worst gradient error / rounding-model's ({wh:.2e} / {wm:.2e})", wh / wm, TOL_RATIO_GRAD))
     return out
 
 
@@ -270,7 +297,7 @@ def check_forecast_eval_golden():
     model.to(DEV).eval()
     with torch.no_grad():
         probs = model(f["x"].to(DEV))
-    return [("forecast eval probabilities vs reference", rel(probs, f["probs"]), 3e-2),
+    return [("forecast eval probabilities vs reference", rel(probs, f["probs"]), 3 * TOL_ACT),
             ("forecast eval argmax agreement (fraction differing)", float((probs.argmax(1).cpu() != f["probs"].argmax(1)).float().mean()), 0.0)]
 
 
@@ -328,9 +355,9 @@ def check_decoded_clips_train_step():
     # the two patch matrices differ in 0.014 % of their bf16 values by one ulp (kernel_checks.check_input_pipeline);
     # a random-init network at temperature 0.02 turns that into 2-4e-3 on logits / gradients (observed), the same
     # sensitivity the bf16 datapath shows everywhere else -> same 1e-2 tolerance as the other end-to-end checks
-    return [("decoded-clips logits vs fp32-pipeline logits", rel(res[1][0], res[0][0]), 1e-2),
-            ("decoded-clips d patch_embed.weight", rel(res[1][1], res[0][1]), 1e-2),
-            ("decoded-clips d blocks.0.attn.qkv.weight", rel(res[1][2], res[0][2]), 1e-2)]
+    return [("decoded-clips logits vs fp32-pipeline logits", rel(res[1][0], res[0][0]), TOL_ACT),
+            ("decoded-clips d patch_embed.weight", rel(res[1][1], res[0][1]), TOL_GRAD),
+            ("decoded-clips d blocks.0.attn.qkv.weight", rel(res[1][2], res[0][2]), TOL_GRAD)]
 
 
 def check_step_is_bit_reproducible():

@@ -10,8 +10,12 @@ import math
 import torch
 import torch.nn.functional as F
 
-BF = torch.bfloat16
-TOL_BF16 = 1e-2
+from procedurevrl_amd._lib import OPERAND
+
+BF = torch.bfloat16 if OPERAND == "bf16" else torch.float16     # the library flavour's 16-bit operand type
+# a kernel that rounds its output to the operand type sits at ~1.7e-3 (bf16) / 2.1e-4 (fp16) against fp32 math on the
+# rounded inputs; backward kernels chain two or three such roundings
+TOL_BF16 = 1e-2 if OPERAND == "bf16" else 1.5e-3
 TOL_F32 = 2e-5
 
 
@@ -104,33 +108,6 @@ def check_gemm_nt():
     return out
 
 
-def check_gemm_nt_tiles():
-    """every NT tile / pipeline variant behind the benchmark knob against the same reference (K = 768, 192 and 64:
-    pipeline prologue / tail paths), three epilogue families"""
-    from procedurevrl_amd import ops
-    from procedurevrl_amd._lib import lib
-    L = lib()
-    g = torch.Generator().manual_seed(41)
-    out = []
-    try:
-        for (M, N, K) in [(700, 512, 768), (300, 256, 192), (260, 256, 64)]:
-            A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05
-            bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
-            ref = bf(A) @ bf(W).t()
-            Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
-            for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
-                L.call("pvrl_debug_set_gemm_tile", knob)
-                o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_BF16, bias=bias.to(dev()))
-                out.append((f"gemm_nt tile{knob} bf16 {M}x{N}x{K}", rel(o, ref + bias), TOL_BF16))
-                o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bias.to(dev()), aux=resid.to(dev()))
-                out.append((f"gemm_nt tile{knob} resid {M}x{N}x{K}", rel(o, resid + ref + bias), 1e-4))
-                u, gl = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_GELU, bias=bias.to(dev()))
-                out.append((f"gemm_nt tile{knob} gelu {M}x{N}x{K}", rel(gl, F.gelu(ref + bias)), TOL_BF16))
-    finally:
-        L.call("pvrl_debug_set_gemm_tile", 0)
-    return out
-
-
 def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -160,39 +137,6 @@ def check_gemm_tn():
         out.append((f"gemm_tn dbias {M}x{N}x{K}", rel(db, bf(P).sum(0)), 1e-4))
         ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, beta=1.0, splits=splits)
         out.append((f"gemm_tn accumulate {M}x{N}x{K}", rel(dW, 2 * ref), 1e-4))
-    return out
-
-
-def check_gemm_tn_variants():
-    """the alternative weight-gradient kernels behind the benchmark knob (LDS-DMA staging, 256x256 tile)"""
-    from procedurevrl_amd import ops
-    from procedurevrl_amd._lib import lib
-    L = lib()
-    g = torch.Generator().manual_seed(31)
-    out = []
-    M, N, K = 1111, 512, 256
-    P = torch.randn(M, N, generator=g); Q = torch.randn(M, K, generator=g)
-    ref = bf(P).t() @ bf(Q)
-    try:
-        for knob, name in ((2, "lds-dma"), (3, "256x256"), (4, "256x256 w128")):
-            L.call("pvrl_debug_set_gemm_tn_tile", knob)
-            dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
-            ops.gemm_tn(P.to(dev(), BF), Q.to(dev(), BF), dW, db, splits=16)
-            out.append((f"gemm_tn[{name}] dW", rel(dW, ref), 1e-4))
-            out.append((f"gemm_tn[{name}] dbias", rel(db, bf(P).sum(0)), 1e-4))
-        # the 4-wave 256x256 kernels need M % 64 == 0; slices of 2, 4, ... stages and empty slices
-        for knob, name in ((5, "ring"), (6, "rt"), (7, "rt32"), (8, "rt8")):
-            L.call("pvrl_debug_set_gemm_tn_tile", knob)
-            for (M2, N2, K2, sp) in [(1152, 512, 256, 8), (4160, 256, 768, 16), (128, 256, 256, 8), (6400, 768, 768, 32),
-                                     (3200, 768, 256, 9 if knob >= 6 else 8)] + ([(1111, 512, 256, 5), (1569, 256, 256, 3), (40, 256, 512, 4)] if knob >= 6 else []):
-                P2 = torch.randn(M2, N2, generator=g); Q2 = torch.randn(M2, K2, generator=g)
-                ref2 = bf(P2).t() @ bf(Q2)
-                dW = torch.zeros(N2, K2, device=dev()); db = torch.zeros(N2, device=dev())
-                ops.gemm_tn(P2.to(dev(), BF), Q2.to(dev(), BF), dW, db, splits=sp)
-                out.append((f"gemm_tn[{name}] dW {M2}x{N2}x{K2} s={sp}", rel(dW, ref2), 1e-4))
-                out.append((f"gemm_tn[{name}] dbias {M2}x{N2}x{K2}", rel(db, bf(P2).sum(0)), 1e-4))
-    finally:
-        L.call("pvrl_debug_set_gemm_tn_tile", 0)
     return out
 
 
@@ -574,5 +518,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_tiles, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_variants, check_gemm_tn_grouped, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_grouped, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]

@@ -8,7 +8,8 @@ import torch.nn.functional as F
 
 from oracle import mvit_oracle as mo
 
-BF = torch.bfloat16
+from procedurevrl_amd._lib import OPERAND
+BF = torch.bfloat16 if OPERAND == "bf16" else torch.float16
 DEV = "cuda:0"
 
 

@@ -40,7 +40,8 @@ def test_nccl_world1_training_step_matches_no_dist_step():
         reducer.finish()
         vt.adopt_grads()
         stats = du.all_reduce_scalars([loss.detach()]) if with_dist else torch.stack([loss.detach()])
-        return float(stats[0]), vt.grad_store().flat.clone()
+        gs = vt.grad_store()
+        return float(stats[0]), gs.flat[:gs.end].clone()      # (the tail past `end` holds the reducer's used-parameter flags)
 
     l0, g0 = run(False)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

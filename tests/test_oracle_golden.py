@@ -305,3 +305,44 @@ def test_mvit_oracle_droppath():
     for n, ref in g["grads"].items():
         got = p[n].grad[:64] if p[n].grad.dim() == 2 else p[n].grad
         assert (got - ref).norm() < 2e-4 * ref.norm() + 1e-6 * ref.numel() ** 0.5, n
+
+
+def test_rounded_oracle_without_rounding_is_the_oracle():
+    """oracle/rounded_oracle.py (the oracle + the HIP datapath's rounding points) with rounding switched off must BE the
+    fp32 oracle -- forward and backward, DropPath included -- which pins it to the reference through the goldens above; and
+    against the reference's own block it must sit where a 16-bit operand datapath sits (a few 1e-3), not elsewhere."""
+    from oracle import rounded_oracle as rorc
+    f = load("block")
+    outs = {}
+    for name, blockfn, dtype in (("orc", orc.block, None), ("off", rorc.block, None), ("bf16", rorc.block, torch.bfloat16),
+                                 ("f16", rorc.block, torch.float16)):
+        sd = {k: v.requires_grad_(True) for k, v in block_state(f["seed"]).items()}
+        x = f["x"].clone().requires_grad_(True)
+        B, T = f["B"], f["T"]
+        N = (x.shape[1] - 1) // T
+        g = torch.Generator().manual_seed(0)
+        dp = tuple(torch.floor(0.7 + torch.rand(n, generator=g)) / 0.7 for n in (B * N, B * T, B))
+        with rorc.operand(dtype):
+            y = blockfn(sd, "", x, B, T, f["W"], dp=dp)
+        y.backward(f["dy"])
+        outs[name] = (y.detach(), x.grad, {k: v.grad for k, v in sd.items()})
+    y0, dx0, g0 = outs["orc"]
+    y1, dx1, g1 = outs["off"]
+    assert rel(y1, y0) < 1e-6 and rel(dx1, dx0) < 1e-6
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 1e-5, k
+    e_bf, e_f16 = rel(outs["bf16"][0], y0), rel(outs["f16"][0], y0)
+    assert 2e-4 < e_bf < 1e-2, e_bf                 # bf16 operands: 2^-9 per rounding
+    assert e_f16 < e_bf / 4, (e_f16, e_bf)          # fp16 operands: three more mantissa bits
+
+
+def test_rounded_oracle_features_match_oracle_when_off():
+    from oracle import rounded_oracle as rorc
+    f = load("features")
+    e = load("e2e")
+    full = orc.seeded_state(e2e_state(e), f["seed"])
+    sd = {k[len("model."):]: v for k, v in full.items()}
+    with torch.no_grad():
+        a = orc.forward_features(sd, f["x"], e["depth"])
+        b = rorc.forward_features(sd, f["x"], e["depth"])
+    assert rel(b, a) < 1e-6

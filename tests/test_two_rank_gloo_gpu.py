@@ -38,7 +38,8 @@ def _worker(rank, world, port, out_dir):
         kl_topk_loss(model(x), teacher, 5).backward()
         if reducer is not None:
             reducer.finish()
-        return vt.adopt_grads().flat.clone()
+        gs = vt.adopt_grads()
+        return gs.flat[:gs.end].clone()
 
     own = step(None)                                                         # this rank's gradients, no communication
     reducer = du.GradReducer(vt)

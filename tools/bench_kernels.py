@@ -8,6 +8,8 @@ import torch  # noqa: E402
 
 from procedurevrl_amd import ops  # noqa: E402
 from procedurevrl_amd._lib import lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe"))
+import probe_lib as pl  # noqa: E402   (measured-and-rejected variants: tools/probe/libpvrl_probe.so)
 
 DEV = "cuda:0"
 BF = torch.bfloat16
@@ -37,6 +39,8 @@ def main():
     rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
     rows = []
 
+    sel = {"tile": 0, "gm": 0}     # 0 = the product library; otherwise the probe library's explicit selectors
+
     def gemm_case(name, M_, N_, K_, epi, **kw):
         if not want(name):
             return
@@ -47,11 +51,14 @@ def main():
             args["aux"] = rnd(M_, N_)
         if epi in (L.PVRL_EPI_DGELU,):
             args["aux"] = rnd(M_, N_).to(BF); args.pop("bias")
-        us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
+        if sel["tile"] or sel["gm"]:
+            us = timeit(lambda: pl.gemm_nt(sel["tile"], A, W, epi, gm=sel["gm"], **args))
+        else:
+            us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
     for tile in (1, 2, 3):
-        L.call("pvrl_debug_set_gemm_tile", tile)
+        sel["tile"] = tile
         tg = {1: "128x128", 2: "256x128", 3: "256x256"}[tile]
         gemm_case(f"nt[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
         gemm_case(f"nt[{tg}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
@@ -63,7 +70,7 @@ def main():
         gemm_case(f"nt[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
     for rep in range(2):
         for tile, tg in ((3, "256 16 waves"), (13, "4 waves, register-staged, 32x32x16")):
-            L.call("pvrl_debug_set_gemm_tile", tile)
+            sel["tile"] = tile
             gemm_case(f"ab[{tg}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
             gemm_case(f"ab[{tg}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
@@ -72,15 +79,15 @@ def main():
             gemm_case(f"ab[{tg}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] dqkv  bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
             gemm_case(f"ab[{tg}] dfc2  dgelu M x3072x768", M, 3072, 768, L.PVRL_EPI_DGELU)
-    L.call("pvrl_debug_set_gemm_tile", 0)
+    sel["tile"] = 0
     for rep in range(2):
         for gm in (1, 2, 3, 4):
-            L.call("pvrl_debug_set_gemm_gm", gm)
+            sel["gm"] = gm
             gemm_case(f"gm[{gm}] qkv   bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
             gemm_case(f"gm[{gm}] dfc1  bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
             gemm_case(f"gm[{gm}] fc1   gelu  M x3072x768", M, 3072, 768, L.PVRL_EPI_GELU)
             gemm_case(f"gm[{gm}] proj  bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
-    L.call("pvrl_debug_set_gemm_gm", 2)
+    sel["gm"] = 0
     gemm_case("nt-auto qkv      bf16  M x2304x768", M, 2304, 768, L.PVRL_EPI_BF16)
     gemm_case("nt proj     bf16  M x768x768", R, 768, 768, L.PVRL_EPI_BF16)
     gemm_case("nt fc/projs resid M x768x768", R, 768, 768, L.PVRL_EPI_RESID_F32)
@@ -90,25 +97,32 @@ def main():
     gemm_case("nt dfc1     bf16  M x768x3072", M, 768, 3072, L.PVRL_EPI_BF16)
     gemm_case("nt dqkv     bf16  M x768x2304", M, 768, 2304, L.PVRL_EPI_BF16)
 
+    tn_sel = {"tile": 0}
+
     def tn_case(name, M_, N_, K_, splits=None):
         if not want(name):
             return
         P = rnd(M_, N_).to(BF); Q = rnd(M_, K_).to(BF)
         dW = torch.zeros(N_, K_, device=DEV); db = torch.zeros(N_, device=DEV)
-        if splits is None:
-            splits = ops.tn_splits(M_, N_, K_)
-        us = timeit(lambda: ops.gemm_tn(P, Q, dW, db, splits=splits))
+        if tn_sel["tile"]:
+            if splits is None:
+                splits = pl.tn_splits(tn_sel["tile"], M_, N_, K_)
+            us = timeit(lambda: pl.gemm_tn(tn_sel["tile"], P, Q, dW, db, splits=splits))
+        else:
+            if splits is None:
+                splits = ops.tn_splits(M_, N_, K_)
+            us = timeit(lambda: ops.gemm_tn(P, Q, dW, db, splits=splits))
         name = name + f" s={splits}"
         rows.append((name, us, 2.0 * M_ * N_ * K_ / us / 1e6))
 
     for tile in (7, 8, 7, 8):
-        L.call("pvrl_debug_set_gemm_tn_tile", tile)
+        tn_sel["tile"] = tile
         tg = {1: "128x128 tr-read", 0: "default", 6: "rt 16x16x32", 7: "rt 32x32x16", 8: "rt 8 waves"}[tile]
         tn_case(f"tn[{tg}] wqkv  2304x768", M, 2304, 768)
         tn_case(f"tn[{tg}] wproj 768x768", R, 768, 768)
         tn_case(f"tn[{tg}] wfc1  3072x768", M, 3072, 768)
         tn_case(f"tn[{tg}] wfc2  768x3072", M, 768, 3072)
-    L.call("pvrl_debug_set_gemm_tn_tile", 0)
+    tn_sel["tile"] = 0
 
     if want("f32"):
         a = rnd(32, 512); lab = rnd(9871, 512); labt = lab.t().contiguous(); dyl = rnd(32, 9871)
