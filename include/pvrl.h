@@ -37,7 +37,8 @@ extern "C" {
 
 /* The 16-bit operand type this library was built with: 0 = bf16 (libpvrl_hip.so), 1 = fp16 (libpvrl_hip_f16.so, built
  * with -DPVRL_OPERAND_F16).  Wherever an entry point below says "bf16" (names, PVRL_EPI_BF16, comments) read "the
- * library's 16-bit operand type": same layouts, same MFMA rate; fp16 gradients need the caller's loss scaling. */
+ * library's 16-bit operand type": same layouts, same MFMA rate; with fp16 the caller scales the gradients it feeds the backward entry points
+ * (5 exponent bits; procedurevrl_amd/engine.py GradStore.begin_scaled does this per engine). */
 int pvrl_operand_dtype(void);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.

@@ -9,7 +9,7 @@
 //   default            bf16   (libpvrl_hip.so)      8 exponent bits: gradients need no scaling
 //   -DPVRL_OPERAND_F16 fp16   (libpvrl_hip_f16.so)  3 more mantissa bits at the same MFMA rate (v_mfma_f32_*_f16 = *_bf16
 //                              on gfx950): 8x smaller rounding error -- the flavour that meets the 1e-3 parity bar; its
-//                              gradients need the host-side loss scaling of procedurevrl_amd/amp.py (5 exponent bits)
+//                              gradients are scaled inside each engine's backward (engine.GradStore.begin_scaled; 5 exponent bits)
 // `pvrl_operand_dtype()` reports which one a library was built with.
 #if defined(PVRL_OPERAND_F16)
 typedef _Float16 op_t;

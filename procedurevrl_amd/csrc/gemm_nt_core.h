@@ -37,6 +37,7 @@ struct GemmNT {
   int tiles_m, tiles_n, nwg;
   int m_off;   // global row of local row 0 (a launch may cover a row range of the logical GEMM)
   int gm;      // rasterisation group height in tiles
+  int skew_n, skew_len;   // start-up phase skew of the first round of workgroups (see gemm_nt_kernel); 0 = none
 };
 
 constexpr int BK = 64;
@@ -179,6 +180,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     tm = mbase + g * GM + (r - tn * gm);
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  // Phase skew.  All workgroups of a round start together, run the same K loop and reach their HBM-bound epilogue together:
+  // the memory system sees a burst while every MFMA pipe idles, then nothing while they all compute.  Delaying the first
+  // round's workgroups by (index mod skew_n) * skew_len * ~2 us spreads the phases, so some CUs stream their epilogue while
+  // others multiply (later rounds inherit the phase of the workgroup they replace).
+  if (p.skew_n > 1 && blockIdx.x < 256) {
+    const int ph = (int)(blockIdx.x >> 3) % p.skew_n;
+    for (int d = 0; d < ph * p.skew_len; ++d) __builtin_amdgcn_s_sleep(64);
+  }
 
   // ---- staging: instruction `it` of a stage copies 8 tile rows (X rows first, then W rows) ----
   const op_t* gsrc[PER];

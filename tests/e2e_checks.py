@@ -19,10 +19,10 @@ from procedurevrl_amd._lib import OPERAND
 # flavour's bar (PVRL_OPERAND=f16, tests/test_f16_flavour_gpu.py); the bf16 flavour's error is operand rounding (8x larger
 # unit roundoff), demonstrated by the oracle with the datapath's rounding points (oracle/rounded_oracle.py).
 if OPERAND == "bf16":
-    TOL_ACT, TOL_GRAD, TOL_LOSS = 9e-3, 1.5e-2, 2.5e-3
+    TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-2, 2e-2, 2.5e-3       # observed maxima (32-clip timed config): 6.4e-3, 1.26e-2, 1.45e-3
     OPERAND_DTYPE = torch.bfloat16
 else:
-    TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-3, 2.5e-3, 1e-3
+    TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-3, 2.5e-3, 1e-3       # observed maxima: 7.9e-4, 1.34e-3, 2.7e-4
     OPERAND_DTYPE = torch.float16
 TOL_GSUM = 2 * TOL_GRAD      # worst relative error of a parameter's sum |grad| over ALL parameters
 TOL_RATIO = 1.3              # HIP logits error / error of the oracle with the datapath's rounding points (observed 0.93-1.08)
@@ -172,6 +172,24 @@ def check_e2e_golden():
     return out
 
 
+def _oracle_step_micro(sd_cpu, frames, label, teacher, depth, micro):
+    """the oracle's step on a batch too large for one autograd graph in host memory (32 clips of 8x224^2 through 12 blocks
+    keep ~70 GB of fp32 activations): micro-batches of `micro` clips, gradients accumulated.  KLDivLoss(batchmean) over
+    the whole batch = sum over micro-batches of (rows_mb / rows) x their batchmean loss, so the result is the same step."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd_cpu.items()}
+    B = frames.shape[0]
+    logits_all, loss_all = [], 0.0
+    for a in range(0, B, micro):
+        xb, tb = frames[a:a + micro], teacher[a:a + micro]
+        feat = orc.forward_features(params, xb, depth)
+        _, logits = orc.head_logits(params, feat, label, 0.02)
+        loss, _, _ = orc.pretrain_loss(logits, tb, None, 5)
+        (loss * (xb.shape[0] / B)).backward()
+        logits_all.append(logits.detach())
+        loss_all += float(loss) * xb.shape[0] / B
+    return torch.cat(logits_all), loss_all, {k: p.grad for k, p in params.items()}
+
+
 def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=None):
     """`rounded` = torch.bfloat16 / torch.float16: the oracle with the HIP datapath's rounding points (oracle/rounded_oracle.py)"""
     params = {k: v.clone().requires_grad_(True) for k, v in sd_cpu.items()}
@@ -186,7 +204,7 @@ def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=N
     return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
 
 
-def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True):
+def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -210,7 +228,14 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
             s = [torch.floor(keep + torch.rand(n, generator=g)) / keep if keep < 1 else torch.ones(n) for n in (B * N, B * frames, B)]
             dp_ref.append(tuple(s))
             dp_hip.append(EncoderEngine.expand_droppath(s[0].to(DEV), s[1].to(DEV), s[2].to(DEV), B, N, frames))
-    logits_ref, loss_ref, grads_ref = _oracle_step(sd, x, label, teacher, depth, dp_ref)
+    if micro:
+        try:
+            torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+        except Exception:
+            pass
+        logits_ref, loss_ref, grads_ref = _oracle_step_micro(sd, x, label, teacher, depth, micro)
+    else:
+        logits_ref, loss_ref, grads_ref = _oracle_step(sd, x, label, teacher, depth, dp_ref)
     for p in model.parameters():
         p.grad = None
     pred = model(x.to(DEV), rng=dict(droppath=dp_hip) if dp_hip else None)
@@ -262,6 +287,55 @@ def check_train_step_t4():
 def check_train_step_t32():
     """T = 32 frames (BASELINE config 4 shape in time): temporal attention over 32-token sequences on the MFMA path."""
     return _hip_vs_oracle(1, 32, 64, 1, frames=32, seed=9, tag="T=32: ")
+
+
+def check_train_step_t32_full_res():
+    """BASELINE config 4's real token count: T = 32 frames at 224^2 (6,273 tokens per clip, temporal sequences of 32 on the
+    MFMA attention path, 1,024 spatial sequences per 4 clips), two blocks, one clip, vs the oracle."""
+    return _hip_vs_oracle(2, 224, 512, 1, frames=32, seed=13, tag="T=32 224^2: ", rounding_model=False)
+
+
+def check_timed_config_train_step():
+    """The benchmark's OWN configuration -- 32 clips of 8x224^2, 12 blocks, K = 9871 (BASELINE configs[1]) -- one training
+    step (forward, step logits, top-5 KL loss, backward) against the oracle run in micro-batches on the host cores:
+    every kernel launch of the timed step at its timed shape (M = 50,208 rows, grouped weight gradients, 256x256 tiles)."""
+    return _hip_vs_oracle(12, 224, 9871, 32, seed=17, tag="32 clips (timed config): ", rounding_model=False, micro=4)
+
+
+def check_text_tower_full_size():
+    """Row T1 at real size: the frozen CLIP-text teacher as the reference instantiates it (ViT-B/16 text half: 12 layers,
+    width 512, 8 heads, context 77, vocabulary 49,408, causal mask; lib/models/vit.py:258-261,425-433) on 36 narrations
+    vs the oracle's `clip_encode_text` / `pseudo_labels` (openai/CLIP's published algorithm; parity unpinned w.r.t. CLIP's
+    own weights, see the oracle header) -- text embeddings and teacher logits over K = 9871 steps."""
+    import test_oracle_golden as tg
+    from procedurevrl_amd.datasets import synthetic_text_ids
+    from procedurevrl_amd.tfm_model import ClipTextModel
+    g = torch.Generator().manual_seed(21)
+    K, n = 9871, 36
+    sd = orc.seeded_state(tg.orc_text_shapes(12), 5)
+    tower = ClipTextModel(layers=12).float()
+    tower.load_state_dict({k[len("text_model."):]: v for k, v in sd.items()}, strict=True)
+    cfg = make_cfg(1, 32, K, text=True, text_layers=12, order=True)
+    label = torch.randn(K, 512, generator=g) * 0.38
+    label = label / label.norm(dim=1, keepdim=True)
+    model = build(cfg, label.clone())
+    vt = model.model
+    vt.text_model.load_state_dict(tower.state_dict(), strict=True)
+    model.to(DEV)
+    ids = synthetic_text_ids(n, g)
+    vis = torch.randn(n, 512, generator=g) * 0.4
+    with torch.no_grad():
+        emb_ref = orc.clip_encode_text(sd, "text_model.", ids, 12)
+        teacher_ref = orc.pseudo_labels(sd, ids, vis, label, 0.02, 12)
+        out = []
+        for rep in range(4):         # eager, eager, captured, replayed: the HIP graph of the tower is part of the check
+            emb = vt.text_model.encode_text(ids.to(DEV))
+            teacher = vt.get_pseudo_labels(torch.device(DEV), {"clip_text_ids": ids.to(DEV), "clip_vis_feat": vis.to(DEV)})
+        out.append(("text tower 12 layers ctx 77: embeddings vs oracle", rel(emb, emb_ref), TOL_ACT))
+        out.append(("text tower: teacher logits K=9871 vs oracle", rel(teacher, teacher_ref), TOL_ACT))
+        out.append(("text tower: teacher top-5 sets differ (rows)",
+                    float((teacher.topk(5, 1)[1].sort(1)[0].cpu() != teacher_ref.topk(5, 1)[1].sort(1)[0]).any(1).float().sum()), 2.0))
+    return out
 
 
 def check_embed_resize_golden():
@@ -462,4 +536,5 @@ def check_hip_graph_replay():
 
 
 ALL_CHECKS = [check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
-              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size]
+              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
+              check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step]

@@ -178,6 +178,27 @@ def check_gemm_tn_grouped():
     return out
 
 
+def check_gemm_tn_grouped_block_size():
+    """the benchmark's dominant launch at ITS size: the seven weight gradients of one TimeSformer block at 32 clips
+    (M = 50,208 / 50,176 rows; the (N, K) of tests/test_cabi.py) in one grouped launch vs fp32 CPU matmuls."""
+    from procedurevrl_amd import ops
+    gg = torch.Generator().manual_seed(77)
+    R, M, BT = 50176, 50208, 256
+    shapes = [(M, 768, 3072, "fc2"), (M, 3072, 768, "fc1"), (R + BT, 768, 768, "attn.proj"), (M, 2304, 768, "attn.qkv"),
+              (R, 768, 768, "fused temporal map"), (R, 2304, 768, "temporal_attn.qkv"), (R, 768, 768, "patch_embed")]
+    probs, refs = [], []
+    for (m, N, K, _) in shapes:
+        P = (torch.randn(m, N, generator=gg) * 0.05).to(BF); Q = torch.randn(m, K, generator=gg).to(BF)
+        refs.append((P.float().t() @ Q.float(), P.float().sum(0)))
+        probs.append((P.to(dev()), Q.to(dev()), torch.empty(N, K, device=dev()), torch.empty(N, device=dev()), 0.0))
+    ops.gemm_tn_grouped(probs)
+    out = []
+    for (m, N, K, name), (_, _, dW, db, _), (rw, rb) in zip(shapes, probs, refs):
+        out.append((f"grouped dW {name} {m}x{N}x{K}", rel(dW, rw), 1e-4))
+        out.append((f"grouped dbias {name}", rel(db, rb), 1e-4))
+    return out
+
+
 def check_cast_weights_multi():
     """pvrl_cast_weights_multi_bf16: many fp32 weight matrices -> bf16 copy + transposed copy in one launch (ragged
     shapes, with and without the transposed copy, more than one launch worth of items)"""
@@ -518,5 +539,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_grouped, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]

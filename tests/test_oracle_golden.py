@@ -346,3 +346,43 @@ def test_rounded_oracle_features_match_oracle_when_off():
         a = orc.forward_features(sd, f["x"], e["depth"])
         b = rorc.forward_features(sd, f["x"], e["depth"])
     assert rel(b, a) < 1e-6
+
+
+def test_clip_text_oracle_matches_hf_clip_port():
+    """Row T1's arithmetic lives in third-party openai/CLIP (`clip.load("ViT-B/16")`, reference lib/models/vit.py:258),
+    which is absent here.  The `transformers` package in this image carries an independent, widely used port of that
+    text encoder (CLIPTextModelWithProjection, validated upstream against openai's weights): with the SAME random weights
+    mapped by name, at the real geometry (12 layers, width 512, 8 heads, context 77, vocabulary 49,408, quick_gelu,
+    causal mask, EOT pooling, text_projection), the oracle's `clip_encode_text` must reproduce its text embeddings."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    from procedurevrl_amd.datasets import synthetic_text_ids
+    layers = 12
+    sd = orc.seeded_state(orc_text_shapes(layers), 5)
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=512, intermediate_size=2048, projection_dim=512,
+                         num_hidden_layers=layers, num_attention_heads=8, max_position_embeddings=77, hidden_act="quick_gelu",
+                         layer_norm_eps=1e-5, attention_dropout=0.0, eos_token_id=49407, bos_token_id=49406, pad_token_id=0)
+    cfg._attn_implementation = "eager"
+    hf = CLIPTextModelWithProjection(cfg).eval()
+    m = {"text_model.embeddings.token_embedding.weight": sd["text_model.token_embedding.weight"],
+         "text_model.embeddings.position_embedding.weight": sd["text_model.positional_embedding"],
+         "text_model.final_layer_norm.weight": sd["text_model.ln_final.weight"],
+         "text_model.final_layer_norm.bias": sd["text_model.ln_final.bias"],
+         "text_projection.weight": sd["text_model.text_projection"].t().contiguous()}
+    for i in range(layers):
+        src, dst = f"text_model.transformer.resblocks.{i}.", f"text_model.encoder.layers.{i}."
+        w, b = sd[src + "attn.in_proj_weight"], sd[src + "attn.in_proj_bias"]
+        for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            m[dst + f"self_attn.{n}.weight"] = w[512 * j:512 * (j + 1)]
+            m[dst + f"self_attn.{n}.bias"] = b[512 * j:512 * (j + 1)]
+        for a, c in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                     ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            m[dst + c + ".weight"] = sd[src + a + ".weight"]
+            m[dst + c + ".bias"] = sd[src + a + ".bias"]
+    missing, unexpected = hf.load_state_dict(m, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    ids = synthetic_text_ids(6, torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = hf(input_ids=ids).text_embeds
+        got = orc.clip_encode_text(sd, "text_model.", ids, layers)
+    assert rel(got, want) < 2e-5, rel(got, want)

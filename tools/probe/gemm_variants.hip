@@ -12,6 +12,8 @@
 //            staging, 3 = 256x256 / 16 waves, 4 = 256x256 / 8 waves, 5 = LDS-DMA ring, 6 / 7 = register-transposed 4 waves
 //            with 16x16x32 / 32x32x16 MFMAs.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include "../../procedurevrl_amd/csrc/gemm_nt_core.h"
 #include "../../procedurevrl_amd/csrc/gemm_tn_core.h"
 
@@ -1173,6 +1175,8 @@ extern "C" int pvrl_probe_gemm_nt_bf16(int tile, int gm, const void* A, int64_t 
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
   p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = gm < 1 ? NT_GM : gm;
+  p.skew_n = 0; p.skew_len = 0;
+  if (const char* e = getenv("PVRL_PROBE_SKEW")) sscanf(e, "%d,%d", &p.skew_n, &p.skew_len);   // probe-only knob
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s, tile);

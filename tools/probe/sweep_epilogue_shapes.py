@@ -36,19 +36,24 @@ def timeit(fn, reps=10, warm=2):
 cases = [("resid K=768 N=768", R, 768, 768, L.PVRL_EPI_RESID_F32), ("bf16  K=768 N=768", R, 768, 768, L.PVRL_EPI_BF16),
          ("gelu  K=768 N=3072", M, 3072, 768, L.PVRL_EPI_GELU), ("dgelu K=768 N=3072", M, 3072, 768, L.PVRL_EPI_DGELU),
          ("resid K=3072 N=768", M, 768, 3072, L.PVRL_EPI_RESID_F32), ("bf16 K=768 N=2304", M, 2304, 768, L.PVRL_EPI_BF16)]
-for name, M_, N_, K_, epi in cases:
-    A = rnd(M_, K_).to(OP); W = (rnd(N_, K_) * 0.02).to(OP)
-    args = dict(bias=rnd(N_))
-    if epi == L.PVRL_EPI_RESID_F32:
-        args["aux"] = rnd(M_, N_)
-    if epi == L.PVRL_EPI_DGELU:
-        args["aux"] = rnd(M_, N_).to(OP); args.pop("bias")
-    us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
-    line = [f"{name:22s} product {us:7.1f} us ({2.0 * M_ * N_ * K_ / us / 1e6:6.0f} TF)"]
-    for tile in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
-        try:
-            us = timeit(lambda: pl.gemm_nt(tile, A, W, epi, **args))
-            line.append(f"t{tile}:{us:.0f}")
-        except Exception as e:  # noqa
-            line.append(f"t{tile}:ERR")
-    print("  ".join(line), flush=True)
+def main():
+  for name, M_, N_, K_, epi in cases:
+      A = rnd(M_, K_).to(OP); W = (rnd(N_, K_) * 0.02).to(OP)
+      args = dict(bias=rnd(N_))
+      if epi == L.PVRL_EPI_RESID_F32:
+          args["aux"] = rnd(M_, N_)
+      if epi == L.PVRL_EPI_DGELU:
+          args["aux"] = rnd(M_, N_).to(OP); args.pop("bias")
+      us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
+      line = [f"{name:22s} product {us:7.1f} us ({2.0 * M_ * N_ * K_ / us / 1e6:6.0f} TF)"]
+      for tile in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+          try:
+              us = timeit(lambda: pl.gemm_nt(tile, A, W, epi, **args))
+              line.append(f"t{tile}:{us:.0f}")
+          except Exception as e:  # noqa
+              line.append(f"t{tile}:ERR")
+      print("  ".join(line), flush=True)
+
+
+if __name__ == "__main__":
+  main()
