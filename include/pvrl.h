@@ -284,6 +284,18 @@ int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out
 /* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
 int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);
 
+/* ---- collectives (RCCL over xGMI), for hosts that bind this library without torch.distributed ------------------------
+ * Replaces: the DistributedDataParallel gradient reducer (lib/models/build.py:49-53) = in-place SUM all-reduce of the flat
+ * fp32 gradient buffer (averaging is the optimiser's gscale), and the all-gather of lib/utils/distributed.py:13-50
+ * (rank r's block lands at recv + r * bytes_per_rank).  One communicator per process / GPU; rank 0 creates the 128-byte id
+ * and hands it to the others out of band (file, env, socket).  Asynchronous on `stream` like every other entry point.
+ * RCCL is bound at run time: status -3 = librccl.so not found or a RCCL call failed. */
+int pvrl_comm_unique_id(void* id128);
+int pvrl_comm_init(void** comm, int world, int rank, const void* id128);
+int pvrl_comm_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int pvrl_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int pvrl_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 // bf16 MFMA GEMM, "NT" form: the C-ABI entry points.  The kernel, its epilogues and the tile launcher live in
 // gemm_nt_core.h (shared with the measured-and-rejected variants kept under tools/probe/, which are NOT part of this library).
+#include <cstdlib>
 #include "gemm_nt_core.h"
 
 namespace {
@@ -101,7 +102,8 @@ static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
 //  launch serialises behind the first; one launch with a partly idle last wave wins.)
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
-  if (p.M >= 4096 && p.N % 256 == 0) return launch_tile<EPI, 4, 4>(p, s);
+  static const bool persist = getenv("PVRL_NT_PERSIST") && atoi(getenv("PVRL_NT_PERSIST"));   // EXPERIMENT switch (to be fixed)
+  if (p.M >= 4096 && p.N % 256 == 0) return persist ? launch_tile_persist<EPI, 4, 4>(p, s) : launch_tile<EPI, 4, 4>(p, s);
   if (p.M >= 2048) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);
 }

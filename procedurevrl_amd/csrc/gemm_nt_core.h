@@ -71,28 +71,40 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     for (int nt = 0; nt < 4; ++nt)
       bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1))
                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // The residual loads of TWO row tiles (32 registers, freed by the MFMA fragments) go out together, twice: two memory
+    // round trips per wave instead of four dependent ones (all 16 at once would spill).  With every CU in its epilogue at
+    // the same time the loaded latency of a round trip is microseconds.  Rows past M load a clamped row and store nothing.
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + i;
-      if (m >= p.M) continue;
-      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
-      float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 8 * q;
-      const float* r = nullptr;
+    for (int half = 0; half < 2; ++half) {
+      f32x4 rv[2][4];
       if constexpr (EPI == PVRL_EPI_RESID_F32) {
-        const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
-        r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 8 * q;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = min(m0 + wm * 64 + (2 * half + h) * 16 + i, p.M - 1);
+          const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
+          const float* r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 8 * q;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) rv[h][nt] = *reinterpret_cast<const f32x4*>(r + 32 * (nt >> 1) + 4 * (nt & 1));
+        }
       }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int off = 32 * (nt >> 1) + 4 * (nt & 1);
-        f32x4 ov;
+      for (int h = 0; h < 2; ++h) {
+        const int mt = 2 * half + h;
+        const int m = m0 + wm * 64 + mt * 16 + i;
+        const float rs = p.rowscale ? p.rowscale[min(m, p.M - 1)] : 1.f;
+        float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 8 * q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
-        if constexpr (EPI == PVRL_EPI_RESID_F32) {
-          ov += *reinterpret_cast<const f32x4*>(r + off);
-          if (p.bias2) ov += *reinterpret_cast<const f32x4*>(p.bias2 + nw0 + 8 * q + off);
+        for (int nt = 0; nt < 4; ++nt) {
+          const int off = 32 * (nt >> 1) + 4 * (nt & 1);
+          f32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
+          if constexpr (EPI == PVRL_EPI_RESID_F32) {
+            ov += rv[h][nt];
+            if (p.bias2) ov += *reinterpret_cast<const f32x4*>(p.bias2 + nw0 + 8 * q + off);
+          }
+          if (m < p.M) *reinterpret_cast<f32x4*>(o + off) = ov;
         }
-        *reinterpret_cast<f32x4*>(o + off) = ov;
       }
     }
   } else {
@@ -103,42 +115,56 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
 #pragma unroll
       for (int e = 0; e < 8; ++e) bv[c][e] = p.bias ? p.bias[nw0 + 32 * c + 8 * q + e] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + i;
-      if (m >= p.M) continue;
-      const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+    for (int half = 0; half < 2; ++half) {
+      opx8 uv[2][2];
+      if constexpr (EPI == PVRL_EPI_DGELU || EPI == PVRL_EPI_DQGELU) {   // the stored pre-activations of two row tiles: one round trip
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float v[8];
+        for (int h = 0; h < 2; ++h) {
+          const int m = min(m0 + wm * 64 + (2 * half + h) * 16 + i, p.M - 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[mt][2 * c][e] + bv[c][e];
-          v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
+          for (int c = 0; c < 2; ++c)
+            uv[h][c] = *reinterpret_cast<const opx8*>((const op_t*)p.aux + (long)m * p.aux_ld + nw0 + 32 * c + 8 * q);
         }
-        const long col = nw0 + 32 * c + 8 * q;
-        if constexpr (EPI == PVRL_EPI_BF16) {
-          opx8 o0;
+      }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o0[e] = (op_t)(rs * v[e]);
-          *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
-        } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
-          opx8 u0, g0;
+      for (int h = 0; h < 2; ++h) {
+        const int mt = 2 * half + h;
+        const int m = m0 + wm * 64 + mt * 16 + i;
+        if (m >= p.M) continue;
+        const float rs = p.rowscale ? p.rowscale[m] : 1.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            u0[e] = (op_t)v[e];
-            g0[e] = (op_t)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
+        for (int c = 0; c < 2; ++c) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mt][2 * c][e] + bv[c][e];
+            v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
           }
-          *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = u0;
-          *reinterpret_cast<opx8*>((op_t*)p.out1 + (long)m * p.ld1 + col) = g0;
-        } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
-          const opx8 ua = *reinterpret_cast<const opx8*>((const op_t*)p.aux + (long)m * p.aux_ld + col);
-          opx8 o0;
+          const long col = nw0 + 32 * c + 8 * q;
+          if constexpr (EPI == PVRL_EPI_BF16) {
+            opx8 o0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
-            o0[e] = (op_t)(rs * v[e] * d);
+            for (int e = 0; e < 8; ++e) o0[e] = (op_t)(rs * v[e]);
+            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
+          } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
+            opx8 u0, g0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              u0[e] = (op_t)v[e];
+              g0[e] = (op_t)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
+            }
+            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = u0;
+            *reinterpret_cast<opx8*>((op_t*)p.out1 + (long)m * p.ld1 + col) = g0;
+          } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
+            const opx8 ua = uv[h][c];
+            opx8 o0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
+              o0[e] = (op_t)(rs * v[e] * d);
+            }
+            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
           }
-          *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
         }
       }
     }
@@ -271,6 +297,150 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   }
 
   nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PERSISTENT form of gemm_nt_kernel: one workgroup per CU walks its XCD's tile list with stride (workgroups per XCD)
+// instead of one workgroup per tile.  Same LDS image, staging, K loop and epilogue; what changes is the seam between two
+// tiles.  A one-tile workgroup pays, per tile: launch + LDS-DMA pipeline fill (first stage's HBM latency, nothing to
+// overlap it with) at the front, and at the back its epilogue's loads / stores must DRAIN before the wave slots and the
+// 128 KiB of LDS pass to the next workgroup.  Here the LDS-DMA of the NEXT tile's first stage is issued at the top of the
+// LAST K step of the current tile (the other ring slot is free by then), so it is in flight under that step's MFMAs and
+// under the whole epilogue, and the epilogue's stores drain under the next tile's first K steps.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_persist_kernel(GemmNT p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int NINST = (BM + BN) / 8;
+  constexpr int PER = NINST / NW;
+  static_assert(NINST % NW == 0, "stage instructions must divide evenly over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int GM = p.gm;
+  // this XCD's tile list (same order as gemm_nt_kernel): entry j -> (tm, tn)
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+  const int cm = qm + (xcd < rm ? 1 : 0);
+  const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+  const int nlist = cm * p.tiles_n;
+  const int gsz = GM * p.tiles_n;
+  auto tile_of = [&](int j, int& tm, int& tn) {
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  };
+  int j = blockIdx.x >> 3;
+  if (j >= nlist) return;
+  int tm, tn;
+  tile_of(j, tm, tn);
+
+  const op_t* gsrc[PER];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int it = wave * PER + e;
+      const int pc = lane & 7;
+      if (it < BM / 8) {
+        const int row = it * 8 + (lane >> 3);
+        int grow = m0 + row;
+        grow = grow < p.M ? grow : p.M - 1;
+        gsrc[e] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+      } else {
+        const int row = (it - BM / 8) * 8 + (lane >> 3);
+        gsrc[e] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
+      }
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) glds16(gsrc[e] + k0, b + (wave * PER + e) * 1024);
+  };
+  int xoff[4], woff[4];
+  {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rx = wm * 64 + t * 16 + i;
+      xoff[t] = rx * 128 + ((q ^ swz_x(rx)) << 4);
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = rw * 128 + ((q ^ swz_w<F32OUT>(rw)) << 4);
+    }
+  }
+  const int nk = p.K / BK;
+  int slot = 0;                       // ring slot holding the stage the next K step consumes
+  set_src(tm * BM, tn * BN);
+  stage(0, 0);
+  while (true) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool more = j + nper < nlist;          // workgroup-uniform
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
+      if (kt + 1 < nk) {
+        stage(slot ^ 1, (kt + 1) * BK);
+      } else if (more) {                         // the seam: the next tile's first stage goes out under this step + the epilogue
+        tile_of(j + nper, tm, tn);
+        set_src(tm * BM, tn * BN);
+        stage(slot ^ 1, 0);
+      }
+      const char* bx = smem + slot * STAGE;
+      const char* bw = bx + XBYTES;
+      opx8 xf0[4], wf0[4], xf1[4], wf1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf0[t] = *reinterpret_cast<const opx8*>(bw + woff[t]);
+        xf0[t] = *reinterpret_cast<const opx8*>(bx + xoff[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf1[t] = *reinterpret_cast<const opx8*>(bw + (woff[t] ^ 64));
+        xf1[t] = *reinterpret_cast<const opx8*>(bx + (xoff[t] ^ 64));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = MFMA_16x16x32(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = MFMA_16x16x32(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      slot ^= 1;
+    }
+    nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+    if (!more) break;
+    j += nper;
+  }
+}
+
+template <int EPI, int WM, int WN>
+int launch_tile_persist(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / (64 * WN);
+  p.tiles_m = cdiv(p.M, 64 * WM);
+  const int per_xcd = cdiv(p.tiles_m, 8) * p.tiles_n;          // longest per-XCD tile list
+  const int cus_per_xcd = 32;                                  // MI355X: 256 CUs in 8 XCDs, one 16-wave workgroup per CU
+  p.nwg = 8 * (per_xcd < cus_per_xcd ? per_xcd : cus_per_xcd);
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
 }
 
 template <int EPI, int WM, int WN>

@@ -23,7 +23,7 @@ def check_nt():
         bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
         ref = bf(A) @ bf(W).t()
         Ad, Wd = A.to(dev(), BF), W.to(dev(), BF)
-        for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+        for knob in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
             o = pl.gemm_nt(knob, Ad, Wd, L.PVRL_EPI_BF16, bias=bias.to(dev()))
             out.append((f"gemm_nt tile{knob} bf16 {M}x{N}x{K}", rel(o, ref + bias), TOL_BF16))
             o = pl.gemm_nt(knob, Ad, Wd, L.PVRL_EPI_RESID_F32, bias=bias.to(dev()), aux=resid.to(dev()))

@@ -1113,6 +1113,7 @@ int launch_w4x32(GemmNT p, hipStream_t s) {
 
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s, int t) {
+  if (t == 14 && p.N % 256 == 0) return launch_tile_persist<EPI, 4, 4>(p, s);      // persistent 256x256 (gemm_nt_core.h)
   if (t == 10 && p.N % 256 == 0) return launch_w4x32<EPI>(p, s);
   if (t == 11 && p.N % 256 == 0) {
     GemmNT q = p;

@@ -46,7 +46,7 @@ def main():
           args["aux"] = rnd(M_, N_).to(OP); args.pop("bias")
       us = timeit(lambda: ops.gemm_nt(A, W, epi, **args))
       line = [f"{name:22s} product {us:7.1f} us ({2.0 * M_ * N_ * K_ / us / 1e6:6.0f} TF)"]
-      for tile in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+      for tile in (3, 14, 3, 14):
           try:
               us = timeit(lambda: pl.gemm_nt(tile, A, W, epi, **args))
               line.append(f"t{tile}:{us:.0f}")
