@@ -145,7 +145,10 @@ class DiffusionTransformer(nn.Module):
         mask_inds, pad_start = rng["mask_inds"].to(dev), rng["pad_start"].to(dev)
         bs = torch.arange(b, device=dev)
         feats = x.view(b, L, C)                                  # batch-first view of '(b t) c'
-        x0 = feats[bs, mask_inds]                                # clip_feats_x0 (copy), tfm_model.py:148
+        rows = bs * L + mask_inds                                # row of each video's masked clip in the '(b t) c' matrix
+        # (index_select: its backward is index_add_, which a HIP graph can hold; advanced indexing's backward is a
+        #  sort-based index_put that crashes stream capture on ROCm 7.x)
+        x0 = x.index_select(0, rows)                             # clip_feats_x0 (copy), tfm_model.py:148
         pos = torch.arange(L, device=dev)[None, :]
         pad_mask = pos >= pad_start[:, None]                     # [b, L] bool, True = padded key
         feats = torch.where(pad_mask[:, :, None], self.pad_embedding.weight[0][None, None, :], feats)
@@ -164,7 +167,7 @@ class DiffusionTransformer(nn.Module):
             t = torch.full((b,), t_index, device=dev, dtype=torch.long)
             cur = cur + type_emb + temb + self._time_mlp(t)[:, None, :]
             out = self._stack(cur.reshape(b * L, C).contiguous(), b, L, kpm).view(b, L, C)
-            denoised = out[bs, mask_inds]
+            denoised = out.reshape(b * L, C).index_select(0, rows)
             intermediate.append(denoised)
         x0_rep = x0.unsqueeze(0).expand(self.total_levels, -1, -1).reshape(-1, C)
         inter = torch.cat(intermediate)

@@ -250,6 +250,41 @@ class VisionTransformer(nn.Module):
         s = all_samples.view(all_samples.shape[0] // L, L, -1)
         return s[torch.arange(s.shape[0], device=s.device), mask_inds, :]
 
+    def _pretrain_head(self, feat, teacher_x, rng, batch_size):
+        """Everything between the encoder's features and the loss in the pre-training forward (vit.py:298-352):
+        projection head, L2 norm, step logits, order / diffusion transformer, output assembly.
+        -> (pred [13b, K], teacher [13b, K], [mse_target, mse_pred])"""
+        dev = feat.device
+        le, le_t = self._labels(dev)
+        x = linear_f32(feat, self.head.weight, self.head.bias)
+        video_emb = l2norm(x)
+        self.last_video_emb = video_emb
+        x = step_logits(video_emb, le, le_t, self.temp)
+        pred_video_emb, mask_inds, mse, intermediate = self.order_tfm(video_emb, is_pretrain=True,
+                                                                     rng=(rng or {}).get("order"))
+        # (vit.py:331-334 also computes `mask_pred` from pred_video_emb; it is never used and is skipped)
+        masked_teacher_x = self.get_mask_samples(teacher_x, mask_inds)
+        intermediate = l2norm(intermediate.contiguous())
+        intermediate_pred = step_logits(intermediate, le, le_t, self.temp)
+        lv = self.order_tfm.level_batch
+        intermediate_teacher_x = masked_teacher_x.unsqueeze(0).expand(lv, -1, -1).reshape(-1, masked_teacher_x.size(-1))
+        n_keep = batch_size * self.order_recog_batch
+        rand_inds = (rng or {}).get("rand_inds")
+        if rand_inds is None:       # vit.py:345 torch.randperm; argsort of uniforms is the same distribution, sync-free and
+            rand_inds = torch.rand(x.shape[0], device=dev).argsort()        # capturable in a HIP graph
+        rand_inds = rand_inds.to(dev)[:n_keep]
+        x = torch.cat((x.index_select(0, rand_inds), intermediate_pred), dim=0)      # (index_select: see tfm_model.forward_pretrain)
+        teacher_x = torch.cat((teacher_x.index_select(0, rand_inds), intermediate_teacher_x), dim=0)
+        return x, teacher_x, mse
+
+    def _pretrain_forward(self, feat, text, rng, batch_size):
+        teacher_x = self.get_pseudo_labels(feat.device, text)                 # frozen text tower: its own HIP graph
+        # The head below (~1,000 small launches forward + backward) stays eager.  Replaying it from a HIP graph needs
+        # torch.autograd inside a stream capture; on ROCm 7.x that crashes in hipStreamEndCapture as soon as a leaf created on
+        # the default stream takes part (its AccumulateGrad node is bound to the default stream) -- tried in round 2,
+        # DESIGN.md section 7.  On an idle host the step time is the same either way (the host runs ahead of the GPU).
+        return self._pretrain_head(feat, teacher_x, rng, batch_size)
+
     def forward(self, x, rng=None):
         """`rng` (optional) pins the random draws of the pre-training forward:
         dict(order=<DiffusionTransformer.draw()>, rand_inds=<permutation>, droppath=<per-block dicts>)."""
@@ -263,8 +298,13 @@ class VisionTransformer(nn.Module):
             b, c, mt, h, w = x.shape
             t = mt // self.num_seg
             x = x.view(b, c, self.num_seg, t, h, w).permute(0, 2, 1, 3, 4, 5).reshape(b * self.num_seg, c, t, h, w)
-        x = self.forward_features(x.contiguous(), droppath=(rng or {}).get("droppath"))
+        x = feat = self.forward_features(x.contiguous(), droppath=(rng or {}).get("droppath"))
         dev = x.device
+        if isinstance(self.label_emb, torch.Tensor) and len(self.text) > 0 and self.training:
+            if not self.cfg.DEV.MATCH_LANG_EMB or (hasattr(self, "num_seg") and self.num_seg > 0):
+                raise NotImplementedError("pre-training forward (vit.py:325-352) is built for DEV.MATCH_LANG_EMB True and "
+                                          "MODEL.NUM_SEG 0, the setting of every shipped pre-training config")
+            return self._pretrain_forward(feat, text, rng, batch_size)
 
         if self.cfg.DEV.MATCH_LANG_EMB:
             le, le_t = self._labels(dev)
@@ -290,26 +330,6 @@ class VisionTransformer(nn.Module):
                     n = linear_f32(x, self.head_n.weight, self.head_n.bias) / self.temp
                     return (v, n)
                 x = linear_f32(x, self.head_cls.weight, self.head_cls.bias) / self.temp
-
-        if isinstance(self.label_emb, torch.Tensor) and len(self.text) > 0 and self.training:
-            le, le_t = self._labels(dev)
-            teacher_x = self.get_pseudo_labels(dev, text)
-            pred_video_emb, mask_inds, mse, intermediate = self.order_tfm(video_emb, is_pretrain=True,
-                                                                         rng=(rng or {}).get("order"))
-            # (vit.py:331-334 also computes `mask_pred` from pred_video_emb; it is never used and is skipped)
-            masked_teacher_x = self.get_mask_samples(teacher_x, mask_inds)
-            intermediate = l2norm(intermediate.contiguous())
-            intermediate_pred = step_logits(intermediate, le, le_t, self.temp)
-            lv = self.order_tfm.level_batch
-            intermediate_teacher_x = masked_teacher_x.unsqueeze(0).expand(lv, -1, -1).reshape(-1, masked_teacher_x.size(-1))
-            n_keep = batch_size * self.order_recog_batch
-            rand_inds = (rng or {}).get("rand_inds")
-            if rand_inds is None:
-                rand_inds = torch.randperm(x.shape[0], device=dev)
-            rand_inds = rand_inds.to(dev)[:n_keep]
-            x = torch.cat((x[rand_inds], intermediate_pred), dim=0)
-            teacher_x = torch.cat((teacher_x[rand_inds], intermediate_teacher_x), dim=0)
-            return x, teacher_x, mse
 
         if not self.training:
             x = ops.softmax_rows(x.contiguous())

@@ -83,9 +83,16 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     per_step = [round(evs[k].elapsed_time(evs[k + 1]), 1) for k in range(args.steps)]
     clips = args.videos * 9
-    print(json.dumps({"workload": f"full pre-training step, {args.arch}, {args.videos} videos x 9 clips of {frames}x224^2, "
-                                  "CLIP-text teacher (12 layers) + order transformer + KL/MSE + AdamW",
-                      "clips_per_s": round(clips / dt, 2), "ms_per_step": round(1e3 * dt, 2), "per_step_ms": per_step, "loss": float(loss)}))
+    from procedurevrl_amd._lib import OPERAND
+    print(json.dumps({"metric": f"training clips/sec ({frames}f x 224^2, {'ViT-B TimeSformer' if args.arch == 'vit' else 'MViTv2-S'}), "
+                                "FULL pre-training step", "value": round(clips / dt, 3), "unit": "clips/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt, 3), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": OPERAND, "data": "synthetic",
+                      "config": {"workload": f"full pre-training step (reference cfg shape): {args.videos} videos x 9 clips of "
+                                             f"{frames}x224^2, frozen CLIP-text teacher (12 layers, ctx 77) + order / diffusion "
+                                             "transformer + top-5 KL + MSE, fwd+bwd+AdamW (SURVEY 8d's separate 36-clip run)",
+                                 "clips_per_gpu": clips, "global_batch": clips, "parallelism": "dp1"},
+                      "per_step_ms": per_step, "loss": float(loss)}))
 
 
 if __name__ == "__main__":
