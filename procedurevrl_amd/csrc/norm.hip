@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NV], gy[NV];
+    f32x4 xh[NV], gy[NV], din[NV];
     float c1 = 0.f, c2 = 0.f;
+    // the incoming residual gradient is not needed before the row reductions, but its load goes out WITH x and dy: one
+    // memory round trip per row instead of two
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      din[j] = dx_in ? *reinterpret_cast<const f32x4*>(dx_in + (long)row * ldi + 4 * lane + 256 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = 4 * lane + 256 * j;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - c1 - xh[j][e] * c2);
-      if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + (long)row * ldi + c);
+      o += din[j];
       *reinterpret_cast<f32x4*>(dx_out + (long)row * ldo + c) = o;
       if (want_sum && row < dxs_rows) ds[j] += o;      // unscaled column sums of the rows that feed the next stage
       if (dxs && row < dxs_rows) {   // bf16 (optionally DropPath-scaled) copy: the GEMM operand of the next backward stage
@@ -180,6 +185,9 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
   }
 }
 
+// measured on MI355X (M = 50,208): alone, 256 workgroups are fastest (94 us; 512: 99, 1024: 111, 2048: 117 -- fewer partial
+// sums to write and reduce); inside the training step, next to the weight-gradient GEMMs of the side stream, 512 win (572 vs
+// 561 clips/s): one workgroup per CU is starved by the co-running kernel.
 constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 }  // namespace
