@@ -273,10 +273,11 @@ def spawn_ranks(n):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_j_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
+    (profiles/r2_b_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
     A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
-    path = os.path.join(ROOT, "profiles", "r1_j_traffic.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r2_b_traffic.json", "r1_j_traffic.json"))
+                 if os.path.exists(q)), None)
+    if path is None:
         return None
     t = json.load(open(path))
     epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
