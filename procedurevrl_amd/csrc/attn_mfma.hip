@@ -15,6 +15,18 @@
 // steps, and P feeds the second MFMA straight from registers as its b-operand.  V (and, in the
 // backward, K / Q / dO) is read through ds_read_b64_tr_b16 from a [4][16]-blocked LDS image, so
 // no transposed copies are ever built.
+// Round 2 measured a PERSISTENT form of the forward kernel (one workgroup per CU walking its (sequence, head) items, K / V in two
+// LDS slots filled by LDS-DMA one item ahead, counted vmcnt so output stores are not waited for; 8 waves sharing each K / V
+// fragment between two query tiles, or 16 waves): 121-127 us and 157 us against 100 us for this kernel at 3,072 items.  The
+// kernel is not latency-bound: an item costs ~8 us of CU time whatever hides its loads -- 700 MFMAs (1.4 us), 43 k exp2
+// (1.3 us at quarter rate), ~6 VALU operations per score (2 us) and 650 KB of LDS fragment reads (3-5 us) that 8-16 waves
+// do not overlap with each other -- 12 items per CU = the 96 us measured (3.3 TB/s is a consequence, not the limit).
+// Round 2 measured a PERSISTENT form of the forward kernel (one workgroup per CU walking its (sequence, head) items, K / V in two
+// LDS slots filled by LDS-DMA one item ahead, counted vmcnt so output stores are not waited for; 8 waves sharing each K / V
+// fragment between two query tiles, or 16 waves): 121-127 us and 157 us against 100 us for this kernel at 3,072 items.  The
+// kernel is not latency-bound: an item costs ~8 us of CU time whatever hides its loads -- 700 MFMAs (1.4 us), 43 k exp2
+// (1.3 us at quarter rate), ~6 VALU operations per score (2 us) and 650 KB of LDS fragment reads (3-5 us) that 8-16 waves
+// do not overlap with each other -- 12 items per CU = the 96 us measured (3.3 TB/s is a consequence, not the limit).
 // The number of 16-key tiles NKT is a template parameter (1, 2, 3, 5, 13): every loop over keys is
 // straight-line code the compiler can software-pipeline (a run-time tile count cost 5x in branches).
 #include "attn_common.h"

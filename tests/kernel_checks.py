@@ -357,7 +357,9 @@ def check_attn_mfma_spatial():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(7)
     out = []
-    for (B, T, N, H) in [(2, 4, 16, 2), (2, 8, 196, 12)]:
+    # (11, 8, 196, 12): 88 sequences x 12 heads = 1,056 (sequence, head) items -> the persistent LDS-DMA forward kernel,
+    # ragged over the 256 workgroups (some walk 5 items, some 4) and over the XCDs (11 sequences each)
+    for (B, T, N, H) in [(2, 4, 16, 2), (2, 8, 196, 12), (11, 8, 196, 12)]:
         HD = H * 64
         S = N + 1
         R = B * N * T
