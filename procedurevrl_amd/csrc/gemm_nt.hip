@@ -1,6 +1,5 @@
 // bf16 MFMA GEMM, "NT" form: the C-ABI entry points.  The kernel, its epilogues and the tile launcher live in
 // gemm_nt_core.h (shared with the measured-and-rejected variants kept under tools/probe/, which are NOT part of this library).
-#include <cstdlib>
 #include "gemm_nt_core.h"
 
 namespace {
@@ -102,8 +101,7 @@ static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
 //  launch serialises behind the first; one launch with a partly idle last wave wins.)
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
-  static const bool persist = getenv("PVRL_NT_PERSIST") && atoi(getenv("PVRL_NT_PERSIST"));   // EXPERIMENT switch (to be fixed)
-  if (p.M >= 4096 && p.N % 256 == 0) return persist ? launch_tile_persist<EPI, 4, 4>(p, s) : launch_tile<EPI, 4, 4>(p, s);
+  if (p.M >= 4096 && p.N % 256 == 0) return launch_tile<EPI, 4, 4>(p, s);
   if (p.M >= 2048) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);
 }
@@ -126,7 +124,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   p.A = (const op_t*)A; p.lda = lda; p.W = (const op_t*)W; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
-  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = NT_GM; p.skew_n = 0; p.skew_len = 0;
+  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = NT_GM;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s);

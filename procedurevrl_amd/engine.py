@@ -410,7 +410,7 @@ class EncoderEngine(GraphReplay):
         the first block's LayerNorm / QKV / attention; each block waits for its own event."""
         self._fe_events = {}
         side = self.side_stream(device)
-        if side is None or not device.type == "cuda" or os.environ.get("PVRL_FE_PREFETCH", "1") != "1":
+        if side is None or not device.type == "cuda":
             return
         stale = [blk for blk in self.m.blocks if self._fused_temporal_stale(blk)]
         if not stale:

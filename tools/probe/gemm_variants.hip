@@ -20,6 +20,152 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
+// PERSISTENT form of gemm_nt_kernel (probe tile 14; MEASURED round 2: 171 vs 128 us on the fp32-residual K = 768 shape,
+// 452 vs 351 us dGELU -- the loop-carried state pushes the 128-VGPR kernel into scratch spills): one workgroup per CU walks its XCD's tile list with stride (workgroups per XCD)
+// instead of one workgroup per tile.  Same LDS image, staging, K loop and epilogue; what changes is the seam between two
+// tiles.  A one-tile workgroup pays, per tile: launch + LDS-DMA pipeline fill (first stage's HBM latency, nothing to
+// overlap it with) at the front, and at the back its epilogue's loads / stores must DRAIN before the wave slots and the
+// 128 KiB of LDS pass to the next workgroup.  Here the LDS-DMA of the NEXT tile's first stage is issued at the top of the
+// LAST K step of the current tile (the other ring slot is free by then), so it is in flight under that step's MFMAs and
+// under the whole epilogue, and the epilogue's stores drain under the next tile's first K steps.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_persist_kernel(GemmNT p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int NINST = (BM + BN) / 8;
+  constexpr int PER = NINST / NW;
+  static_assert(NINST % NW == 0, "stage instructions must divide evenly over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int GM = p.gm;
+  // this XCD's tile list (same order as gemm_nt_kernel): entry j -> (tm, tn)
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+  const int cm = qm + (xcd < rm ? 1 : 0);
+  const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
+  const int nlist = cm * p.tiles_n;
+  const int gsz = GM * p.tiles_n;
+  auto tile_of = [&](int j, int& tm, int& tn) {
+    const int g = j / gsz, r = j - g * gsz;
+    const int gm = min(GM, cm - g * GM);
+    tn = r / gm;
+    tm = mbase + g * GM + (r - tn * gm);
+  };
+  int j = blockIdx.x >> 3;
+  if (j >= nlist) return;
+  int tm, tn;
+  tile_of(j, tm, tn);
+
+  const op_t* gsrc[PER];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int it = wave * PER + e;
+      const int pc = lane & 7;
+      if (it < BM / 8) {
+        const int row = it * 8 + (lane >> 3);
+        int grow = m0 + row;
+        grow = grow < p.M ? grow : p.M - 1;
+        gsrc[e] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
+      } else {
+        const int row = (it - BM / 8) * 8 + (lane >> 3);
+        gsrc[e] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
+      }
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* b = smem + buf * STAGE;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) glds16(gsrc[e] + k0, b + (wave * PER + e) * 1024);
+  };
+  int xoff[4], woff[4];
+  {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rx = wm * 64 + t * 16 + i;
+      xoff[t] = rx * 128 + ((q ^ swz_x(rx)) << 4);
+      const int rw = wn * 64 + w_row<F32OUT>(t, i);
+      woff[t] = rw * 128 + ((q ^ swz_w<F32OUT>(rw)) << 4);
+    }
+  }
+  const int nk = p.K / BK;
+  int slot = 0;                       // ring slot holding the stage the next K step consumes
+  set_src(tm * BM, tn * BN);
+  stage(0, 0);
+  while (true) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool more = j + nper < nlist;          // workgroup-uniform
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
+      if (kt + 1 < nk) {
+        stage(slot ^ 1, (kt + 1) * BK);
+      } else if (more) {                         // the seam: the next tile's first stage goes out under this step + the epilogue
+        tile_of(j + nper, tm, tn);
+        set_src(tm * BM, tn * BN);
+        stage(slot ^ 1, 0);
+      }
+      const char* bx = smem + slot * STAGE;
+      const char* bw = bx + XBYTES;
+      opx8 xf0[4], wf0[4], xf1[4], wf1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf0[t] = *reinterpret_cast<const opx8*>(bw + woff[t]);
+        xf0[t] = *reinterpret_cast<const opx8*>(bx + xoff[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf1[t] = *reinterpret_cast<const opx8*>(bw + (woff[t] ^ 64));
+        xf1[t] = *reinterpret_cast<const opx8*>(bx + (xoff[t] ^ 64));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = MFMA_16x16x32(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = MFMA_16x16x32(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      slot ^= 1;
+    }
+    nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+    if (!more) break;
+    j += nper;
+  }
+}
+
+template <int EPI, int WM, int WN>
+int launch_tile_persist(GemmNT p, hipStream_t s) {
+  p.tiles_n = p.N / (64 * WN);
+  p.tiles_m = cdiv(p.M, 64 * WM);
+  const int per_xcd = cdiv(p.tiles_m, 8) * p.tiles_n;          // longest per-XCD tile list
+  const int cus_per_xcd = 32;                                  // MI355X: 256 CUs in 8 XCDs, one 16-wave workgroup per CU
+  p.nwg = 8 * (per_xcd < cus_per_xcd ? per_xcd : cus_per_xcd);
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
 // 256x256 tile with EIGHT waves, each owning a 128(m) x 64(n) block (8 x 4 MFMA tiles, 128 accumulator VGPRs): 24
 // ds_read_b128 per 64 MFMAs instead of 32 per 64 for two 64x64 wave blocks, half as many waves meeting at each barrier.
 // Same LDS image, swizzles, staging (8 LDS-DMA instructions per wave and stage) and epilogue as gemm_nt_kernel.
@@ -1176,8 +1322,6 @@ extern "C" int pvrl_probe_gemm_nt_bf16(int tile, int gm, const void* A, int64_t 
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
   p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = gm < 1 ? NT_GM : gm;
-  p.skew_n = 0; p.skew_len = 0;
-  if (const char* e = getenv("PVRL_PROBE_SKEW")) sscanf(e, "%d,%d", &p.skew_n, &p.skew_len);   // probe-only knob
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s, tile);
