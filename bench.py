@@ -233,7 +233,7 @@ def main():
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "comm": None if world == 1 else {"backend": backend, "ranks": dist.get_world_size(),
-                                             "rccl": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None,
+                                             "rccl": rccl_version(torch) if backend == "nccl" else None,
                                              "grad_allreduce_mb": round(vt.grad_store().flat.numel() * 4 / 2 ** 20, 1)},
             "loss": float(loss.item()), "hip_graphs": bool(graphs), "hbm_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3),
@@ -256,6 +256,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(map(str, v)) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa  (informational field only)
+        return f"unknown ({type(e).__name__})"
 
 
 def spawn_ranks(n):

@@ -99,7 +99,85 @@ def construct_loader(cfg, split="train", num_videos=None, batch_size=None):
         shuffle, drop_last = split == "train", split == "train"
     sampler = create_sampler(ds, shuffle, cfg)
     return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(False if sampler else shuffle), sampler=sampler,
-                                       num_workers=0, drop_last=drop_last)
+                                       num_workers=0, drop_last=drop_last,
+                                       pin_memory=bool(cfg.DATA_LOADER.PIN_MEMORY) and torch.cuda.is_available())
+
+
+class DevicePrefetcher:
+    """Host-to-device overlap for the training loop (the reference pins loader memory and calls
+    `.cuda(non_blocking=True)` per batch inside the iteration, tools/train_net.py:103-119, DATA_LOADER.PIN_MEMORY).
+    Wraps a loader that yields `(inputs, labels, index, meta)`: batch i+1 is staged in pinned host memory and copied on a
+    dedicated HIP stream while step i computes; the consumer's stream waits on the copy's event, nothing blocks the host.
+    A 32-clip fp32 batch is 154 MB (2.4 ms at 63 GB/s of PCIe), a decoded uint8 batch 38 MB -- hidden either way."""
+
+    def __init__(self, loader, device):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def sampler(self):
+        return self.loader.sampler
+
+    @property
+    def dataset(self):
+        return self.loader.dataset
+
+    def _to_device(self, obj):
+        if torch.is_tensor(obj):
+            if obj.device.type != "cpu":
+                return obj.to(self.device, non_blocking=True)
+            src = obj if obj.is_pinned() else obj.pin_memory()
+            out = src.to(self.device, non_blocking=True)
+            self._hold.append(src)                      # the pinned source must outlive the asynchronous copy
+            return out
+        if isinstance(obj, dict):
+            return {k: self._to_device(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._to_device(v) for v in obj)
+        return obj
+
+    def _stage(self, batch):
+        self._hold = []
+        if self.stream is None:
+            return self._to_device(batch), None, []
+        with torch.cuda.stream(self.stream):
+            dev_batch = self._to_device(batch)
+            ev = self.stream.record_event()
+        return dev_batch, ev, self._hold
+
+    @staticmethod
+    def _record(obj, stream):
+        if torch.is_tensor(obj):
+            obj.record_stream(stream)
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                DevicePrefetcher._record(v, stream)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                DevicePrefetcher._record(v, stream)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            batch, ev, hold = nxt
+            try:
+                nxt = self._stage(next(it))             # next batch's copy is in flight while this one is consumed
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                self._record(batch, cur)                # allocated on the copy stream, consumed on the compute stream
+            yield batch
+            del hold
 
 
 def shuffle_dataset(loader, cur_epoch):

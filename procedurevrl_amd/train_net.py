@@ -17,7 +17,7 @@ from . import checkpoint as cu
 from . import distributed as du
 from . import optimizer as optim
 from .build import build_model
-from .datasets import construct_loader, shuffle_dataset
+from .datasets import DevicePrefetcher, construct_loader, shuffle_dataset
 from .vit import pretrain_loss
 
 
@@ -99,6 +99,9 @@ def train(cfg, max_iters=None):
     start_epoch = cu.load_train_checkpoint(cfg, model, optimizer)
     reducer = du.GradReducer(model.model)
     train_loader = construct_loader(cfg, "train")
+    dev = next(model.parameters()).device
+    if dev.type == "cuda":
+        train_loader = DevicePrefetcher(train_loader, dev)       # H2D copy of batch i+1 under step i
     for cur_epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
         shuffle_dataset(train_loader, cur_epoch)               # train_net.py:503
         train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_iters)

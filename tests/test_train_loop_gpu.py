@@ -81,3 +81,27 @@ def test_loss_decreases_on_fixed_batch():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_yields_the_loaders_batches_on_the_device(tmp_path):
+    """datasets.DevicePrefetcher (pinned staging + copy stream): same batches, same order, on the GPU, nested
+    meta dict included; the copy of batch i+1 is issued before batch i is consumed."""
+    from procedurevrl_amd.datasets import DevicePrefetcher, construct_loader
+    cfg = _cfg(tmp_path)
+    cfg.SYNTHETIC.NUM_VIDEOS = 5
+    cfg.TRAIN.BATCH_SIZE = 2
+    torch.manual_seed(3)
+    plain = list(construct_loader(cfg, "train"))
+    torch.manual_seed(3)
+    pf = DevicePrefetcher(construct_loader(cfg, "train"), "cuda:0")
+    assert len(pf) == len(plain) == 2 and pf.stream is not None
+    got = []
+    for inputs, labels, index, meta in pf:
+        assert inputs.is_cuda and labels.is_cuda and meta["clip_text_ids"].is_cuda and meta["clip_vis_feat"].is_cuda
+        (inputs * 2).sum().item()                       # consume on the current stream
+        got.append((inputs.cpu(), labels.cpu(), index.cpu(), {k: v.cpu() for k, v in meta.items()}))
+    for a, b in zip(got, plain):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for k in b[3]:
+            assert torch.equal(a[3][k], b[3][k]), k
