@@ -102,3 +102,42 @@ def test_fused_step_matches_torch_optim(method):
     print(method, worst)
     for k, v in worst.items():
         assert v <= TOL, (method, k, v, worst)
+
+
+@pytest.mark.gpu
+def test_resume_from_a_torch_optim_sgd_checkpoint_keeps_the_momentum():
+    """A reference checkpoint's `optimizer_state` is a torch.optim state_dict (lib/utils/checkpoint.py:126-131) with no
+    private keys.  Loading it and stepping on must continue torch's trajectory: in particular the loaded SGD momentum
+    buffers are used, not overwritten by the "first step" branch (round-1 ADVICE)."""
+    import e2e_checks as ec
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+    torch.manual_seed(1)
+    cfg = ec.make_cfg(1, 32, 64)
+    cfg.SOLVER.OPTIMIZING_METHOD = "sgd"
+    cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV, cfg.SOLVER.WEIGHT_DECAY = 0.9, True, 1e-4
+    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1))
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    cpu = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in named}
+    ref = torch.optim.SGD([{"params": []}, {"params": [cpu[n] for n, _ in named]}], lr=1e-2, momentum=0.9, nesterov=True,
+                          weight_decay=1e-4)                                 # same group layout as construct_optimizer
+    gen = torch.Generator().manual_seed(9)
+    grads = [{n: torch.randn(p.shape, generator=gen) * 0.1 for n, p in named} for _ in range(3)]
+    for k in range(2):                                                        # two steps in torch only
+        for n, _ in named:
+            cpu[n].grad = grads[k][n].clone()
+        ref.step()
+    with torch.no_grad():
+        for n, p in named:
+            p.copy_(cpu[n])
+    opt = construct_optimizer(model, cfg)
+    opt.load_state_dict(ref.state_dict())
+    set_lr(opt, 1e-2)
+    for n, p in named:
+        p.grad = grads[2][n].to(p.device)
+        cpu[n].grad = grads[2][n].clone()
+    opt.step()
+    ref.step()
+    torch.cuda.synchronize()
+    worst = max(float((p.detach().cpu() - cpu[n].detach()).abs().max() / cpu[n].detach().abs().max()) for n, p in named)
+    assert worst <= TOL, worst
