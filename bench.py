@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (A/B switch)")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of HIP-graph replay of the encoder")
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient instead of one per block")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (configs[3] T=32 and configs[4] MViTv2-S) "
+                                                           "that the default single-GPU run appends to its JSON line")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
     args = ap.parse_args()
@@ -252,10 +254,35 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # noqa
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
+        if world == 1 and args.arch == "vit" and args.frames == 8 and not args.no_side and not args.no_cpu_baseline:
+            # the other single-GPU configurations BASELINE names, timed by the same script in child processes (their own
+            # model, graphs and memory): configs[3] long clips (T = 32) and configs[4] MViTv2-S.  Informational: `value` above
+            # is the headline metric; a failing side run is reported, never fatal.
+            del model, vt, optimizer, reducer, frames, teacher
+            torch.cuda.empty_cache()
+            out["side"] = side_measurements()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_measurements():
+    import subprocess
+    res = []
+    for name, extra in (("configs[3]: TimeSformer ViT-B 32x224^2, 8 clips/GPU", ["--frames", "32", "--batch", "8"]),
+                        ("configs[4]: MViTv2-S 16x224^2, 32 clips/GPU", ["--arch", "mvit"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+               "--no-kernel-timing", "--no-side"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            res.append({"config": name, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                        "steps": d["steps"], "frac_of_bf16_peak": d["end_to_end"]["frac_of_bf16_peak"]})
+        except Exception as e:  # noqa
+            res.append({"config": name, "error": repr(e)[:160]})
+    return res
 
 
 def rccl_version(torch):
