@@ -499,7 +499,7 @@ struct MaxPoolGeom {
 
 // out rows: (b, t, ho, wo) then the B cls rows (copied).  4 channels per thread.
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, MaxPoolGeom g,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, unsigned char* __restrict__ amax) {
   const int c4n = g.C >> 2;
   const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
   const long rows = g.B * Lo + g.B;
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       const int wo = (int)(row % g.Wo), ho = (int)((row / g.Wo) % g.Ho);
       const long bt = row / ((long)g.Wo * g.Ho);       // b*T + t
       m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int arg[4] = {-1, -1, -1, -1};
       for (int yy = 0; yy < g.k; ++yy) {
         const int yi = ho * g.s - pad + yy;
         if (yi < 0 || yi >= g.H) continue;
@@ -523,8 +524,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
           if (xi < 0 || xi >= g.W) continue;
           const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bt * g.H + yi) * g.W + xi) * g.ldi + c4 * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+          for (int e = 0; e < 4; ++e)
+            if (v[e] > m[e] || arg[e] < 0) { m[e] = v[e]; arg[e] = yy * g.k + xx; }   // first maximum in scan order
         }
+      }
+      if (amax) {      // window-local position of each channel's winner: the backward routes by it instead of re-scanning
+        const unsigned w = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+        *reinterpret_cast<unsigned*>(amax + row * g.C + c4 * 4) = w;
       }
     }
     *reinterpret_cast<f32x4*>(y + row * g.ldo + c4 * 4) = m;
@@ -536,7 +542,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 // 2 x 2) windows that contain it and adds, in a fixed order, the gradients of those it wins -- so there are no atomics
 // (bit-reproducible) and dx needs no zero fill.  4 channels per thread.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          MaxPoolGeom g, float* __restrict__ dx) {
+                                                          MaxPoolGeom g, float* __restrict__ dx,
+                                                          const unsigned char* __restrict__ amax) {
   const int c4n = g.C >> 2;
   const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
   const long rows = g.B * L + g.B;
@@ -560,6 +567,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     ho1 = ho1 < g.Ho - 1 ? ho1 : g.Ho - 1;
     wo1 = wo1 < g.Wo - 1 ? wo1 : g.Wo - 1;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (amax) {       // the forward recorded every window's winner (1 byte per channel): 4 bytes + 16 bytes of dy per window
+      for (int ho = ho0; ho <= ho1; ++ho)
+        for (int wo = wo0; wo <= wo1; ++wo) {
+          const long orow = (bt * g.Ho + ho) * g.Wo + wo;
+          const unsigned w = *reinterpret_cast<const unsigned*>(amax + orow * g.C + c);
+          const unsigned mine = (unsigned)((yi - (ho * g.s - pad)) * g.k + (xi - (wo * g.s - pad)));
+          const f32x4 d = *reinterpret_cast<const f32x4*>(dy + orow * g.ldo + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (((w >> (8 * e)) & 255u) == mine) acc[e] += d[e];
+        }
+      *reinterpret_cast<f32x4*>(dx + row * g.ldi + c) = acc;
+      continue;
+    }
     for (int ho = ho0; ho <= ho1; ++ho)
       for (int wo = wo0; wo <= wo1; ++wo) {
         f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -886,24 +907,26 @@ static int maxpool_geom(MaxPoolGeom& g, int64_t B, int64_t T, int64_t H, int64_t
 }
 
 extern "C" int pvrl_mvit_maxpool_fwd(const float* x, int64_t ldi, int64_t B, int64_t T, int64_t H, int64_t W, int64_t s,
-                                     int64_t C, float* y, int64_t ldo, void* stream) {
+                                     int64_t C, float* y, int64_t ldo, void* argmax, void* stream) {
   MaxPoolGeom g;
   if (!x || !y || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
   const long total = ((long)B * T * g.Ho * g.Wo + B) * (C >> 2);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, g, y);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, g, y,
+                     (unsigned char*)argmax);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
 
 extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* dy, int64_t ldo, int64_t B, int64_t T,
-                                     int64_t H, int64_t W, int64_t s, int64_t C, float* dx, void* stream) {
+                                     int64_t H, int64_t W, int64_t s, int64_t C, float* dx, const void* argmax, void* stream) {
   MaxPoolGeom g;
   if (!x || !dy || !dx || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
   // (no zero fill: the gather kernel writes every element.  An earlier scatter version zeroed dx with hipMemsetAsync, whose
   //  memset node in a captured HIP graph did not re-zero the buffer on replay -- ROCm 7.2 -- so gradients accumulated
   //  across replays; nothing on a captured path uses hipMemset* any more.)
   const long total = ((long)B * T * H * W + B) * (C >> 2);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx,
+                     (const unsigned char*)argmax);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -384,9 +384,12 @@ class MViTEngine(GraphReplay):
         pooled = max(sq) > 1
         if pooled:
             assert sq[0] == 1 and sq[1] == sq[2], "max-pool skip kernel is built for stride (1, s, s)"
-            xres = om.maxpool_fwd(xs, B, thw, sq[1], dout)
+            if save:
+                xres, amax = om.maxpool_fwd(xs, B, thw, sq[1], dout, want_argmax=True)
+            else:
+                xres, amax = om.maxpool_fwd(xs, B, thw, sq[1], dout), None
         else:
-            xres = xs
+            xres, amax = xs, None
         # DropPath: one factor per clip, expanded to the output rows (patch tokens (b, l) then the cls rows)
         rs_a = rs_m = None
         if dp is not None:
@@ -401,7 +404,7 @@ class MViTEngine(GraphReplay):
         x2 = ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, rowscale=rs_m, aux=x1)
         if save:
             sv["blocks"].append(dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, q=q, k=k, v=v, cq=cq, ck=ck, cv=cv,
-                                     rel=rel, o=o, lse=lse, xs=xs if pooled else None, x1=x1, xn2=xn2, mean2=mean2,
+                                     rel=rel, o=o, lse=lse, xs=xs if pooled else None, amax=amax, x1=x1, xn2=xn2, mean2=mean2,
                                      rstd2=rstd2, u=u, g=g, q_thw=q_thw, k_thw=k_thw, pooled=pooled, rs_a=rs_a, rs_m=rs_m))
         return x2
 
@@ -487,7 +490,7 @@ class MViTEngine(GraphReplay):
         self._wgrad(dqkv, s["xn"], a.qkv.weight, a.qkv.bias, wqkv)
         dxn = ops.gemm_nt(dqkv, wqkv.t, L.PVRL_EPI_F32)
         # ---- skip path
-        dxs = om.maxpool_bwd(s["xs"], dx1, B, thw, sq[1], dout) if s["pooled"] else dx1
+        dxs = om.maxpool_bwd(s["xs"], dx1, B, thw, sq[1], dout, argmax=s["amax"]) if s["pooled"] else dx1
         dres = None
         if dim != dout:
             wsk = self._wpad(blk.proj.weight, blk.proj.bias)

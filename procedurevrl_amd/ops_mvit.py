@@ -81,7 +81,8 @@ def pool_bwd(dy, conv_out, qkv, dqkv, col0, B, H, thw, stride, w, gamma, eps, dw
            ws.numel(), _stream())
 
 
-def maxpool_fwd(x, B, thw, s, C):
+def maxpool_fwd(x, B, thw, s, C, want_argmax=False):
+    """-> y, or (y, argmax uint8 [B*T*Ho*Wo, C]) with `want_argmax` (saved for maxpool_bwd)"""
     L = lib()
     T, H, W = thw
     k = s + 1
@@ -89,17 +90,19 @@ def maxpool_fwd(x, B, thw, s, C):
     y = torch.empty((B * T * Ho * Wo + B, x.shape[1]), device=x.device, dtype=F32)
     if x.shape[1] > C:
         y[:, C:].zero_()
-    L.call("pvrl_mvit_maxpool_fwd", _ptr(x), x.stride(0), B, T, H, W, s, C, _ptr(y), y.stride(0), _stream())
-    return y
+    am = torch.empty((B * T * Ho * Wo, C), device=x.device, dtype=torch.uint8) if want_argmax else None
+    L.call("pvrl_mvit_maxpool_fwd", _ptr(x), x.stride(0), B, T, H, W, s, C, _ptr(y), y.stride(0), _ptr(am), _stream())
+    return (y, am) if want_argmax else y
 
 
-def maxpool_bwd(x, dy, B, thw, s, C):
+def maxpool_bwd(x, dy, B, thw, s, C, argmax=None):
     L = lib()
     T, H, W = thw
     dx = torch.empty_like(x)
     if x.shape[1] > C:
         dx[:, C:].zero_()          # the kernel writes the C real columns of every row; the padding stays zero
-    L.call("pvrl_mvit_maxpool_bwd", _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), B, T, H, W, s, C, _ptr(dx), _stream())
+    L.call("pvrl_mvit_maxpool_bwd", _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), B, T, H, W, s, C, _ptr(dx), _ptr(argmax),
+           _stream())
     return dx
 
 

@@ -126,6 +126,10 @@ def check_mvit_maxpool_rel():
     dx = om.maxpool_bwd(x.to(DEV), dy.to(DEV), B, thw, 2, C)
     out.append(("maxpool bwd tokens", rel(dx[:B * L, :C], xr.grad[:, 1:].reshape(B * L, C)), 1e-6))
     out.append(("maxpool bwd cls", rel(dx[B * L:, :C], xr.grad[:, 0]), 0.0))
+    y2, am = om.maxpool_fwd(x.to(DEV), B, thw, 2, C, want_argmax=True)          # the path the engine takes: saved winners
+    dx2 = om.maxpool_bwd(x.to(DEV), dy.to(DEV), B, thw, 2, C, argmax=am)
+    out.append(("maxpool fwd with argmax == without", 0.0 if torch.equal(y2, y) else 1.0, 0.0))
+    out.append(("maxpool bwd routed by saved argmax == re-scanned", 0.0 if torch.equal(dx2, dx) else 1.0, 0.0))
     # relative-position tables
     for q_thw, k_thw in [((2, 8, 8), (2, 2, 2)), ((2, 4, 4), (2, 4, 4)), ((3, 4, 8), (3, 4, 2))]:
         BH = 3
