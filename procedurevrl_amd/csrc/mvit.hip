@@ -245,7 +245,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const op_t* __restrict__ 
   float gm[6], bt[6];
 #pragma unroll
   for (int e = 0; e < 6; ++e) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
-  for (unsigned tok = (blockIdx.x * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
+  // Workgroup b runs on XCD b % 8: dealt out in launch order, every XCD would touch every part of the clip and its 4 MiB L2
+  // would have to hold the +-1 frame halo of ALL tokens in flight (~10 MB at 56 x 56 tokens per frame: measured 502 us for
+  // block 0's q pooling, L2-miss-bound).  xcd_remap gives each XCD one contiguous run of tokens: its own three frames.
+  const unsigned wg = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  for (unsigned tok = (wg * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
     const int lo = (int)(tok % (unsigned)(Lo + 1));
     const unsigned bh = tok / (unsigned)(Lo + 1);
     const int h = (int)(bh % (unsigned)g.H), b = (int)(bh / (unsigned)g.H);
@@ -365,7 +369,8 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const op_t* __restrict_
   const int Lo = g.To * g.Ho * g.Wo, L = g.T * g.Hh * g.Ww;
   const int st = S ? 1 : g.st, sh = S ? S : g.sh, sw = S ? S : g.sw;
   const unsigned ntok = (unsigned)((long)g.B * g.H * L);          // < 2^31 (checked by the launcher)
-  for (unsigned tok = (blockIdx.x * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
+  const unsigned wg = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);     // contiguous tokens per XCD (see pool_fwd_kernel)
+  for (unsigned tok = (wg * 256u + threadIdx.x) >> 4; tok < ntok; tok += (gridDim.x * 256u) >> 4) {
     const unsigned l = tok % (unsigned)L, bh = tok / (unsigned)L;
     const unsigned h = bh % (unsigned)g.H, b = bh / (unsigned)g.H;
     const int xi = (int)(l % (unsigned)g.Ww), yi = (int)((l / (unsigned)g.Ww) % (unsigned)g.Hh), ti = (int)(l / (unsigned)(g.Ww * g.Hh));
@@ -423,7 +428,12 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const op_t
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) red[i / HD][i % HD] = 0.f;
-  for (long tok = (long)blockIdx.x * PW_LANES + tl; tok < ntok; tok += (long)gridDim.x * PW_LANES) {
+  // each workgroup sums ONE contiguous run of tokens (its 8 token lanes interleaved inside it), runs dealt to the XCDs in
+  // contiguous chunks: neighbouring outputs share 2/3 of their 27 inputs, and an XCD's L2 sees only its own frames
+  const long wgl = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const long chunk = (ntok + gridDim.x - 1) / gridDim.x;
+  const long tend = min(ntok, (wgl + 1) * chunk);
+  for (long tok = wgl * chunk + tl; tok < tend; tok += PW_LANES) {
     const int lo = (int)(tok % Lo);
     const long bh = tok / Lo;
     const int h = (int)(bh % g.H), b = (int)(bh / g.H);
