@@ -296,6 +296,95 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const op_t* __restrict__ 
   }
 }
 
+// The same for temporal stride 1 (every MViTv2 pooling operator: stride (1, s, s)), sliding along t: the kernel above is
+// VALU-bound, not memory-bound -- per output 27 x (address arithmetic + 12-byte load + unpack) next to the 162 FMAs (488 us
+// for block 0's q pooling against ~100 us of memory time).  Here 16 lanes own one output COLUMN (b, h, yo, xo) and walk the
+// T input frames once: the 9 in-plane neighbours of a frame are loaded ONCE and feed three running sums (the outputs of the
+// frame before, this frame and the next: taps a = 2, 1, 0); a third of the loads, unpacks and address computations.
+__device__ __forceinline__ void pool_ln_store(const float (&acc)[6], const float (&gm)[6], const float (&bt)[6], float eps,
+                                              op_t* cdst, op_t* ydst) {
+  st6(cdst, acc);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) s += acc[e];
+  const float mu = sum16(s) * (1.f / HD);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) q += (acc[e] - mu) * (acc[e] - mu);
+  const float rs = rsqrtf(sum16(q) * (1.f / HD) + eps);
+  float o[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) o[e] = (acc[e] - mu) * rs * gm[e] + bt[e];
+  st6(ydst, o);
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_t_kernel(const op_t* __restrict__ qkv, PoolGeom g,
+                                                         const float* __restrict__ w, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, op_t* __restrict__ y,
+                                                         op_t* __restrict__ cbuf) {
+  __shared__ float ws[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];   // [tap][c]
+  __syncthreads();
+  const int sub = threadIdx.x & 15, c0 = sub * 6;
+  const int HoWo = g.Ho * g.Wo, Lo = g.T * HoWo, L = g.T * g.Hh * g.Ww, plane = g.Hh * g.Ww;
+  const unsigned ncol = (unsigned)((long)g.B * g.H * (HoWo + 1));      // + one "column" per (b, h) for the cls token
+  float gm[6], bt[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
+  const unsigned wg = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  for (unsigned colid = (wg * 256u + threadIdx.x) >> 4; colid < ncol; colid += (gridDim.x * 256u) >> 4) {
+    const int pos = (int)(colid % (unsigned)(HoWo + 1));
+    const unsigned bh = colid / (unsigned)(HoWo + 1);
+    const int h = (int)(bh % (unsigned)g.H), b = (int)(bh / (unsigned)g.H);
+    const int col = g.col0 + h * HD + c0;
+    op_t* cdst = cbuf + (long)bh * (Lo + 1) * HD + c0;
+    op_t* ydst = y + (long)bh * (Lo + 1) * HD + c0;
+    if (pos == HoWo) {                                               // cls token: LayerNorm only
+      float acc[6];
+      ld6(qkv + (g.cls_row0 + b) * g.ld + col, acc);
+      pool_ln_store(acc, gm, bt, eps, cdst + (long)Lo * HD, ydst + (long)Lo * HD);
+      continue;
+    }
+    const int xo = pos % g.Wo, yo = pos / g.Wo;
+    int noff[9];                                                      // row offset of the 9 in-plane neighbours, -1 = outside
+#pragma unroll
+    for (int yy = 0; yy < 3; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 3; ++xx) {
+        const int yi = yo * g.sh - 1 + yy, xi = xo * g.sw - 1 + xx;
+        noff[yy * 3 + xx] = (yi >= 0 && yi < g.Hh && xi >= 0 && xi < g.Ww) ? yi * g.Ww + xi : -1;
+      }
+    const op_t* base = qkv + (long)b * L * g.ld + col;
+    float aP[6], aC[6], aN[6];                                        // running sums of outputs t-1, t, t+1
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { aP[e] = 0.f; aC[e] = 0.f; aN[e] = 0.f; }
+    for (int ti = 0; ti < g.T; ++ti) {
+      const op_t* pb = base + (long)ti * plane * g.ld;
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        if (noff[n] < 0) continue;
+        float v[6];
+        ld6(pb + (long)noff[n] * g.ld, v);
+        const float* w0 = ws + n * HD + c0;                            // tap (a, yy, xx) at [(a*9 + n)][c]
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          aN[e] = fmaf(v[e], w0[e], aN[e]);                            // a = 0: this frame is the one BEFORE output ti + 1
+          aC[e] = fmaf(v[e], w0[9 * HD + e], aC[e]);                   // a = 1
+          aP[e] = fmaf(v[e], w0[18 * HD + e], aP[e]);                  // a = 2: this frame is the one AFTER output ti - 1
+        }
+      }
+      if (ti >= 1) {
+        const long o = ((long)(ti - 1) * HoWo + pos) * HD;
+        pool_ln_store(aP, gm, bt, eps, cdst + o, ydst + o);
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { aP[e] = aC[e]; aC[e] = aN[e]; aN[e] = 0.f; }
+    }
+    const long o = ((long)(g.T - 1) * HoWo + pos) * HD;
+    pool_ln_store(aP, gm, bt, eps, cdst + o, ydst + o);
+  }
+}
+
 // LayerNorm backward of the pooled tensor: dc = dLN(dy | c) (bf16, same layout), dgamma / dbeta accumulated atomically;
 // the cls token's dc goes straight to its row of the packed activation gradient (it bypassed the conv).
 __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const op_t* __restrict__ dy, const op_t* __restrict__ cbuf,
@@ -402,6 +491,59 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const op_t* __restrict_
       }
     }
     st6(dqkv + ((long)b * L + l) * g.ld + g.col0 + h * HD + c0, acc);
+  }
+}
+
+// The same for temporal stride 1, sliding along t (see pool_fwd_t_kernel): 16 lanes own one INPUT column (b, h, yi, xi); the
+// (at most 9) outputs of a frame that touch it are loaded once and feed the running sums of dX at t - 1, t and t + 1.
+__global__ __launch_bounds__(256) void pool_dgrad_t_kernel(const op_t* __restrict__ dc, PoolGeom g,
+                                                           const float* __restrict__ w, op_t* __restrict__ dqkv) {
+  __shared__ float ws[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) ws[i] = w[(i % HD) * 27 + i / HD];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, c0 = sub * 6;
+  const int HoWo = g.Ho * g.Wo, Lo = g.T * HoWo, plane = g.Hh * g.Ww, L = g.T * plane;
+  const unsigned ncol = (unsigned)((long)g.B * g.H * plane);
+  const unsigned wg = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  for (unsigned colid = (wg * 256u + threadIdx.x) >> 4; colid < ncol; colid += (gridDim.x * 256u) >> 4) {
+    const int pos = (int)(colid % (unsigned)plane);
+    const unsigned bh = colid / (unsigned)plane;
+    const int h = (int)(bh % (unsigned)g.H), b = (int)(bh / (unsigned)g.H);
+    const int xi = pos % g.Ww, yi = pos / g.Ww;
+    int noff[9];                                   // output position (yo * Wo + xo) reached through tap (yy, xx), -1 = none
+#pragma unroll
+    for (int yy = 0; yy < 3; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 3; ++xx) {
+        const int yn = yi + 1 - yy, xn = xi + 1 - xx;
+        const bool ok = yn >= 0 && xn >= 0 && (yn % g.sh) == 0 && (xn % g.sw) == 0 && yn / g.sh < g.Ho && xn / g.sw < g.Wo;
+        noff[yy * 3 + xx] = ok ? (yn / g.sh) * g.Wo + xn / g.sw : -1;
+      }
+    const op_t* base = dc + (long)bh * (Lo + 1) * HD + c0;
+    op_t* dst = dqkv + ((long)b * L + pos) * g.ld + g.col0 + h * HD + c0;
+    float aP[6], aC[6], aN[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { aP[e] = 0.f; aC[e] = 0.f; aN[e] = 0.f; }
+    for (int to = 0; to < g.T; ++to) {
+      const op_t* pb = base + (long)to * HoWo * HD;
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        if (noff[n] < 0) continue;
+        float v[6];
+        ld6(pb + (long)noff[n] * HD, v);
+        const float* w0 = ws + n * HD + c0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          aP[e] = fmaf(v[e], w0[e], aP[e]);                            // a = 0: output frame `to` reads input frame to - 1
+          aC[e] = fmaf(v[e], w0[9 * HD + e], aC[e]);                   // a = 1
+          aN[e] = fmaf(v[e], w0[18 * HD + e], aN[e]);                  // a = 2: ... and input frame to + 1
+        }
+      }
+      if (to >= 1) st6(dst + (long)(to - 1) * plane * g.ld, aP);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { aP[e] = aC[e]; aC[e] = aN[e]; aN[e] = 0.f; }
+    }
+    st6(dst + (long)(g.T - 1) * plane * g.ld, aP);
   }
 }
 
@@ -851,8 +993,14 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   if (!qkv || !w || !gamma || !beta || !y || !conv_out || pool_geom(g, B, H, T, Hh, Ww, st, sh, sw, ld, col0)) return PVRL_EINVAL;
   const long ntok = (long)B * H * ((long)g.To * g.Ho * g.Wo + 1);
   if (ntok >= (1L << 27)) return PVRL_EINVAL;         // 16 lanes per token, 32-bit token arithmetic in the kernel
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
-                     w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
+  if (g.st == 1) {      // temporal stride 1 (every MViTv2 pooling operator): one 16-lane group per output column, sliding along t
+    const long ncol = (long)B * H * ((long)g.Ho * g.Wo + 1);
+    hipLaunchKernelGGL(pool_fwd_t_kernel, dim3(grid_for(ncol * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
+                       w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
+  } else {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
+                       w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
+  }
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -889,7 +1037,10 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
     const dim3 dg(grid_for(nin * 16)), db(256);
     const int S = (st == 1 && sh == sw && (sh == 1 || sh == 2 || sh == 4 || sh == 8)) ? (int)sh : 0;
 #define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const op_t*)dc_scratch, g, w, (op_t*)dqkv)
-    if (S == 1) DGRAD(1); else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
+    if (st == 1)         // temporal stride 1: one 16-lane group per input column, sliding along t
+      hipLaunchKernelGGL(pool_dgrad_t_kernel, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch, g, w,
+                         (op_t*)dqkv);
+    else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
 #undef DGRAD
   }
   PVRL_LAUNCH_CHECK();

@@ -66,7 +66,9 @@ def check_mvit_pool():
     from procedurevrl_amd import ops_mvit as om
     g = torch.Generator().manual_seed(2)
     out = []
-    for (B, H, thw, stride) in [(2, 2, (2, 8, 8), (1, 2, 2)), (1, 1, (3, 6, 10), (1, 1, 1)), (2, 4, (2, 8, 8), (1, 4, 4))]:
+    # temporal stride 1 -> the t-sliding forward kernel (incl. a single frame); (2, 2, 2) -> the general one
+    for (B, H, thw, stride) in [(2, 2, (2, 8, 8), (1, 2, 2)), (1, 1, (3, 6, 10), (1, 1, 1)), (2, 4, (2, 8, 8), (1, 4, 4)),
+                                (1, 1, (1, 6, 6), (1, 1, 1)), (1, 2, (4, 6, 6), (2, 2, 2)), (3, 1, (8, 14, 14), (1, 1, 1))]:
         T, Hh, Ww = thw
         L = T * Hh * Ww
         dout = H * 96
