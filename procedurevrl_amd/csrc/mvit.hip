@@ -617,6 +617,68 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_kernel(const op_t
   for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) mine[i] = red[i / HD][i % HD];
 }
 
+// The same for temporal stride 1, sliding along t: a token lane walks the T frames of one output COLUMN (b, h, yo, xo); the 9
+// in-plane inputs of frame ti are loaded once and meet the conv outputs' gradients of frames ti + 1, ti, ti - 1 (taps a = 0, 1,
+// 2), which stay in registers: 10 loads per output instead of 28, and no 27-vector of inputs to keep.
+__global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_t_kernel(const op_t* __restrict__ dc,
+                                                                        const op_t* __restrict__ qkv, PoolGeom g,
+                                                                        float* __restrict__ part) {
+  __shared__ float red[27][HD];
+  const int cq = threadIdx.x % PW_CQ, tl = threadIdx.x / PW_CQ, c0 = cq * 4;
+  const int HoWo = g.Ho * g.Wo, Lo = g.T * HoWo, plane = g.Hh * g.Ww, L = g.T * plane;
+  const long ncol = (long)g.B * g.H * HoWo;
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) red[i / HD][i % HD] = 0.f;
+  const long wgl = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const long chunk = (ncol + gridDim.x - 1) / gridDim.x;
+  const long cend = min(ncol, (wgl + 1) * chunk);
+  for (long colid = wgl * chunk + tl; colid < cend; colid += PW_LANES) {
+    const int pos = (int)(colid % HoWo);
+    const long bh = colid / HoWo;
+    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+    const int xo = pos % g.Wo, yo = pos / g.Wo;
+    int noff[9];
+#pragma unroll
+    for (int yy = 0; yy < 3; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 3; ++xx) {
+        const int yi = yo * g.sh - 1 + yy, xi = xo * g.sw - 1 + xx;
+        noff[yy * 3 + xx] = (yi >= 0 && yi < g.Hh && xi >= 0 && xi < g.Ww) ? yi * g.Ww + xi : -1;
+      }
+    const op_t* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c0;
+    const op_t* db = dc + (bh * (Lo + 1) + pos) * HD + c0;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 dP = zero, dC = ld4bf(db), dN = g.T > 1 ? ld4bf(db + (long)HoWo * HD) : zero;   // dc of output frames ti-1, ti, ti+1
+    for (int ti = 0; ti < g.T; ++ti) {
+      const op_t* pb = xb + (long)ti * plane * g.ld;
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        if (noff[n] < 0) continue;
+        const f32x4 xv = ld4bf(pb + (long)noff[n] * g.ld);
+        acc[n] += dN * xv;                 // tap a = 0: frame ti is the first input frame of output ti + 1
+        acc[9 + n] += dC * xv;             // a = 1
+        acc[18 + n] += dP * xv;            // a = 2
+      }
+      dP = dC; dC = dN;
+      dN = ti + 2 < g.T ? ld4bf(db + (long)(ti + 2) * HoWo * HD) : zero;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < PW_LANES; ++k) {      // the 8 token lanes add their sums one after the other: a fixed order
+    if (tl == k) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[t][c0 + e] += acc[t][e];
+    }
+    __syncthreads();
+  }
+  float* mine = part + (long)blockIdx.x * (27 * HD);
+  for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) mine[i] = red[i / HD][i % HD];
+}
+
 // dw[c][tap] += sum over workgroups of part[wg][tap][c] in a fixed order (deterministic): 16 outputs x 16 slices of
 // the workgroup list per block, slices combined through LDS
 constexpr int PW_MAX_WG = 2048;
@@ -1047,8 +1109,15 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
   if (wb > PW_MAX_WG) wb = PW_MAX_WG;
   if (wb < 1) wb = 1;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const op_t*)dc_scratch,
-                     (const op_t*)qkv, g, (float*)workspace);
+  // measured per block of MViTv2-S (tools/probe/mvit_pool_times.py): the t-sliding form wins on the small planes with spatial
+  // stride 1 (14 x 14: 271 -> 227 us, 7 x 7: 176 -> 139), loses on 56 x 56 / 28 x 28 and on strided pooling (fewer loads in
+  // flight per lane than the 27-at-once form, which hides the longer misses of the big planes better)
+  if (st == 1 && sh == 1 && sw == 1 && Hh * Ww <= 196)
+    hipLaunchKernelGGL(pool_wgrad_t_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const op_t*)dc_scratch,
+                       (const op_t*)qkv, g, (float*)workspace);
+  else
+    hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const op_t*)dc_scratch,
+                       (const op_t*)qkv, g, (float*)workspace);
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_wgrad_reduce_kernel, dim3(27 * HD / 16), dim3(256), 0, s, (const float*)workspace,
                      (int)wb, dw);
