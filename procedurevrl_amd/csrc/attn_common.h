@@ -116,3 +116,20 @@ __device__ __forceinline__ unsigned pack_opx2(float a, float b) {
   x.v[0] = (op_t)a; x.v[1] = (op_t)b;
   return x.u;
 }
+
+// ---- head_dim 96 (MViTv2): 32-row tiles of 6 sixteen-column blocks, shared by attn_pool.hip and mvit_rel.hip
+constexpr int PB_D = 96, NCB = 6;
+// blocked [rows][96] bf16 tile: contiguous [4 rows][16 cols] 128-byte blocks, pairwise block swizzle
+__device__ __forceinline__ int pb_off(int row, int col) {
+  const int rb = row >> 2;
+  return (rb * NCB + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
+}
+__device__ __forceinline__ opx8 pb_row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const opx8*>(tile + pb_off(row, chunk * 8));
+}
+// transposed fragment over the tile's 32 rows: lane (i, q) receives column 16*ct + i at rows {4q..4q+3, 16+4q..16+4q+3}
+__device__ __forceinline__ opx8 pb_tr_frag(const char* tile, int ct, int lane) {
+  const int q = lane >> 4, i = lane & 15;
+  const int rb0 = q, rb1 = q + 4;
+  return tr_frag8(tile, (rb0 * NCB + (ct ^ (rb0 & 1))) * 128 + i * 8, (rb1 * NCB + (ct ^ (rb1 & 1))) * 128 + i * 8);
+}

@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int D = 96, NCB = 6;          // head_dim, 16-column blocks per row
+constexpr int D = PB_D;                 // head_dim
 constexpr int KT = 32;                  // keys (or queries) per LDS tile
 constexpr int TILE_BYTES = KT * D * 2;  // 6 KiB
 constexpr int JMAX = 40;                // kh + kw + kt <= 36 (14 + 14 + 8); the d-rel MFMA covers 48 columns
@@ -35,21 +35,6 @@ struct PA {
   int B, H, Lq, Lk, kt, kh, kw, J;
   float scale;
 };
-
-// blocked [rows][96] bf16 tile: contiguous [4 rows][16 cols] 128-byte blocks, pairwise block swizzle
-__device__ __forceinline__ int pb_off(int row, int col) {
-  const int rb = row >> 2;
-  return (rb * NCB + ((col >> 4) ^ (rb & 1))) * 128 + (row & 3) * 32 + (col & 15) * 2;
-}
-__device__ __forceinline__ opx8 pb_row_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const opx8*>(tile + pb_off(row, chunk * 8));
-}
-// transposed fragment over the tile's 32 rows: lane (i, q) receives column 16*ct + i at rows {4q..4q+3, 16+4q..16+4q+3}
-__device__ __forceinline__ opx8 pb_tr_frag(const char* tile, int ct, int lane) {
-  const int q = lane >> 4, i = lane & 15;
-  const int rb0 = q, rb1 = q + 4;
-  return tr_frag8(tile, (rb0 * NCB + (ct ^ (rb0 & 1))) * 128 + i * 8, (rb1 * NCB + (ct ^ (rb1 & 1))) * 128 + i * 8);
-}
 
 // cooperative tile load: 32 rows x 12 chunks of 16 B = 384 chunks, rows >= nrows zero
 struct TileRegs { u32x4 v[2]; };

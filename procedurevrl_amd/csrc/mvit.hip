@@ -820,139 +820,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------- relative position
-struct RelGeom {
-  int BH, qt, qh, qw, kt, kh, kw;   // J = kh + kw + kt columns: [0,kh) height, [kh,kh+kw) width, then time
-};
-
-// rel[bh][q][j] = sum_c Q[bh][q][c] * R_j(q)[c],  R_j(q) = rel_pos_h[idx_h[qh(q)][j]] etc. (attention.py:97-115,139-151)
-__global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q, RelGeom g, const float* __restrict__ Rh,
-                                                      const float* __restrict__ Rw, const float* __restrict__ Rt,
-                                                      const int* __restrict__ ih, const int* __restrict__ iw,
-                                                      const int* __restrict__ it, float* __restrict__ rel) {
-  const int J = g.kh + g.kw + g.kt;
-  const int Lq = g.qt * g.qh * g.qw;
-  const long total = (long)g.BH * Lq * J;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int j = (int)(idx % J);
-    const long bq = idx / J;
-    const int q = (int)(bq % Lq);
-    const long bh = bq / Lq;
-    const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
-    const float* R;
-    if (j < g.kh) R = Rh + (long)ih[y * g.kh + j] * HD;
-    else if (j < g.kh + g.kw) R = Rw + (long)iw[x * g.kw + (j - g.kh)] * HD;
-    else R = Rt + (long)it[t * g.kt + (j - g.kh - g.kw)] * HD;
-    const op_t* qp = Q + (bh * (Lq + 1) + q) * HD;
-    float a = 0.f;
-#pragma unroll 4
-    for (int c8 = 0; c8 < HD / 8; ++c8) {                       // 16-byte loads: 8 bf16 of q, 2 x 4 floats of R
-      const opx8 qv = *reinterpret_cast<const opx8*>(qp + c8 * 8);
-      const f32x4 r0 = *reinterpret_cast<const f32x4*>(R + c8 * 8), r1 = *reinterpret_cast<const f32x4*>(R + c8 * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a = fmaf((float)qv[e], r0[e], fmaf((float)qv[4 + e], r1[e], a));
-    }
-    rel[idx] = a;
-  }
-}
-
-// dQ[bh][q][c] += sum_j drel[bh][q][j] * R_j(q)[c]     (dQ is the bf16 gradient written by the attention backward)
-// one thread per (q, 4 channels)
-__global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
-                                                        const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                        const float* __restrict__ Rt, const int* __restrict__ ih,
-                                                        const int* __restrict__ iw, const int* __restrict__ it,
-                                                        op_t* __restrict__ dQ) {
-  const int J = g.kh + g.kw + g.kt;
-  const int Lq = g.qt * g.qh * g.qw;
-  const long total = (long)g.BH * Lq * (HD / 4);
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % (HD / 4)) * 4;
-    const long bq = idx / (HD / 4);
-    const int q = (int)(bq % Lq);
-    const long bh = bq / Lq;
-    const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
-    const float* d = drel + bq * J;
-    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < g.kh; ++j) a += d[j] * *reinterpret_cast<const f32x4*>(Rh + (long)ih[y * g.kh + j] * HD + c);
-    for (int j = 0; j < g.kw; ++j) a += d[g.kh + j] * *reinterpret_cast<const f32x4*>(Rw + (long)iw[x * g.kw + j] * HD + c);
-    for (int j = 0; j < g.kt; ++j) a += d[g.kh + g.kw + j] * *reinterpret_cast<const f32x4*>(Rt + (long)it[t * g.kt + j] * HD + c);
-    opx4* p = reinterpret_cast<opx4*>(dQ + (bh * (Lq + 1) + q) * HD + c);
-    opx4 v = *p;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (op_t)((float)v[e] + a[e]);
-    *p = v;
-  }
-}
-
-// dR_axis[idx[coord][j]][c] += sum over all (bh, q with that axis coordinate) drel[bh][q][off + j] * Q[bh][q][c]
-// grid (q_n, chunks of the (bh, other) range); block = 96 channels x 2 slices; a thread keeps all k_n <= 16 sums of its channel.
-constexpr int REL_KMAX = 16;
-__global__ __launch_bounds__(192) void rel_bwd_table_kernel(const float* __restrict__ drel, const op_t* __restrict__ Q,
-                                                            RelGeom g, int axis, float* __restrict__ part) {
-  __shared__ float red[REL_KMAX][HD];
-  const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
-  const int coord = blockIdx.x;
-  const int J = g.kh + g.kw + g.kt;
-  const int Lq = g.qt * g.qh * g.qw;
-  int n_other, off, kn;
-  if (axis == 0) { n_other = g.qt * g.qw; off = 0; kn = g.kh; }
-  else if (axis == 1) { n_other = g.qt * g.qh; off = g.kh; kn = g.kw; }
-  else { n_other = g.qh * g.qw; off = g.kh + g.kw; kn = g.kt; }
-  const long n = (long)g.BH * n_other;
-  const long per = (n + gridDim.y - 1) / gridDim.y;
-  const long i0 = (long)blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
-  float a[REL_KMAX];
-#pragma unroll
-  for (int j = 0; j < REL_KMAX; ++j) a[j] = 0.f;
-  for (long i = i0 + sl; i < i1; i += 2) {
-    const int o = (int)(i % n_other);
-    const long bh = i / n_other;
-    int q;
-    if (axis == 0) { const int t = o / g.qw, x = o % g.qw; q = (t * g.qh + coord) * g.qw + x; }
-    else if (axis == 1) { q = o * g.qw + coord; }                 // o = t*qh + y
-    else { q = coord * g.qh * g.qw + o; }
-    const float qv = (float)Q[(bh * (Lq + 1) + q) * HD + c];
-    const float* d = drel + (bh * Lq + q) * J + off;
-#pragma unroll
-    for (int j = 0; j < REL_KMAX; ++j)
-      if (j < kn) a[j] = fmaf(d[j], qv, a[j]);
-  }
-  if (sl == 1) {
-#pragma unroll
-    for (int j = 0; j < REL_KMAX; ++j) red[j][c] = a[j];
-  }
-  __syncthreads();
-  if (sl == 0) {                                   // part[chunk][coord][j][c]
-    float* mine = part + ((long)blockIdx.y * gridDim.x + coord) * kn * HD;
-#pragma unroll
-    for (int j = 0; j < REL_KMAX; ++j)
-      if (j < kn) mine[j * HD + c] = a[j] + red[j][c];
-  }
-}
-
-// p2[coord][j][c] = sum over chunks of part[chunk][coord][j][c], in chunk order
-__global__ __launch_bounds__(256) void rel_table_reduce1_kernel(const float* __restrict__ part, int nchunks, long n,
-                                                                float* __restrict__ p2) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f;
-  int b = 0;
-  for (; b + 2 <= nchunks; b += 2) { a0 += part[(long)b * n + i]; a1 += part[(long)(b + 1) * n + i]; }
-  if (b < nchunks) a0 += part[(long)b * n + i];
-  p2[i] = a0 + a1;
-}
-// dR[r][c] += sum of p2[coord][j][c] over the (coord, j) whose table index is r, in (coord, j) order (deterministic; the
-// same-address fp32 atomics this replaces cost ~100 us per call).  One block of 96 threads per table row.
-__global__ __launch_bounds__(HD) void rel_table_reduce2_kernel(const float* __restrict__ p2, const int* __restrict__ idx,
-                                                               int npairs, float* __restrict__ dR) {
-  const int r = blockIdx.x, c = threadIdx.x;
-  float a = 0.f;
-  for (int e = 0; e < npairs; ++e)
-    if (idx[e] == r) a += p2[(long)e * HD + c];
-  dR[(long)r * HD + c] += a;
-}
-
 // ------------------------------------------------------------------------------------------------- misc
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                      long ldo, long R, int C, float beta) {
@@ -1157,76 +1024,6 @@ extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* d
   const long total = ((long)B * T * H * W + B) * (C >> 2);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx,
                      (const unsigned char*)argmax);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
-}
-
-static int rel_geom(RelGeom& g, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw) {
-  if (BH <= 0 || qt <= 0 || qh <= 0 || qw <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return PVRL_EINVAL;
-  g.BH = (int)BH; g.qt = (int)qt; g.qh = (int)qh; g.qw = (int)qw; g.kt = (int)kt; g.kh = (int)kh; g.kw = (int)kw;
-  return PVRL_OK;
-}
-
-extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
-                                 int64_t kw, const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h,
-                                 const int32_t* idx_w, const int32_t* idx_t, float* rel, void* stream) {
-  RelGeom g;
-  if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !rel || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
-  const long total = (long)BH * qt * qh * qw * (kh + kw + kt);
-  hipLaunchKernelGGL(rel_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const op_t*)Q, g, Rh, Rw,
-                     Rt, idx_h, idx_w, idx_t, rel);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
-}
-
-namespace {
-unsigned rel_chunks(int64_t BH, int64_t qn, int64_t n_other) {     // ~2048 blocks per axis, at least 64 (bh, other) pairs each
-  int64_t c = 2048 / qn, m = (BH * n_other + 63) / 64;
-  if (c > m) c = m;
-  return (unsigned)(c < 1 ? 1 : c);
-}
-}  // namespace
-
-extern "C" int64_t pvrl_mvit_rel_bwd_workspace_bytes(int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
-                                                     int64_t kw) {
-  if (BH <= 0 || qt <= 0 || qh <= 0 || qw <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return PVRL_EINVAL;
-  const int64_t eh = (rel_chunks(BH, qh, qt * qw) + 1) * qh * kh, ew = (rel_chunks(BH, qw, qt * qh) + 1) * qw * kw,
-                et = (rel_chunks(BH, qt, qh * qw) + 1) * qt * kt;
-  return (eh + ew + et) * HD * (int64_t)sizeof(float);
-}
-
-extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh,
-                                 int64_t qw, int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw,
-                                 const float* Rt, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
-                                 int64_t nrows_h, int64_t nrows_w, int64_t nrows_t, float* dRh, float* dRw, float* dRt,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
-  RelGeom g;
-  if (!drel || !Q || !dQ || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !dRh || !dRw || !dRt || !workspace ||
-      nrows_h <= 0 || nrows_w <= 0 || nrows_t <= 0 || rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
-    return PVRL_EINVAL;
-  if (kh > REL_KMAX || kw > REL_KMAX || kt > REL_KMAX) return PVRL_EINVAL;
-  if (workspace_bytes < pvrl_mvit_rel_bwd_workspace_bytes(BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  const long total = (long)BH * qt * qh * qw * (HD / 4);
-  hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
-                     (op_t*)dQ);
-  PVRL_LAUNCH_CHECK();
-  float* w = (float*)workspace;
-  auto axis = [&](int ax, int64_t qn, int64_t kn, int64_t n_other, const int32_t* idx, int64_t nrows, float* dR) {
-    const unsigned ch = rel_chunks(BH, qn, n_other);
-    const long n = (long)qn * kn * HD;
-    float* part = w;
-    float* p2 = w + (long)ch * n;
-    w = p2 + n;
-    hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)qn, ch), dim3(192), 0, s, drel, (const op_t*)Q, g, ax, part);
-    hipLaunchKernelGGL(rel_table_reduce1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)part,
-                       (int)ch, n, p2);
-    hipLaunchKernelGGL(rel_table_reduce2_kernel, dim3((unsigned)nrows), dim3(HD), 0, s, (const float*)p2, idx,
-                       (int)(qn * kn), dR);
-  };
-  axis(0, qh, kh, qt * qw, idx_h, nrows_h, dRh);
-  axis(1, qw, kw, qt * qh, idx_w, nrows_w, dRw);
-  axis(2, qt, kt, qh * qw, idx_t, nrows_t, dRt);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

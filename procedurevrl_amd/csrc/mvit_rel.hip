@@ -1,0 +1,348 @@
+// Decomposed relative-position terms of MViTv2's pooling attention (reference: cal_rel_pos_spatial / cal_rel_pos_temporal,
+// lib/models/slowfast_mvit/attention.py:67-159):
+//     rel[bh][q][j] = Q[bh][q] . R_j(q),   R_j(q) = rel_pos_h[idx_h[y(q)][j]]  (j <  kh)
+//                                                   rel_pos_w[idx_w[x(q)][j-kh]]  (j <  kh+kw)
+//                                                   rel_pos_t[idx_t[t(q)][j-kh-kw]]
+// and their gradients.  Along one axis every query with the same coordinate v multiplies the SAME k_n x 96 matrix
+// R_a(v), so the work is cut into (axis, v, run of queries) units and each unit is a small MFMA GEMM:
+//   forward   D[j][query]  = R_a(v)[j][:] . Q[query][:]        one lane owns one query; R_a(v) stays in registers
+//   table     D[j][c]     += drel[query][j] * Q[query][c]      32 queries per MFMA step, Q^T through ds_read_b64_tr_b16
+// The fp32 tables (forward) and the fp32 d rel (table gradient) enter the MFMA as hi + lo 16-bit pairs, so the products
+// keep ~16 mantissa bits (the bf16 q operand is exact): results agree with fp32 FMA arithmetic to ~1e-6.
+// dQ += d rel . R stays a VALU kernel: all three axes must be summed in fp32 before the single rounding into the
+// 16-bit dQ, and the 16 queries of an MFMA tile never share R along all three axes.
+#include "attn_common.h"
+#include "../../include/pvrl.h"
+
+namespace {
+
+constexpr int HD = PB_D;          // 96
+constexpr int REL_KMAX = 16;      // k_h, k_w, k_t <= 16: one MFMA row block
+
+inline unsigned grid_for(long total, int per_block = 256) {
+  long b = (total + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 65535L * 16) b = 65535L * 16;
+  return (unsigned)b;
+}
+
+struct RelGeom {
+  int BH, qt, qh, qw, kt, kh, kw;   // J = kh + kw + kt columns: [0,kh) height, [kh,kh+kw) width, then time
+};
+
+// work list: axis a owns units [first[a], first[a+1]); unit -> (v = coordinate, ck = chunk of `per` queries among the
+// BH * Lq / qn[a] queries that have coordinate v on that axis)
+struct RelAxes {
+  const float* R[3];
+  const int* idx[3];
+  float* part[3];          // table gradient: [chunk][v][j][96] partial sums per axis
+  int qn[3], kn[3], off[3], chunks[3], first[4];
+  int per;
+};
+
+__device__ __forceinline__ int rel_unit(const RelAxes& ax, int u, int& v, int& ck) {
+  const int a = u >= ax.first[2] ? 2 : (u >= ax.first[1] ? 1 : 0);
+  u -= ax.first[a];
+  v = u / ax.chunks[a];
+  ck = u - v * ax.chunks[a];
+  return a;
+}
+// the o-th query (o in [0, Lq / qn)) with coordinate v on axis a
+__device__ __forceinline__ int rel_query(const RelGeom& g, int a, int v, int o) {
+  if (a == 0) { const int t = o / g.qw, x = o - t * g.qw; return (t * g.qh + v) * g.qw + x; }
+  if (a == 1) return o * g.qw + v;                          // o = t*qh + y
+  return v * g.qh * g.qw + o;
+}
+__device__ __forceinline__ void split8(const f32x4 r0, const f32x4 r1, opx8& hi, opx8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (op_t)r0[e]; lo[e] = (op_t)(r0[e] - (float)hi[e]);
+    hi[4 + e] = (op_t)r1[e]; lo[4 + e] = (op_t)(r1[e] - (float)hi[4 + e]);
+  }
+}
+__device__ __forceinline__ void wave_lds_sync() {   // LDS traffic of one wave is executed in order: only the compiler needs the fence
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q, RelGeom g, RelAxes ax,
+                                                      float* __restrict__ rel) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q4 = lane >> 4;
+  int v, ck;
+  const int a = rel_unit(ax, blockIdx.x, v, ck);
+  const int kn = ax.kn[a];
+  const int J = g.kh + g.kw + g.kt, Lq = g.qt * g.qh * g.qw;
+  const int n_other = Lq / ax.qn[a];
+  const int n = g.BH * n_other;
+  opx8 ah[3], al[3];                               // R_a(v): row j = i, channels 32 ks + 8 q4 .. + 8
+  {
+    const bool jr = i < kn;
+    const float* row = ax.R[a] + (long)(jr ? ax.idx[a][v * kn + i] : 0) * HD + 8 * q4;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
+      if (jr) { r0 = *reinterpret_cast<const f32x4*>(row + 32 * ks); r1 = *reinterpret_cast<const f32x4*>(row + 32 * ks + 4); }
+      split8(r0, r1, ah[ks], al[ks]);
+    }
+  }
+  const int i0 = ck * ax.per, i1 = min(n, i0 + ax.per);
+  const int off = ax.off[a];
+  for (int base = i0 + wave * 16; base < i1; base += 64) {
+    const int item = base + i;
+    const bool valid = item < i1;
+    const int it2 = valid ? item : i1 - 1;
+    const int bh = it2 / n_other, o = it2 - bh * n_other;
+    const int q = rel_query(g, a, v, o);
+    const op_t* qrow = Q + ((long)bh * (Lq + 1) + q) * HD + 8 * q4;
+    opx8 qf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const opx8*>(qrow + 32 * ks);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      acc = MFMA_16x16x32(ah[ks], qf[ks], acc, 0, 0, 0);
+      acc = MFMA_16x16x32(al[ks], qf[ks], acc, 0, 0, 0);
+    }
+    if (valid) {                                   // acc[r] = rel[query][off + 4 q4 + r]
+      float* dst = rel + ((long)bh * Lq + q) * J + off + 4 * q4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q4 + r < kn) dst[r] = acc[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- dQ
+// dQ[bh][q][c] += sum_j drel[bh][q][j] * R_j(q)[c]     (dQ is the 16-bit gradient written by the attention backward)
+// one thread per (q, 4 channels)
+__global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
+                                                        const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                        const float* __restrict__ Rt, const int* __restrict__ ih,
+                                                        const int* __restrict__ iw, const int* __restrict__ it,
+                                                        op_t* __restrict__ dQ) {
+  const int J = g.kh + g.kw + g.kt;
+  const int Lq = g.qt * g.qh * g.qw;
+  const long total = (long)g.BH * Lq * (HD / 4);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % (HD / 4)) * 4;
+    const long bq = idx / (HD / 4);
+    const int q = (int)(bq % Lq);
+    const long bh = bq / Lq;
+    const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
+    const float* d = drel + bq * J;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < g.kh; ++j) a += d[j] * *reinterpret_cast<const f32x4*>(Rh + (long)ih[y * g.kh + j] * HD + c);
+    for (int j = 0; j < g.kw; ++j) a += d[g.kh + j] * *reinterpret_cast<const f32x4*>(Rw + (long)iw[x * g.kw + j] * HD + c);
+    for (int j = 0; j < g.kt; ++j) a += d[g.kh + g.kw + j] * *reinterpret_cast<const f32x4*>(Rt + (long)it[t * g.kt + j] * HD + c);
+    opx4* p = reinterpret_cast<opx4*>(dQ + (bh * (Lq + 1) + q) * HD + c);
+    opx4 v = *p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (op_t)((float)v[e] + a[e]);
+    *p = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- table gradient
+// part_a[ck][v][j][c] = sum over the unit's queries of drel[query][off + j] * Q[query][c].  Every wave streams its own
+// 32-query tiles (own LDS tile, wave-level synchronisation only); the four accumulators meet in LDS at the end.
+constexpr int REL_TILE_BYTES = 32 * HD * 2;       // 6 KiB
+__global__ __launch_bounds__(256) void rel_bwd_table_kernel(const float* __restrict__ drel, const op_t* __restrict__ Q,
+                                                            RelGeom g, RelAxes ax) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * REL_TILE_BYTES];      // = 4 waves x [16][96] fp32 for the final sum
+  __shared__ int rowq_s[4][32], rowd_s[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q4 = lane >> 4;
+  int v, ck;
+  const int a = rel_unit(ax, blockIdx.x, v, ck);
+  const int kn = ax.kn[a], off = ax.off[a];
+  const int J = g.kh + g.kw + g.kt, Lq = g.qt * g.qh * g.qw;
+  const int n_other = Lq / ax.qn[a];
+  const int n = g.BH * n_other;
+  const int i0 = ck * ax.per, i1 = min(n, i0 + ax.per);
+  char* tile = smem + wave * REL_TILE_BYTES;
+  f32x4 acc[6];
+#pragma unroll
+  for (int ct = 0; ct < 6; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool jr = i < kn;
+
+  for (int base = i0 + wave * 32; base < i1; base += 128) {
+    if (lane < 32) {
+      const int item = base + lane;
+      int rq = -1, rd = -1;
+      if (item < i1) {
+        const int bh = item / n_other, o = item - bh * n_other;
+        const int q = rel_query(g, a, v, o);
+        rq = bh * (Lq + 1) + q; rd = bh * Lq + q;
+      }
+      rowq_s[wave][lane] = rq; rowd_s[wave][lane] = rd;
+    }
+    wave_lds_sync();
+    u32x4 qv[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {                                   // 32 rows x 12 chunks of 16 B
+      const int c = lane + 64 * e;
+      const int row = c / 12, ch = c - row * 12;
+      const int rq = rowq_s[wave][row];
+      qv[e] = (u32x4){0u, 0u, 0u, 0u};
+      if (rq >= 0) qv[e] = *reinterpret_cast<const u32x4*>(Q + (long)rq * HD + ch * 8);
+    }
+    // A operand: d rel of the tile's queries in the k order of pb_tr_frag (rows 4q4+e | 16+4q4+e), column j = i
+    float dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = (e < 4 ? 0 : 12) + 4 * q4 + e;
+      const int rd = rowd_s[wave][row];
+      dv[e] = (jr && rd >= 0) ? drel[(long)rd * J + off + i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int c = lane + 64 * e;
+      const int row = c / 12, ch = c - row * 12;
+      *reinterpret_cast<u32x4*>(tile + pb_off(row, ch * 8)) = qv[e];
+    }
+    opx8 dh, dl;
+    split8((f32x4){dv[0], dv[1], dv[2], dv[3]}, (f32x4){dv[4], dv[5], dv[6], dv[7]}, dh, dl);
+    wave_lds_sync();
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) {
+      const opx8 b = pb_tr_frag(tile, ct, lane);
+      acc[ct] = MFMA_16x16x32(dh, b, acc[ct], 0, 0, 0);
+      acc[ct] = MFMA_16x16x32(dl, b, acc[ct], 0, 0, 0);
+    }
+    wave_lds_sync();                                                 // the next tile overwrites what was just read
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                       // [wave][16][96]; acc[ct][r] = D[j = 4 q4 + r][c = 16 ct + i]
+#pragma unroll
+  for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * q4 + r) * HD + 16 * ct + i] = acc[ct][r];
+  __syncthreads();
+  float* mine = ax.part[a] + ((long)ck * ax.qn[a] + v) * kn * HD;
+  for (int e = tid; e < kn * HD; e += 256)
+    mine[e] = (red[e] + red[16 * HD + e]) + (red[32 * HD + e] + red[48 * HD + e]);
+}
+
+// dR_a[r][c] += sum over the (v, j) pairs whose table index is r, in (v, j) order, of the sum over chunks of part_a
+// (deterministic).  One block per table row of the three tables; 4 chunk slices x 96 channels.
+struct RelReduce {
+  const float* part[3]; const int* idx[3]; float* dR[3];
+  int npairs[3], chunks[3], first[4];          // first: block -> (axis, table row)
+};
+__global__ __launch_bounds__(4 * HD) void rel_table_reduce_kernel(RelReduce rr) {
+  __shared__ float red[4][HD];
+  const int b = blockIdx.x;
+  const int a = b >= rr.first[2] ? 2 : (b >= rr.first[1] ? 1 : 0);
+  const int r = b - rr.first[a];
+  const int c = threadIdx.x % HD, sl = threadIdx.x / HD;
+  const int np = rr.npairs[a], nch = rr.chunks[a];
+  const float* part = rr.part[a];
+  const int* idx = rr.idx[a];
+  float s = 0.f;
+  for (int e = 0; e < np; ++e) {
+    if (idx[e] != r) continue;
+    float s0 = 0.f, s1 = 0.f;
+    int ch = sl;
+    for (; ch + 4 < nch; ch += 8) { s0 += part[((long)ch * np + e) * HD + c]; s1 += part[((long)(ch + 4) * np + e) * HD + c]; }
+    if (ch < nch) s0 += part[((long)ch * np + e) * HD + c];
+    s += s0 + s1;
+  }
+  red[sl][c] = s;
+  __syncthreads();
+  if (sl == 0) rr.dR[a][(long)r * HD + c] += (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+int rel_geom(RelGeom& g, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw) {
+  if (BH <= 0 || qt <= 0 || qh <= 0 || qw <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return PVRL_EINVAL;
+  if (kh > REL_KMAX || kw > REL_KMAX || kt > REL_KMAX) return PVRL_EINVAL;
+  if (BH * qt * qh * qw >= (1LL << 31) / HD) return PVRL_EINVAL;          // row indices are 32-bit in the kernels
+  g.BH = (int)BH; g.qt = (int)qt; g.qh = (int)qh; g.qw = (int)qw; g.kt = (int)kt; g.kh = (int)kh; g.kw = (int)kw;
+  return PVRL_OK;
+}
+
+// units of `per` queries: ~1500 workgroups over the three axes, at least 512 queries each (the R_a(v) fragments and the
+// final cross-wave sum are per-unit overheads), `per` a multiple of 128 (4 waves x 32-query tiles)
+void rel_axes(RelAxes& ax, const RelGeom& g) {
+  const long NQ = (long)g.BH * g.qt * g.qh * g.qw;
+  long per = (3 * NQ / 1536 + 127) / 128 * 128;
+  if (per < 512) per = 512;
+  if (per > 8192) per = 8192;
+  ax.per = (int)per;
+  const int qn[3] = {g.qh, g.qw, g.qt}, kn[3] = {g.kh, g.kw, g.kt};
+  int first = 0, off = 0;
+  for (int a = 0; a < 3; ++a) {
+    ax.qn[a] = qn[a]; ax.kn[a] = kn[a]; ax.off[a] = off;
+    off += kn[a];
+    ax.chunks[a] = cdiv(NQ / qn[a], per);
+    ax.first[a] = first;
+    first += qn[a] * ax.chunks[a];
+  }
+  ax.first[3] = first;
+}
+
+}  // namespace
+
+extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
+                                 int64_t kw, const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h,
+                                 const int32_t* idx_w, const int32_t* idx_t, float* rel, void* stream) {
+  RelGeom g;
+  if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !rel || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
+  RelAxes ax = {};
+  rel_axes(ax, g);
+  ax.R[0] = Rh; ax.R[1] = Rw; ax.R[2] = Rt;
+  ax.idx[0] = idx_h; ax.idx[1] = idx_w; ax.idx[2] = idx_t;
+  hipLaunchKernelGGL(rel_fwd_kernel, dim3((unsigned)ax.first[3]), dim3(256), 0, (hipStream_t)stream, (const op_t*)Q, g, ax, rel);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int64_t pvrl_mvit_rel_bwd_workspace_bytes(int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
+                                                     int64_t kw) {
+  RelGeom g;
+  if (rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
+  RelAxes ax = {};
+  rel_axes(ax, g);
+  int64_t e = 0;
+  for (int a = 0; a < 3; ++a) e += (int64_t)ax.chunks[a] * ax.qn[a] * ax.kn[a];
+  return e * HD * (int64_t)sizeof(float);
+}
+
+extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh,
+                                 int64_t qw, int64_t kt, int64_t kh, int64_t kw, const float* Rh, const float* Rw,
+                                 const float* Rt, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
+                                 int64_t nrows_h, int64_t nrows_w, int64_t nrows_t, float* dRh, float* dRw, float* dRt,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  RelGeom g;
+  if (!drel || !Q || !dQ || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !dRh || !dRw || !dRt || !workspace ||
+      nrows_h <= 0 || nrows_w <= 0 || nrows_t <= 0 || rel_geom(g, BH, qt, qh, qw, kt, kh, kw))
+    return PVRL_EINVAL;
+  if (workspace_bytes < pvrl_mvit_rel_bwd_workspace_bytes(BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)BH * qt * qh * qw * (HD / 4);
+  hipLaunchKernelGGL(rel_bwd_q_kernel, dim3(grid_for(total)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
+                     (op_t*)dQ);
+  PVRL_LAUNCH_CHECK();
+  RelAxes ax = {};
+  rel_axes(ax, g);
+  ax.idx[0] = idx_h; ax.idx[1] = idx_w; ax.idx[2] = idx_t;
+  RelReduce rr = {};
+  float* w = (float*)workspace;
+  const int64_t nrows[3] = {nrows_h, nrows_w, nrows_t};
+  float* dR[3] = {dRh, dRw, dRt};
+  int first = 0;
+  for (int a = 0; a < 3; ++a) {
+    ax.part[a] = w;
+    w += (long)ax.chunks[a] * ax.qn[a] * ax.kn[a] * HD;
+    rr.part[a] = ax.part[a]; rr.idx[a] = ax.idx[a]; rr.dR[a] = dR[a];
+    rr.npairs[a] = ax.qn[a] * ax.kn[a]; rr.chunks[a] = ax.chunks[a];
+    rr.first[a] = first;
+    first += (int)nrows[a];
+  }
+  rr.first[3] = first;
+  hipLaunchKernelGGL(rel_bwd_table_kernel, dim3((unsigned)ax.first[3]), dim3(256), 0, s, drel, (const op_t*)Q, g, ax);
+  PVRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rel_table_reduce_kernel, dim3((unsigned)first), dim3(4 * HD), 0, s, rr);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
