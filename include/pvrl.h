@@ -237,12 +237,18 @@ int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* dy, int64_t 
                           int64_t W, int64_t s, int64_t C, float* dx, const void* argmax, void* stream);
 
 /* Decomposed relative-position terms (attention.py:67-159): rel[bh][q][j] = Q[bh][q] . R_j(q), j over kh heights, kw
- * widths, kt times; R_j(q) = rel_pos_h[idx_h[qh(q)][j]] ... with the int32 index tables of attention.py:80-98,130-137.
- * Backward: dQ += drel . R (in place on the bf16 dQ of the attention backward), dR* ([nrows_*][96]) ACCUMULATED from
- * per-workgroup partials in the workspace (>= pvrl_mvit_rel_bwd_workspace_bytes) summed in a fixed order. */
+ * widths, kt times (each <= 16); R_j(q) = rel_pos_h[idx_h[qh(q)][j]] ... with the int32 index tables of
+ * attention.py:80-98,130-137.  The forward writes the OPERAND FORM that pvrl_mvit_attn_* consume: relp, 16-bit,
+ * [BH][Lq][2 * JP] with JP = pvrl_mvit_rel_width(kt, kh, kw) (32 or 64); columns [0, JP) hold hi and [JP, 2 JP) hold lo of
+ * the pair hi + lo = out_scale * rel[bh][q][j] (~16 mantissa bits), zeros for j >= kh + kw + kt.  The attention kernels
+ * expect out_scale = 1 / scale (the bias joins the q.k score before the scale is applied).
+ * Backward: dQ += drel . R (in place on the 16-bit dQ of the attention backward; drel is the fp32 gradient with respect to
+ * the UNSCALED rel, [BH][Lq][kh+kw+kt]), dR* ([nrows_*][96]) ACCUMULATED from per-workgroup partials in the workspace
+ * (>= pvrl_mvit_rel_bwd_workspace_bytes) summed in a fixed order. */
+int64_t pvrl_mvit_rel_width(int64_t kt, int64_t kh, int64_t kw);
 int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh, int64_t kw,
                       const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h, const int32_t* idx_w,
-                      const int32_t* idx_t, float* rel, void* stream);
+                      const int32_t* idx_t, float out_scale, void* relp, void* stream);
 int64_t pvrl_mvit_rel_bwd_workspace_bytes(int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
                                           int64_t kw);
 int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, int64_t qt, int64_t qh, int64_t qw,
@@ -253,15 +259,22 @@ int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int64_t BH, in
 
 /* Pooling attention (attention.py:404-442): softmax(scale q k^T + rel bias) v (+ q, residual pooling) for head_dim 96;
  * q [B*H][Lq+1][96], k / v [B*H][kt*kh*kw+1][96]; o / d_o token-major [B*Lq + B][ldo] with column h*96 + d.
- * lse / delta fp32 [B*H][Lq+1]; drel fp32 [B*H][Lq][kh+kw+kt].  The dK / dV kernel shares the query range out over
- * workgroups (fp32 partials in `workspace`, pvrl_mvit_attn_bwd_workspace_bytes) and reduces deterministically. */
-int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
-                       int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo, float* lse, void* stream);
+ * relp = the operand form written by pvrl_mvit_rel_fwd with out_scale = 1 / scale.  keymap = the 0/1 matrix
+ * E[key][j] (j = h(key), kh + w(key), kh + kw + t(key)) of the key geometry as MFMA tile images, a function of
+ * (kt, kh, kw) only: build it once with pvrl_mvit_attn_keymap into pvrl_mvit_attn_keymap_bytes bytes and reuse it.
+ * lse / delta fp32 [B*H][Lq+1]; drel fp32 [B*H][Lq][kh+kw+kt] (gradient w.r.t. the unscaled rel).  The dK / dV kernel
+ * shares the query range out over workgroups (fp32 partials in `workspace`, pvrl_mvit_attn_bwd_workspace_bytes) and
+ * reduces deterministically. */
+int64_t pvrl_mvit_attn_keymap_bytes(int64_t kt, int64_t kh, int64_t kw);
+int pvrl_mvit_attn_keymap(int64_t kt, int64_t kh, int64_t kw, void* keymap, void* stream);
+int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const void* relp, const void* keymap, int64_t B,
+                       int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo,
+                       float* lse, void* stream);
 int64_t pvrl_mvit_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw);
-int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
-                       int64_t kt, int64_t kh, int64_t kw, float scale, const void* o, const void* d_o, int64_t ldo,
-                       const float* lse, float* delta, void* dq, void* dk, void* dv, float* drel, void* workspace,
-                       int64_t workspace_bytes, void* stream);
+int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* relp, const void* keymap, int64_t B,
+                       int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, const void* o,
+                       const void* d_o, int64_t ldo, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                       float* drel, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
  * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */

@@ -6,10 +6,14 @@
 // through LDS, online softmax in the exp2 domain, the score tile never leaves registers.
 // MFMA operands are swapped (S^T = K Q^T, O^T = V^T P^T) so that one lane owns one query: the softmax statistics are
 // per-lane scalars, P feeds the second MFMA straight from registers, and V^T / K^T fragments come from the row-major LDS
-// tile through ds_read_b64_tr_b16.  The decomposed relative-position bias is a per-query row of J = kh + kw + kt numbers
-// (computed by pvrl_mvit_rel_fwd) indexed by the key's (t, h, w) decomposition.
-// Backward = two kernels (the contraction over queries needs the un-swapped layout): dQ (+ d rel) per query tile,
-// dK / dV per key tile.
+// tile through ds_read_b64_tr_b16.
+// The decomposed relative-position bias is part of the score MFMA: with E[key][j] the 0/1 key map (j = h(key),
+// kh + w(key), kh + kw + t(key); zero rows for the cls key and the padding) the bias is rel[q][:] . E[key][:], i.e. the
+// head dimension grows from 96 to 96 + J.  rel arrives from pvrl_mvit_rel_fwd already divided by `scale` and split into
+// a hi + lo 16-bit pair (~16 mantissa bits), so  logits = scale * (K Q^T + E rel_hi^T + E rel_lo^T)  and the per-score
+// VALU work is one max, one FMA (scale and running max folded into the exp2 argument), one exp2, one add.
+// Backward = two kernels (the contraction over queries needs the un-swapped layout): dQ (+ d rel = dS E by MFMA) per
+// query tile, dK / dV per key tile.
 #include "attn_common.h"
 #include "../../include/pvrl.h"
 
@@ -20,11 +24,13 @@ constexpr int KT = 32;                  // keys (or queries) per LDS tile
 constexpr int TILE_BYTES = KT * D * 2;  // 6 KiB
 constexpr int JMAX = 40;                // kh + kw + kt <= 36 (14 + 14 + 8); the d-rel MFMA covers 48 columns
 constexpr int MAXKEYS = 1664;           // 8*14*14 + 1 = 1569 keys, rounded
+constexpr int ET_BYTES = KT * 64 * 2;   // key-map tile [32 keys][64 j], blocked layout (bl_off): 4 KiB
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct PA {
   const op_t* q; const op_t* k; const op_t* v;   // [BH][L+1][96]
-  const float* rel;                              // [BH][Lq][J]
+  const op_t* relp;                              // [BH][Lq][hi JP | lo JP]: (rel / scale) as a 16-bit pair, zero for j >= J
+  const char* keymap;                            // [tiles of 32 keys][ET_BYTES]
   op_t* o; long ldo;                             // token-major [B*Lq + B][ldo], column h*96 + d
   float* lse;                                    // [BH][Lq+1]   (log2 domain)
   const op_t* d_o;                               // same layout as o
@@ -32,7 +38,7 @@ struct PA {
   op_t* dq; op_t* dk; op_t* dv;                  // [BH][L+1][96]
   float* drel;                                   // [BH][Lq][J]
   float* kv_part;                                // [nsplit][2][BH][Lk+1][96] fp32 partial dK / dV
-  int B, H, Lq, Lk, kt, kh, kw, J;
+  int B, H, Lq, Lk, kt, kh, kw, J, JP;
   float scale;
 };
 
@@ -59,22 +65,48 @@ __device__ __forceinline__ void tile_lstore(const TileRegs& t, char* tile, int t
     }
   }
 }
-
-// (h, kh + w, kh + kw + t) of key j packed in one word; 0xffffffff for the cls key and the padding
-__device__ __forceinline__ unsigned key_dec(const PA& p, int j) {
-  if (j >= p.Lk) return 0xffffffffu;
-  const int w = j % p.kw, h = (j / p.kw) % p.kh, t = j / (p.kw * p.kh);
-  return (unsigned)h | ((unsigned)(p.kh + w) << 8) | ((unsigned)(p.kh + p.kw + t) << 16);
-}
 __device__ __forceinline__ long tok_row(const PA& p, int b, int query) {
   return query < p.Lq ? (long)b * p.Lq + query : (long)p.B * p.Lq + b;
 }
+// the (rel / scale) operand of one query: k slots j = 32 js + 8 q4 .. + 8, hi and lo halves; zero for the cls query
+template <int NJS>
+__device__ __forceinline__ void rel_frags(const PA& p, int bh, int query, int q4, opx8 (&rh)[NJS], opx8 (&rl)[NJS]) {
+#pragma unroll
+  for (int js = 0; js < NJS; ++js) {
+    union { u32x4 u; opx8 v; } h, l;
+    h.u = l.u = (u32x4){0u, 0u, 0u, 0u};
+    if (query < p.Lq) {
+      const op_t* row = p.relp + ((long)bh * p.Lq + query) * 2 * p.JP + (4 * js + q4) * 8;
+      h.u = *reinterpret_cast<const u32x4*>(row);
+      l.u = *reinterpret_cast<const u32x4*>(row + p.JP);
+    }
+    rh[js] = h.v; rl[js] = l.v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- key map
+// tile image [32 keys][64 j] in the blocked layout: row-wise fragments (score MFMA) and transposed ones (d rel MFMA)
+__global__ __launch_bounds__(256) void pattn_keymap_kernel(int kt, int kh, int kw, int ntiles, op_t* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;        // one 16-byte chunk: (tile, key row, 8 columns)
+  if (idx >= ntiles * KT * 8) return;
+  const int tile = idx / (KT * 8), r = (idx / 8) % KT, ch = idx % 8;
+  const int key = tile * KT + r, Lk = kt * kh * kw;
+  int j0 = -1, j1 = -1, j2 = -1;
+  if (key < Lk) { j0 = (key / kw) % kh; j1 = kh + key % kw; j2 = kh + kw + key / (kw * kh); }
+  opx8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int j = ch * 8 + e;
+    v[e] = (op_t)((j == j0 || j == j1 || j == j2) ? 1.f : 0.f);
+  }
+  *reinterpret_cast<opx8*>(reinterpret_cast<char*>(out) + (long)tile * ET_BYTES + bl_off(r, ch * 8)) = v;
+}
 
 // ------------------------------------------------------------------------------------------------- forward
+constexpr int FWD_BUF = 2 * TILE_BYTES + ET_BYTES;      // [K | V | E] per buffer
+template <int NJS>
 __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][K | V]
-  __shared__ float rel_s[4][16][JMAX];
-  __shared__ unsigned kdec_s[MAXKEYS];
+  __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -82,23 +114,21 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
   const int query = blockIdx.x * 64 + wave * 16 + i;
   const int qc = query < Lq1 ? query : Lq1 - 1;
   const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
-  opx8 qf[3];
+  opx8 qf[3], rh[NJS], rl[NJS];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const opx8*>(qrow + ks * 32 + q4 * 8);
-  for (int j = tid; j < MAXKEYS; j += 256) kdec_s[j] = key_dec(p, j);
-  for (int e = lane; e < 16 * p.J; e += 64) {
-    const int qi = e / p.J, j = e - qi * p.J;
-    const int qq = blockIdx.x * 64 + wave * 16 + qi;
-    rel_s[wave][qi][j] = qq < p.Lq ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
-  }
+  rel_frags<NJS>(p, bh, query, q4, rh, rl);
   const op_t* kb = p.k + (long)bh * Lk1 * D;
   const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
   TileRegs rk, rv;
+  u32x4 re;
   tile_gload(rk, kb, D, 0, Lk1, tid);
   tile_gload(rv, vb, D, 0, Lk1, tid);
+  re = *reinterpret_cast<const u32x4*>(p.keymap + tid * 16);
   tile_lstore(rk, smem, tid);
   tile_lstore(rv, smem + TILE_BYTES, tid);
+  *reinterpret_cast<u32x4*>(smem + 2 * TILE_BYTES + tid * 16) = re;
   __syncthreads();
 
   const float c = p.scale * LOG2E;
@@ -107,16 +137,18 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
   f32x4 oacc[6];
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* relq = rel_s[wave][i];
 
   for (int t = 0; t < ntiles; ++t) {
-    const char* Kb = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* Kb = smem + (t & 1) * FWD_BUF;
     const char* Vb = Kb + TILE_BYTES;
-    if (t + 1 < ntiles) {
+    const char* Eb = Vb + TILE_BYTES;
+    const bool more = t + 1 < ntiles;
+    if (more) {
       tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
       tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+      re = *reinterpret_cast<const u32x4*>(p.keymap + (long)(t + 1) * ET_BYTES + tid * 16);
     }
-    float val[8];
+    float val[8];                                      // raw scores (K Q^T + E rel^T): logits / scale
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -124,12 +156,19 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
       for (int ks = 0; ks < 3; ++ks)
         s = MFMA_16x16x32(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * KT + u * 16 + 4 * q4 + r;
-        float x = s[r] * c;
-        const unsigned kd = kdec_s[key < MAXKEYS ? key : MAXKEYS - 1];
-        if (qpatch && kd != 0xffffffffu) x += relq[kd & 255] + relq[(kd >> 8) & 255] + relq[(kd >> 16) & 255];
-        val[u * 4 + r] = key < Lk1 ? x : -INFINITY;
+      for (int js = 0; js < NJS; ++js) {
+        const opx8 ef = bl_row_frag(Eb, u * 16 + i, js * 4 + q4);
+        s = MFMA_16x16x32(ef, rh[js], s, 0, 0, 0);
+        s = MFMA_16x16x32(ef, rl[js], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) val[u * 4 + r] = s[r];
+    }
+    if (!more) {                                       // only the last tile holds padding keys
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = t * KT + (e >> 2) * 16 + 4 * q4 + (e & 3);
+        if (key >= Lk1) val[e] = -INFINITY;
       }
     }
     float mx = val[0];
@@ -137,26 +176,29 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
     for (int e = 1; e < 8; ++e) mx = fmaxf(mx, val[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
+    const float mn = fmaxf(m, mx * c);
     const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    const bool grew = mn > m;
     m = mn;
     float ps = 0.f;
     float pr[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] = __builtin_amdgcn_exp2f(val[e] - mn); ps += pr[e]; }
+    for (int e = 0; e < 8; ++e) { pr[e] = __builtin_amdgcn_exp2f(fmaf(val[e], c, -mn)); ps += pr[e]; }
     l = l * alpha + ps;
     union { unsigned u[4]; opx8 v; } pf;
 #pragma unroll
     for (int e = 0; e < 4; ++e) pf.u[e] = pack_opx2(pr[2 * e], pr[2 * e + 1]);
+    if (__builtin_amdgcn_ballot_w64(grew)) {           // no lane's running max moved: alpha == 1 everywhere
 #pragma unroll
-    for (int dt = 0; dt < 6; ++dt) {
-      oacc[dt] *= alpha;
-      oacc[dt] = MFMA_16x16x32(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
+      for (int dt = 0; dt < 6; ++dt) oacc[dt] *= alpha;
     }
-    if (t + 1 < ntiles) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) oacc[dt] = MFMA_16x16x32(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
+    if (more) {
+      char* nb = smem + ((t + 1) & 1) * FWD_BUF;
       tile_lstore(rk, nb, tid);
       tile_lstore(rv, nb + TILE_BYTES, tid);
+      *reinterpret_cast<u32x4*>(nb + 2 * TILE_BYTES + tid * 16) = re;
     }
     __syncthreads();
   }
@@ -179,12 +221,10 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
 }
 
 // ------------------------------------------------------------------------------------------------- backward: dQ, d rel
+template <int NJS>
 __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-  __shared__ float rel_s[4][16][JMAX];
-  // E^T tile: [48 rel columns][32 keys] 0/1 indicators (bf16) of the key tile, double buffered: d rel = dS . E by MFMA
-  __shared__ __attribute__((aligned(16))) op_t et_s[2][48][KT];
-  __shared__ unsigned kdec_s[MAXKEYS];
+  constexpr int NJT = NJS == 1 ? 2 : 3;                 // 16-column blocks of d rel (J <= 32 / J <= 40)
+  __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   const bool qpatch = query < p.Lq;
   const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
   const long orow = tok_row(p, b, qc) * p.ldo + h * D;
-  opx8 qf[3], df[3];
+  opx8 qf[3], df[3], rh[NJS], rl[NJS];
   float dl = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
@@ -206,51 +246,40 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   }
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
+  rel_frags<NJS>(p, bh, query, q4, rh, rl);
   const float lse2 = p.lse[(long)bh * Lq1 + qc];
   if (query < Lq1 && q4 == 0) p.delta[(long)bh * Lq1 + query] = dl;
-  for (int j = tid; j < MAXKEYS; j += 256) kdec_s[j] = key_dec(p, j);
-  for (int e = lane; e < 16 * JMAX; e += 64) {
-    const int qi = e / JMAX, j = e - qi * JMAX;
-    const int qq = blockIdx.x * 64 + wave * 16 + qi;
-    rel_s[wave][qi][j] = (qq < p.Lq && j < p.J) ? p.rel[((long)bh * p.Lq + qq) * p.J + j] * LOG2E : 0.f;
-  }
   const op_t* kb = p.k + (long)bh * Lk1 * D;
   const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
   TileRegs rk, rv;
+  u32x4 re;
   tile_gload(rk, kb, D, 0, Lk1, tid);
   tile_gload(rv, vb, D, 0, Lk1, tid);
+  re = *reinterpret_cast<const u32x4*>(p.keymap + tid * 16);
   tile_lstore(rk, smem, tid);
   tile_lstore(rv, smem + TILE_BYTES, tid);
-  __syncthreads();          // kdec_s complete
-  auto build_et = [&](int t) {
-    for (int e = tid; e < 48 * KT; e += 256) {
-      const int j = e / KT, kk = e - j * KT;
-      const int key = t * KT + kk;
-      const unsigned kd = key < MAXKEYS ? kdec_s[key] : 0xffffffffu;
-      const bool hit = kd != 0xffffffffu && (j == (int)(kd & 255) || j == (int)((kd >> 8) & 255) || j == (int)((kd >> 16) & 255));
-      et_s[t & 1][j][kk] = (op_t)(hit ? 1.f : 0.f);
-    }
-  };
-  const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
-  if (qpatch_any) build_et(0);
+  *reinterpret_cast<u32x4*>(smem + 2 * TILE_BYTES + tid * 16) = re;
   __syncthreads();
+  const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
 
   const float c = p.scale * LOG2E;
   f32x4 dq[6];
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* relq = rel_s[wave][i];
-  f32x4 dracc[3];
+  f32x4 dracc[NJT];
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) dracc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int jt = 0; jt < NJT; ++jt) dracc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < ntiles; ++t) {
-    const char* Kb = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* Kb = smem + (t & 1) * FWD_BUF;
     const char* Vb = Kb + TILE_BYTES;
-    if (t + 1 < ntiles) {
+    const char* Eb = Vb + TILE_BYTES;
+    const bool more = t + 1 < ntiles;
+    if (more) {
       tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
       tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+      re = *reinterpret_cast<const u32x4*>(p.keymap + (long)(t + 1) * ET_BYTES + tid * 16);
     }
     float ds[8];
 #pragma unroll
@@ -262,16 +291,22 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
         dp = MFMA_16x16x32(pb_row_frag(Vb, u * 16 + i, ks * 4 + q4), df[ks], dp, 0, 0, 0);
       }
 #pragma unroll
+      for (int js = 0; js < NJS; ++js) {
+        const opx8 ef = bl_row_frag(Eb, u * 16 + i, js * 4 + q4);
+        s = MFMA_16x16x32(ef, rh[js], s, 0, 0, 0);
+        s = MFMA_16x16x32(ef, rl[js], s, 0, 0, 0);
+      }
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = t * KT + u * 16 + 4 * q4 + r;
-        float x = s[r] * c;
-        const unsigned kd = kdec_s[key < MAXKEYS ? key : MAXKEYS - 1];
-        const bool hasb = qpatch && kd != 0xffffffffu;
-        if (hasb) x += relq[kd & 255] + relq[(kd >> 8) & 255] + relq[(kd >> 16) & 255];
-        const float pr = (key < Lk1 && query < Lq1) ? __builtin_amdgcn_exp2f(x - lse2) : 0.f;
-        const float g = pr * (dp[r] - dl);
-        ds[u * 4 + r] = g;
-        (void)hasb;
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+        ds[u * 4 + r] = pr * (dp[r] - dl);
+      }
+    }
+    if (!more) {                                       // padding keys of the last tile
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = t * KT + (e >> 2) * 16 + 4 * q4 + (e & 3);
+        if (key >= Lk1) ds[e] = 0.f;
       }
     }
     union { unsigned u[4]; opx8 v; } sf;
@@ -280,21 +315,15 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt)
       dq[dt] = MFMA_16x16x32(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
-    if (qpatch_any) {
+    if (qpatch_any) {                                  // d rel[query][j] += sum_key E[key][j] dS[key][query]
 #pragma unroll
-      for (int jt = 0; jt < 3; ++jt) {
-        // A = E^T rows j = 16 jt + i, k-slots = the tile's keys in the same permuted order as sf (4q4+e | 16+4q4+e)
-        union { struct { u32x2 a, b; } s2; opx8 v; } ef;
-        ef.s2.a = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][4 * q4]);
-        ef.s2.b = *reinterpret_cast<const u32x2*>(&et_s[t & 1][16 * jt + i][16 + 4 * q4]);
-        dracc[jt] = MFMA_16x16x32(ef.v, sf.v, dracc[jt], 0, 0, 0);
-      }
+      for (int jt = 0; jt < NJT; ++jt) dracc[jt] = MFMA_16x16x32(bl_frag(Eb, 0, jt, lane), sf.v, dracc[jt], 0, 0, 0);
     }
-    if (t + 1 < ntiles) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    if (more) {
+      char* nb = smem + ((t + 1) & 1) * FWD_BUF;
       tile_lstore(rk, nb, tid);
       tile_lstore(rv, nb + TILE_BYTES, tid);
-      if (qpatch_any) build_et(t + 1);
+      *reinterpret_cast<u32x4*>(nb + 2 * TILE_BYTES + tid * 16) = re;
     }
     __syncthreads();
   }
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   if (qpatch) {
     float* dr = p.drel + ((long)bh * p.Lq + query) * p.J;
 #pragma unroll
-    for (int jt = 0; jt < 3; ++jt)
+    for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jt + 4 * q4 + r;
@@ -325,26 +354,29 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 }
 
 // ------------------------------------------------------------------------------------------------- backward: dK, dV
-// one wave = 16 keys (lane i owns key column i), workgroup = 64 keys; queries streamed in tiles of 32 (Q and dO in LDS)
+// one wave = 16 keys (lane i owns key column i), workgroup = 64 keys; queries streamed in tiles of 32 (Q, dO and the
+// rel operand rows in LDS); the lane's key-map row E[key][:] is the constant MFMA operand of the bias term
+template <int NJS>
 __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][Q | dO]
-  __shared__ float rel_s[2][KT * JMAX];          // [32 queries][J] rows of the query tile, contiguous as in HBM
-  __shared__ float lse_s[2][KT], dl_s[2][KT];
+  constexpr int RT_BYTES = NJS * 4096;                  // rel tile: [32 queries][hi | lo] rows of 128 B (NJS such images)
+  constexpr int KV_BUF = 2 * TILE_BYTES + RT_BYTES;     // [Q | dO | R]
+  __shared__ __attribute__((aligned(16))) char smem[2 * KV_BUF];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][KT], dl_s[2][KT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int key = blockIdx.x * 64 + wave * 16 + i;
   const int kc = key < Lk1 ? key : Lk1 - 1;
-  opx8 kf[3], vf[3];
+  opx8 kf[3], vf[3], ef[NJS];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
     kf[ks] = *reinterpret_cast<const opx8*>(p.k + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
     vf[ks] = *reinterpret_cast<const opx8*>(p.v + ((long)bh * Lk1 + kc) * D + ks * 32 + q4 * 8);
   }
-  const unsigned kd = key_dec(p, key);
-  const bool kpatch = kd != 0xffffffffu;
-  const int j0 = kd & 255, j1 = (kd >> 8) & 255, j2 = (kd >> 16) & 255;
+#pragma unroll
+  for (int js = 0; js < NJS; ++js)
+    ef[js] = *reinterpret_cast<const opx8*>(p.keymap + (long)(kc / KT) * ET_BYTES + bl_off(kc % KT, (js * 4 + q4) * 8));
   const int ntiles_all = (Lq1 + KT - 1) / KT;
   const int per = (ntiles_all + gridDim.z - 1) / gridDim.z;          // query tiles of this z-slice
   const int tbeg = blockIdx.z * per, ntiles = min(ntiles_all, tbeg + per);
@@ -364,38 +396,44 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     }
   };
   // the rel rows / lse / delta of a query tile are one contiguous run in HBM: fetched to registers with the tiles
-  // (latency under the MFMAs), stored to LDS after the step
-  struct SideRegs { float r[5]; float l, d; };
-  const float* relb = p.rel + (long)bh * p.Lq * p.J;
+  // (latency under the MFMAs), stored to LDS after the step.  A row is 8 NJS chunks of 16 B: chunk cid = hi/lo * 4 NJS
+  // + 4 js + q4 lives in image cid / 8 at the swizzled slot cid % 8 of its row.
+  struct SideRegs { u32x4 r[NJS]; float l, d; };
+  const op_t* relb = p.relp + (long)bh * p.Lq * 2 * p.JP;
   auto side_gload = [&](SideRegs& sr, int row0) {
-    const int n = (min(row0 + KT, p.Lq) - row0) * p.J;      // valid floats (patch queries only)
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
-      const int idx = tid + 256 * e;
-      sr.r[e] = idx < n ? relb[(long)row0 * p.J + idx] * LOG2E : 0.f;
+    for (int e = 0; e < NJS; ++e) {
+      const int cidx = tid + 256 * e;
+      const int row = cidx / (8 * NJS);
+      sr.r[e] = (u32x4){0u, 0u, 0u, 0u};
+      if (row0 + row < p.Lq) sr.r[e] = *reinterpret_cast<const u32x4*>(relb + (long)row0 * 2 * p.JP + (long)cidx * 8);
     }
-    sr.l = sr.d = 0.f;
+    sr.l = INFINITY; sr.d = 0.f;                           // rows past the last query: exp2(x - inf) = 0
     if (tid < KT && row0 + tid < Lq1) {
       sr.l = p.lse[(long)bh * Lq1 + row0 + tid];
       sr.d = p.delta[(long)bh * Lq1 + row0 + tid];
     }
   };
-  auto side_lstore = [&](const SideRegs& sr, int buf) {
+  auto side_lstore = [&](const SideRegs& sr, char* rt, int buf) {
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
-      const int idx = tid + 256 * e;
-      if (idx < KT * JMAX) rel_s[buf][idx] = sr.r[e];
+    for (int e = 0; e < NJS; ++e) {
+      const int cidx = tid + 256 * e;
+      const int row = cidx / (8 * NJS), cid = cidx - row * (8 * NJS);
+      *reinterpret_cast<u32x4*>(rt + (cid >> 3) * 4096 + rm_off(row, cid & 7)) = sr.r[e];
     }
     if (tid < KT) { lse_s[buf][tid] = sr.l; dl_s[buf][tid] = sr.d; }
   };
   TileRegs rq, rd;
+  SideRegs rs;
   tile_gload(rq, qb, D, tbeg * KT, Lq1, tid);
   load_do(rd, tbeg * KT);
-  tile_lstore(rq, smem + (tbeg & 1) * 2 * TILE_BYTES, tid);
-  tile_lstore(rd, smem + (tbeg & 1) * 2 * TILE_BYTES + TILE_BYTES, tid);
-  SideRegs rs;
   side_gload(rs, tbeg * KT);
-  side_lstore(rs, tbeg & 1);
+  {
+    char* b0 = smem + (tbeg & 1) * KV_BUF;
+    tile_lstore(rq, b0, tid);
+    tile_lstore(rd, b0 + TILE_BYTES, tid);
+    side_lstore(rs, b0 + 2 * TILE_BYTES, tbeg & 1);
+  }
   __syncthreads();
 
   const float c = p.scale * LOG2E;
@@ -405,8 +443,9 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
 
   for (int t = tbeg; t < ntiles; ++t) {
     const int buf = t & 1;
-    const char* Qb = smem + buf * 2 * TILE_BYTES;
+    const char* Qb = smem + buf * KV_BUF;
     const char* Db = Qb + TILE_BYTES;
+    const char* Rb = Db + TILE_BYTES;
     if (t + 1 < ntiles) {
       tile_gload(rq, qb, D, (t + 1) * KT, Lq1, tid);
       load_do(rd, (t + 1) * KT);
@@ -421,16 +460,22 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
         s = MFMA_16x16x32(pb_row_frag(Qb, u * 16 + i, ks * 4 + q4), kf[ks], s, 0, 0, 0);
         dp = MFMA_16x16x32(pb_row_frag(Db, u * 16 + i, ks * 4 + q4), vf[ks], dp, 0, 0, 0);
       }
-      // s[r] = S[query = t*32 + 16u + 4*q4 + r][key]
+#pragma unroll
+      for (int js = 0; js < NJS; ++js)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const int cid = hl * 4 * NJS + 4 * js + q4;
+          const opx8 rf = *reinterpret_cast<const opx8*>(Rb + (cid >> 3) * 4096 + rm_off(u * 16 + i, cid & 7));
+          s = MFMA_16x16x32(rf, ef[js], s, 0, 0, 0);
+        }
+      // s[r] = S[query = t*32 + 16u + 4*q4 + r][key] / scale
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[buf][u * 16 + 4 * q4]);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&dl_s[buf][u * 16 + 4 * q4]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = u * 16 + 4 * q4 + r;
-        const int qq = t * KT + ql;
-        float x = s[r] * c;
-        if (kpatch && qq < p.Lq) x += rel_s[buf][ql * p.J + j0] + rel_s[buf][ql * p.J + j1] + rel_s[buf][ql * p.J + j2];
-        const float pv = (qq < Lq1 && key < Lk1) ? __builtin_amdgcn_exp2f(x - lse_s[buf][ql]) : 0.f;
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[r]));
         pr[u * 4 + r] = pv;
-        ds[u * 4 + r] = pv * (dp[r] - dl_s[buf][ql]);
+        ds[u * 4 + r] = pv * (dp[r] - d4[r]);
       }
     }
     union { unsigned u[4]; opx8 v; } pf, sf;
@@ -445,10 +490,10 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
       dk[dt] = MFMA_16x16x32(pb_tr_frag(Qb, dt, lane), sf.v, dk[dt], 0, 0, 0);
     }
     if (t + 1 < ntiles) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      char* nb = smem + ((t + 1) & 1) * KV_BUF;
       tile_lstore(rq, nb, tid);
       tile_lstore(rd, nb + TILE_BYTES, tid);
-      side_lstore(rs, (t + 1) & 1);
+      side_lstore(rs, nb + 2 * TILE_BYTES, (t + 1) & 1);
     }
     __syncthreads();
   }
@@ -481,28 +526,50 @@ __global__ __launch_bounds__(256) void pattn_kv_reduce_kernel(const float* __res
   }
 }
 
-int fill(PA& p, const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H, int64_t Lq,
-         int64_t kt, int64_t kh, int64_t kw, float scale, int64_t ldo) {
-  if (!q || !k || !v || !rel || B <= 0 || H <= 0 || Lq <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || (ldo % 8) || ldo < H * D)
+int keymap_tiles(int64_t kt, int64_t kh, int64_t kw) { return (int)((kt * kh * kw + 1 + KT - 1) / KT); }
+
+int fill(PA& p, const void* q, const void* k, const void* v, const void* relp, const void* keymap, int64_t B, int64_t H,
+         int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, int64_t ldo) {
+  if (!q || !k || !v || !relp || !keymap || B <= 0 || H <= 0 || Lq <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || (ldo % 8) ||
+      ldo < H * D)
     return PVRL_EINVAL;
-  if (kh + kw + kt > JMAX || kt * kh * kw + 1 > MAXKEYS || kh + kw + kt > 255) return PVRL_EINVAL;
-  p.q = (const op_t*)q; p.k = (const op_t*)k; p.v = (const op_t*)v; p.rel = rel;
+  if (kh + kw + kt > JMAX || kt * kh * kw + 1 > MAXKEYS) return PVRL_EINVAL;
+  p.q = (const op_t*)q; p.k = (const op_t*)k; p.v = (const op_t*)v; p.relp = (const op_t*)relp;
+  p.keymap = (const char*)keymap;
   p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)(kt * kh * kw);
   p.kt = (int)kt; p.kh = (int)kh; p.kw = (int)kw; p.J = (int)(kh + kw + kt);
+  p.JP = (int)pvrl_mvit_rel_width(kt, kh, kw);
   p.scale = scale; p.ldo = ldo;
   return PVRL_OK;
 }
 
 }  // namespace
 
-extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H,
-                                  int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, void* o, int64_t ldo,
-                                  float* lse, void* stream) {
+extern "C" int64_t pvrl_mvit_rel_width(int64_t kt, int64_t kh, int64_t kw) { return kh + kw + kt <= 32 ? 32 : 64; }
+
+extern "C" int64_t pvrl_mvit_attn_keymap_bytes(int64_t kt, int64_t kh, int64_t kw) {
+  if (kt <= 0 || kh <= 0 || kw <= 0 || kt * kh * kw + 1 > MAXKEYS) return PVRL_EINVAL;
+  return (int64_t)keymap_tiles(kt, kh, kw) * ET_BYTES;
+}
+
+extern "C" int pvrl_mvit_attn_keymap(int64_t kt, int64_t kh, int64_t kw, void* keymap, void* stream) {
+  if (!keymap || kt <= 0 || kh <= 0 || kw <= 0 || kt * kh * kw + 1 > MAXKEYS || kh + kw + kt > JMAX) return PVRL_EINVAL;
+  const int nt = keymap_tiles(kt, kh, kw);
+  hipLaunchKernelGGL(pattn_keymap_kernel, dim3((unsigned)cdiv((long)nt * KT * 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (int)kt, (int)kh, (int)kw, nt, (op_t*)keymap);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, const void* relp, const void* keymap,
+                                  int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale,
+                                  void* o, int64_t ldo, float* lse, void* stream) {
   PA p = {};
-  if (!o || !lse || fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo)) return PVRL_EINVAL;
+  if (!o || !lse || fill(p, q, k, v, relp, keymap, B, H, Lq, kt, kh, kw, scale, ldo)) return PVRL_EINVAL;
   p.o = (op_t*)o; p.lse = lse;
-  hipLaunchKernelGGL(pattn_fwd_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, p);
+  const dim3 grid((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H));
+  if (p.JP == 32) hipLaunchKernelGGL(pattn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(pattn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -516,24 +583,27 @@ extern "C" int64_t pvrl_mvit_attn_bwd_workspace_bytes(int64_t B, int64_t H, int6
   return (int64_t)kv_splits(Lq) * 2 * B * H * (kt * kh * kw + 1) * D * (int64_t)sizeof(float);
 }
 
-extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const float* rel, int64_t B, int64_t H,
-                                  int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale, const void* o,
-                                  const void* d_o, int64_t ldo, const float* lse, float* delta, void* dq, void* dk,
-                                  void* dv, float* drel, void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* relp, const void* keymap,
+                                  int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw, float scale,
+                                  const void* o, const void* d_o, int64_t ldo, const float* lse, float* delta, void* dq,
+                                  void* dk, void* dv, float* drel, void* workspace, int64_t workspace_bytes, void* stream) {
   PA p = {};
   if (!o || !d_o || !lse || !delta || !dq || !dk || !dv || !drel || !workspace ||
-      fill(p, q, k, v, rel, B, H, Lq, kt, kh, kw, scale, ldo))
+      fill(p, q, k, v, relp, keymap, B, H, Lq, kt, kh, kw, scale, ldo))
     return PVRL_EINVAL;
   if (workspace_bytes < pvrl_mvit_attn_bwd_workspace_bytes(B, H, Lq, kt, kh, kw)) return PVRL_EINVAL;
   p.kv_part = (float*)workspace;
   p.o = (op_t*)o; p.d_o = (const op_t*)d_o; p.lse = (float*)lse; p.delta = delta;
   p.dq = (op_t*)dq; p.dk = (op_t*)dk; p.dv = (op_t*)dv; p.drel = drel;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(pattn_bwd_q_kernel, dim3((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H)), dim3(256), 0, s, p);
+  const dim3 gq((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H));
+  if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_q_kernel<1>, gq, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(pattn_bwd_q_kernel<2>, gq, dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
   const int ns = kv_splits(Lq);
-  hipLaunchKernelGGL(pattn_bwd_kv_kernel, dim3((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H), (unsigned)ns), dim3(256), 0,
-                     s, p);
+  const dim3 gk((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H), (unsigned)ns);
+  if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_kv_kernel<1>, gk, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(pattn_bwd_kv_kernel<2>, gk, dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
   const long nkv = (long)B * H * (p.Lk + 1) * D;
   hipLaunchKernelGGL(pattn_kv_reduce_kernel, dim3((unsigned)cdiv(2 * (nkv >> 2), 256)), dim3(256), 0, s, p.kv_part, ns,

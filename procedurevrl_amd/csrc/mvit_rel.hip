@@ -67,8 +67,10 @@ __device__ __forceinline__ void wave_lds_sync() {   // LDS traffic of one wave i
 }
 
 // ------------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q, RelGeom g, RelAxes ax,
-                                                      float* __restrict__ rel) {
+// Output = the operand form the attention kernels consume (attn_pool.hip): relp[bh][q][hi JP | lo JP], the 16-bit pair
+// hi + lo = out_scale * rel[bh][q][j] (out_scale = 1 / attention scale), zero for J <= j < JP.
+__global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q, RelGeom g, RelAxes ax, float out_scale,
+                                                      int JP, op_t* __restrict__ relp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q4 = lane >> 4;
   int v, ck;
   const int a = rel_unit(ax, blockIdx.x, v, ck);
@@ -106,10 +108,17 @@ __global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q
       acc = MFMA_16x16x32(al[ks], qf[ks], acc, 0, 0, 0);
     }
     if (valid) {                                   // acc[r] = rel[query][off + 4 q4 + r]
-      float* dst = rel + ((long)bh * Lq + q) * J + off + 4 * q4;
+      op_t* dst = relp + ((long)bh * Lq + q) * 2 * JP;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * q4 + r < kn) dst[r] = acc[r];
+        if (4 * q4 + r < kn) {
+          const float x = acc[r] * out_scale;
+          const op_t hi = (op_t)x;
+          dst[off + 4 * q4 + r] = hi;
+          dst[JP + off + 4 * q4 + r] = (op_t)(x - (float)hi);
+        }
+      if (a == 2)                                  // the time axis comes last: it also clears the padding columns
+        for (int j = J + q4; j < JP; j += 4) { dst[j] = (op_t)0.f; dst[JP + j] = (op_t)0.f; }
     }
   }
 }
@@ -285,14 +294,15 @@ void rel_axes(RelAxes& ax, const RelGeom& g) {
 
 extern "C" int pvrl_mvit_rel_fwd(const void* Q, int64_t BH, int64_t qt, int64_t qh, int64_t qw, int64_t kt, int64_t kh,
                                  int64_t kw, const float* Rh, const float* Rw, const float* Rt, const int32_t* idx_h,
-                                 const int32_t* idx_w, const int32_t* idx_t, float* rel, void* stream) {
+                                 const int32_t* idx_w, const int32_t* idx_t, float out_scale, void* relp, void* stream) {
   RelGeom g;
-  if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !rel || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
+  if (!Q || !Rh || !Rw || !Rt || !idx_h || !idx_w || !idx_t || !relp || rel_geom(g, BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
   RelAxes ax = {};
   rel_axes(ax, g);
   ax.R[0] = Rh; ax.R[1] = Rw; ax.R[2] = Rt;
   ax.idx[0] = idx_h; ax.idx[1] = idx_w; ax.idx[2] = idx_t;
-  hipLaunchKernelGGL(rel_fwd_kernel, dim3((unsigned)ax.first[3]), dim3(256), 0, (hipStream_t)stream, (const op_t*)Q, g, ax, rel);
+  hipLaunchKernelGGL(rel_fwd_kernel, dim3((unsigned)ax.first[3]), dim3(256), 0, (hipStream_t)stream, (const op_t*)Q, g, ax,
+                     out_scale, (int)pvrl_mvit_rel_width(kt, kh, kw), (op_t*)relp);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

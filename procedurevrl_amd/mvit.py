@@ -374,7 +374,8 @@ class MViTEngine(GraphReplay):
         q_thw, k_thw = om.pool_out_thw(thw, sq), om.pool_out_thw(thw, skv)
         Lq = q_thw[0] * q_thw[1] * q_thw[2]
         ih, iw, it = self._rel_idx(i, blk, q_thw, k_thw, x.device)
-        rel = om.rel_fwd(q, B * H, q_thw, k_thw, P(a.rel_pos_h), P(a.rel_pos_w), P(a.rel_pos_t), ih, iw, it)
+        rel = om.rel_fwd(q, B * H, q_thw, k_thw, P(a.rel_pos_h), P(a.rel_pos_w), P(a.rel_pos_t), ih, iw, it,
+                         out_scale=1.0 / a.scale)
         o, lse = om.attn_fwd(q, k, v, rel, B, H, Lq, k_thw, a.scale, Cpo)
         if dim != dout:
             wsk = self._wpad(blk.proj.weight, blk.proj.bias)

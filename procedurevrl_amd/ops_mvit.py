@@ -106,14 +106,52 @@ def maxpool_bwd(x, dy, B, thw, s, C, argmax=None):
     return dx
 
 
-def rel_fwd(Q, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it):
+def rel_width(k_thw):
+    """columns of one half (hi or lo) of the rel operand rows: 32 or 64"""
+    return int(lib().call("pvrl_mvit_rel_width", *k_thw))
+
+
+def rel_fwd(Q, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, out_scale=1.0):
+    """-> relp [BH, Lq, 2*JP] (operand dtype): out_scale * rel as a hi | lo 16-bit pair, the form attn_fwd / attn_bwd take
+    (with out_scale = 1 / attention scale); `rel_unpack` turns it back into fp32 [BH, Lq, J]"""
     L = lib()
     Lq = q_thw[0] * q_thw[1] * q_thw[2]
-    J = k_thw[1] + k_thw[2] + k_thw[0]
-    rel = torch.empty((BH, Lq, J), device=Q.device, dtype=F32)
+    JP = rel_width(k_thw)
+    relp = torch.empty((BH, Lq, 2 * JP), device=Q.device, dtype=OP16)
     L.call("pvrl_mvit_rel_fwd", _ptr(Q), BH, *q_thw, *k_thw, _ptr(Rh), _ptr(Rw), _ptr(Rt), _ptr(ih), _ptr(iw), _ptr(it),
-           _ptr(rel), _stream())
-    return rel
+           float(out_scale), _ptr(relp), _stream())
+    return relp
+
+
+def rel_unpack(relp, k_thw, out_scale=1.0):
+    JP = relp.shape[-1] // 2
+    J = k_thw[0] + k_thw[1] + k_thw[2]
+    return (relp[..., :JP].float() + relp[..., JP:].float())[..., :J] / out_scale
+
+
+def rel_pack(rel, k_thw, out_scale=1.0):
+    """fp32 rel [BH, Lq, J] -> the operand form (what rel_fwd writes), e.g. to feed the attention kernels a given bias"""
+    JP = rel_width(k_thw)
+    x = torch.zeros(rel.shape[:-1] + (JP,), device=rel.device, dtype=F32)
+    x[..., :rel.shape[-1]] = rel.float() * out_scale
+    hi = x.to(OP16)
+    lo = (x - hi.float()).to(OP16)
+    return torch.cat((hi, lo), dim=-1).contiguous()
+
+
+_KEYMAPS = {}
+
+
+def keymap(k_thw, device):
+    """the key geometry's 0/1 map E[key][j] as MFMA tile images (pvrl_mvit_attn_keymap), built once per geometry"""
+    key = (tuple(k_thw), str(device), str(OP16))
+    km = _KEYMAPS.get(key)
+    if km is None:
+        L = lib()
+        km = torch.empty(L.call("pvrl_mvit_attn_keymap_bytes", *k_thw), device=device, dtype=torch.uint8)
+        L.call("pvrl_mvit_attn_keymap", *k_thw, _ptr(km), _stream())
+        _KEYMAPS[key] = km
+    return km
 
 
 def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt):
@@ -126,28 +164,32 @@ def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt
            ws.numel(), _stream())
 
 
-def attn_fwd(q, k, v, rel, B, H, Lq, k_thw, scale, ldo):
-    """-> (o bf16 [B*Lq + B, ldo] token-major (zeros beyond H*96), lse fp32 [B*H, Lq+1])"""
+def attn_fwd(q, k, v, relp, B, H, Lq, k_thw, scale, ldo):
+    """relp = rel_fwd(..., out_scale=1/scale) -> (o bf16 [B*Lq + B, ldo] token-major (zeros beyond H*96), lse fp32 [B*H, Lq+1])"""
     L = lib()
     o = torch.zeros((B * Lq + B, ldo), device=q.device, dtype=OP16) if ldo > H * HD else \
         torch.empty((B * Lq + B, ldo), device=q.device, dtype=OP16)
     lse = torch.empty((B * H, Lq + 1), device=q.device, dtype=F32)
-    L.call("pvrl_mvit_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), ldo,
+    assert relp.dtype == OP16 and relp.shape[-1] == 2 * rel_width(k_thw)
+    L.call("pvrl_mvit_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(relp), _ptr(keymap(k_thw, q.device)), B, H, Lq, *k_thw,
+           float(scale), _ptr(o), ldo,
            _ptr(lse), _stream())
     return o, lse
 
 
-def attn_bwd(q, k, v, rel, B, H, Lq, k_thw, scale, o, d_o, lse):
-    """-> (dq, dk, dv bf16 like q / k / v, drel fp32 like rel)"""
+def attn_bwd(q, k, v, relp, B, H, Lq, k_thw, scale, o, d_o, lse):
+    """-> (dq, dk, dv bf16 like q / k / v, drel fp32 [B*H, Lq, J]: the gradient of the unscaled rel)"""
     L = lib()
     assert d_o.dtype == OP16 and d_o.stride(0) == o.stride(0)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    drel = torch.empty_like(rel)
+    assert relp.dtype == OP16 and relp.shape[-1] == 2 * rel_width(k_thw)
+    drel = torch.empty((B * H, Lq, k_thw[0] + k_thw[1] + k_thw[2]), device=q.device, dtype=F32)
     delta = torch.empty_like(lse)
     from .ops import workspace
     nbytes = L.call("pvrl_mvit_attn_bwd_workspace_bytes", B, H, Lq, *k_thw)
     ws = workspace(nbytes, q.device, "mvit_attn_bwd")
-    L.call("pvrl_mvit_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(rel), B, H, Lq, *k_thw, float(scale), _ptr(o), _ptr(d_o),
+    L.call("pvrl_mvit_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(relp), _ptr(keymap(k_thw, q.device)), B, H, Lq, *k_thw,
+           float(scale), _ptr(o), _ptr(d_o),
            o.stride(0), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(drel), _ptr(ws), ws.numel(), _stream())
     return dq, dk, dv, drel
 

@@ -146,8 +146,12 @@ def check_mvit_maxpool_rel():
                          torch.einsum("bthwc,tkc->bthwk", rq, Rtr[it])), dim=-1).reshape(BH, Lq, -1)
         d = lambda t: t.to(DEV)
         di = lambda t: t.to(DEV, torch.int32).contiguous()
-        relg = om.rel_fwd(d(Q).to(BF), BH, q_thw, k_thw, d(Rh), d(Rw), d(Rt), di(ih), di(iw), di(it))
-        out.append((f"rel fwd {q_thw}x{k_thw}", rel(relg, ref), 1e-5))
+        for osc in (1.0, 96 ** 0.5):              # the operand form (hi | lo pair of out_scale * rel) decodes to rel
+            relp = om.rel_fwd(d(Q).to(BF), BH, q_thw, k_thw, d(Rh), d(Rw), d(Rt), di(ih), di(iw), di(it), out_scale=osc)
+            out.append((f"rel fwd {q_thw}x{k_thw} out_scale {osc:.2f}", rel(om.rel_unpack(relp, k_thw, osc), ref), 2e-5))
+            JP, J = relp.shape[-1] // 2, ref.shape[-1]
+            pad = torch.cat((relp[..., J:JP], relp[..., JP + J:]), dim=-1)
+            out.append((f"rel fwd {q_thw}x{k_thw} padding columns zero", float(pad.float().abs().max()), 0.0))
         drel = torch.randn(ref.shape, generator=g)
         ref.backward(drel)
         dQ0 = bf(torch.randn(BH, Lq + 1, 96, generator=g))
@@ -178,8 +182,9 @@ def check_mvit_attention():
     from procedurevrl_amd import ops_mvit as om
     g = torch.Generator().manual_seed(4)
     out = []
+    # the last two have kh + kw + kt > 32 (the 64-column rel operand: MViTv2-S blocks 1, 3, 14) and > 1 key tile
     for (B, H, q_thw, k_thw) in [(2, 2, (2, 8, 8), (2, 2, 2)), (1, 1, (2, 6, 6), (2, 6, 6)), (2, 4, (1, 3, 5), (1, 3, 5)),
-                                 (1, 2, (4, 8, 8), (4, 4, 4))]:
+                                 (1, 2, (4, 8, 8), (4, 4, 4)), (1, 2, (2, 5, 7), (8, 14, 14)), (2, 1, (8, 7, 7), (7, 13, 14))]:
         BH = B * H
         Lq = q_thw[0] * q_thw[1] * q_thw[2]; Lk = k_thw[0] * k_thw[1] * k_thw[2]
         J = k_thw[1] + k_thw[2] + k_thw[0]
@@ -190,7 +195,8 @@ def check_mvit_attention():
         ref = _attn_ref(qr, kr, vr, rr, q_thw, k_thw, scale)
         ldo = om.pad128(H * 96)
         d = lambda t: t.to(DEV)
-        o, lse = om.attn_fwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), d(relb), B, H, Lq, k_thw, scale, ldo)
+        relp = om.rel_pack(d(relb), k_thw, 1.0 / scale)
+        o, lse = om.attn_fwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), relp, B, H, Lq, k_thw, scale, ldo)
         # token-major [B*Lq + B, ldo] -> [BH, Lq+1, 96]
         ot = torch.cat((o[:B * Lq, :H * 96].float().reshape(B, Lq, H, 96), o[B * Lq:, :H * 96].float().reshape(B, 1, H, 96)), dim=1)
         ot = ot.permute(0, 2, 1, 3).reshape(BH, Lq + 1, 96)
@@ -204,7 +210,7 @@ def check_mvit_attention():
         d_o = torch.zeros(B * Lq + B, ldo)
         d_o[:B * Lq, :H * 96] = dot[:, :Lq].reshape(B * Lq, H * 96)
         d_o[B * Lq:, :H * 96] = dot[:, Lq].reshape(B, H * 96)
-        dq, dk, dv, drel = om.attn_bwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), d(relb), B, H, Lq, k_thw, scale, o,
+        dq, dk, dv, drel = om.attn_bwd(d(q).to(BF), d(k).to(BF), d(v).to(BF), relp, B, H, Lq, k_thw, scale, o,
                                        d(d_o).to(BF), lse)
         out.append((f"attn bwd dq {tag}", rel(dq, qr.grad), 1.5e-2))
         out.append((f"attn bwd dk {tag}", rel(dk, kr.grad), 1.5e-2))

@@ -50,8 +50,8 @@ for i, pl in enumerate(plan):
             ((q_thw[1], k_thw[1]), (q_thw[2], k_thw[2]), (q_thw[0], k_thw[0]))]
     idx = [rel_index(a, b).to(DEV, torch.int32).contiguous() for a, b in
            ((q_thw[1], k_thw[1]), (q_thw[2], k_thw[2]), (q_thw[0], k_thw[0]))]
-    rel = om.rel_fwd(q, BH, q_thw, k_thw, *tabs, *idx)
-    t_rf = timeit(lambda: om.rel_fwd(q, BH, q_thw, k_thw, *tabs, *idx))
+    rel = om.rel_fwd(q, BH, q_thw, k_thw, *tabs, *idx, out_scale=96 ** 0.5)
+    t_rf = timeit(lambda: om.rel_fwd(q, BH, q_thw, k_thw, *tabs, *idx, out_scale=96 ** 0.5))
     ldo = om.pad128(dout)
     o, lse = om.attn_fwd(q, k, v, rel, B, H, Lq, k_thw, 96 ** -0.5, ldo)
     t_af = timeit(lambda: om.attn_fwd(q, k, v, rel, B, H, Lq, k_thw, 96 ** -0.5, ldo))
