@@ -42,28 +42,42 @@ struct PA {
   float scale;
 };
 
-// cooperative tile load: 32 rows x 12 chunks of 16 B = 384 chunks, rows >= nrows zero
-struct TileRegs { u32x4 v[2]; };
-__device__ __forceinline__ void tile_gload(TileRegs& t, const op_t* base, long ld, int row0, int nrows, int tid) {
+// Staging of a PAIR of 32 x 96 tiles (K | V, or Q | dO): 768 chunks of 16 B, exactly three per thread, no branches.  Chunk
+// c = tid + 256 e belongs to the first tile for c < 384.  The (row, column, LDS offset) split is a loop invariant kept
+// in a PairMap.  Rows past the end of the tensor are CLAMPED to its last row instead of zero-filled: every consumer
+// masks the scores of such keys / queries to exactly zero probability, and zero times a finite operand is zero.
+// (Guarding the loads with branches instead made the compiler serialise them: s_waitcnt vmcnt(0) at every join.)
+struct PairRegs { u32x4 v[3]; };
+struct PairMap {
+  int row[3], coff[3], lo[3];
+  bool second1;                 // slot 0 is always in the first tile, slot 2 in the second, slot 1 depends on the thread
+};
+__device__ __forceinline__ PairMap pair_map(int tid) {
+  PairMap m;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < 3; ++e) {
     const int c = tid + 256 * e;
-    t.v[e] = (u32x4){0u, 0u, 0u, 0u};
-    if (c < 384) {
-      const int row = c / 12, ch = c - row * 12;
-      if (row0 + row < nrows) t.v[e] = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * ld + ch * 8);
-    }
+    const int sec = c >= 384, cc = c - 384 * sec;
+    m.row[e] = cc / 12;
+    const int ch = cc - m.row[e] * 12;
+    m.coff[e] = ch * 8;
+    m.lo[e] = sec * TILE_BYTES + pb_off(m.row[e], ch * 8);
+  }
+  m.second1 = tid >= 128;
+  return m;
+}
+// both tiles row-major [nrows][D] (K | V)
+__device__ __forceinline__ void pair_gload(PairRegs& t, const PairMap& m, const op_t* a, const op_t* b, int row0, int nrows) {
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const op_t* base = e == 0 ? a : (e == 2 ? b : (m.second1 ? b : a));
+    const int r = min(row0 + m.row[e], nrows - 1);
+    t.v[e] = *reinterpret_cast<const u32x4*>(base + (long)r * D + m.coff[e]);
   }
 }
-__device__ __forceinline__ void tile_lstore(const TileRegs& t, char* tile, int tid) {
+__device__ __forceinline__ void pair_lstore(const PairRegs& t, const PairMap& m, char* tiles) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int c = tid + 256 * e;
-    if (c < 384) {
-      const int row = c / 12, ch = c - row * 12;
-      *reinterpret_cast<u32x4*>(tile + pb_off(row, ch * 8)) = t.v[e];
-    }
-  }
+  for (int e = 0; e < 3; ++e) *reinterpret_cast<u32x4*>(tiles + m.lo[e]) = t.v[e];
 }
 __device__ __forceinline__ long tok_row(const PA& p, int b, int query) {
   return query < p.Lq ? (long)b * p.Lq + query : (long)p.B * p.Lq + b;
@@ -121,13 +135,12 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
   const op_t* kb = p.k + (long)bh * Lk1 * D;
   const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
-  TileRegs rk, rv;
+  PairRegs rkv;
+  const PairMap pm = pair_map(tid);
   u32x4 re;
-  tile_gload(rk, kb, D, 0, Lk1, tid);
-  tile_gload(rv, vb, D, 0, Lk1, tid);
+  pair_gload(rkv, pm, kb, vb, 0, Lk1);
   re = *reinterpret_cast<const u32x4*>(p.keymap + tid * 16);
-  tile_lstore(rk, smem, tid);
-  tile_lstore(rv, smem + TILE_BYTES, tid);
+  pair_lstore(rkv, pm, smem);
   *reinterpret_cast<u32x4*>(smem + 2 * TILE_BYTES + tid * 16) = re;
   __syncthreads();
 
@@ -144,8 +157,7 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
     const char* Eb = Vb + TILE_BYTES;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
-      tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+      pair_gload(rkv, pm, kb, vb, (t + 1) * KT, Lk1);
       re = *reinterpret_cast<const u32x4*>(p.keymap + (long)(t + 1) * ET_BYTES + tid * 16);
     }
     float val[8];                                      // raw scores (K Q^T + E rel^T): logits / scale
@@ -196,8 +208,7 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
     for (int dt = 0; dt < 6; ++dt) oacc[dt] = MFMA_16x16x32(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
     if (more) {
       char* nb = smem + ((t + 1) & 1) * FWD_BUF;
-      tile_lstore(rk, nb, tid);
-      tile_lstore(rv, nb + TILE_BYTES, tid);
+      pair_lstore(rkv, pm, nb);
       *reinterpret_cast<u32x4*>(nb + 2 * TILE_BYTES + tid * 16) = re;
     }
     __syncthreads();
@@ -252,13 +263,12 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
   const op_t* kb = p.k + (long)bh * Lk1 * D;
   const op_t* vb = p.v + (long)bh * Lk1 * D;
   const int ntiles = (Lk1 + KT - 1) / KT;
-  TileRegs rk, rv;
+  PairRegs rkv;
+  const PairMap pm = pair_map(tid);
   u32x4 re;
-  tile_gload(rk, kb, D, 0, Lk1, tid);
-  tile_gload(rv, vb, D, 0, Lk1, tid);
+  pair_gload(rkv, pm, kb, vb, 0, Lk1);
   re = *reinterpret_cast<const u32x4*>(p.keymap + tid * 16);
-  tile_lstore(rk, smem, tid);
-  tile_lstore(rv, smem + TILE_BYTES, tid);
+  pair_lstore(rkv, pm, smem);
   *reinterpret_cast<u32x4*>(smem + 2 * TILE_BYTES + tid * 16) = re;
   __syncthreads();
   const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
@@ -277,8 +287,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
     const char* Eb = Vb + TILE_BYTES;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_gload(rk, kb, D, (t + 1) * KT, Lk1, tid);
-      tile_gload(rv, vb, D, (t + 1) * KT, Lk1, tid);
+      pair_gload(rkv, pm, kb, vb, (t + 1) * KT, Lk1);
       re = *reinterpret_cast<const u32x4*>(p.keymap + (long)(t + 1) * ET_BYTES + tid * 16);
     }
     float ds[8];
@@ -321,8 +330,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
     }
     if (more) {
       char* nb = smem + ((t + 1) & 1) * FWD_BUF;
-      tile_lstore(rk, nb, tid);
-      tile_lstore(rv, nb + TILE_BYTES, tid);
+      pair_lstore(rkv, pm, nb);
       *reinterpret_cast<u32x4*>(nb + 2 * TILE_BYTES + tid * 16) = re;
     }
     __syncthreads();
@@ -382,57 +390,57 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
   const int tbeg = blockIdx.z * per, ntiles = min(ntiles_all, tbeg + per);
   const op_t* qb = p.q + (long)bh * Lq1 * D;
 
-  // the dO tile is gathered from the token-major activation: rows (b, query) / cls row, columns h*96 ..
-  auto load_do = [&](TileRegs& t, int row0) {
+  // Q | dO pair: the dO rows are gathered from the token-major activation (rows (b, query), the cls row last; columns
+  // h*96 ..).  Rows past the last query are clamped to the cls row: their lse is +inf below, so P = dS = 0.
+  const PairMap pm = pair_map(tid);
+  auto qd_gload = [&](PairRegs& t, int row0) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int cidx = tid + 256 * e;
-      t.v[e] = (u32x4){0u, 0u, 0u, 0u};
-      if (cidx < 384) {
-        const int row = cidx / 12, ch = cidx - row * 12;
-        const int qq = row0 + row;
-        if (qq < Lq1) t.v[e] = *reinterpret_cast<const u32x4*>(p.d_o + tok_row(p, b, qq) * p.ldo + h * D + ch * 8);
-      }
+    for (int e = 0; e < 3; ++e) {
+      const int r = min(row0 + pm.row[e], Lq1 - 1);
+      const op_t* qa = qb + (long)r * D + pm.coff[e];
+      const op_t* da = p.d_o + tok_row(p, b, r) * p.ldo + h * D + pm.coff[e];
+      const op_t* src = e == 0 ? qa : (e == 2 ? da : (pm.second1 ? da : qa));
+      t.v[e] = *reinterpret_cast<const u32x4*>(src);
     }
   };
   // the rel rows / lse / delta of a query tile are one contiguous run in HBM: fetched to registers with the tiles
   // (latency under the MFMAs), stored to LDS after the step.  A row is 8 NJS chunks of 16 B: chunk cid = hi/lo * 4 NJS
-  // + 4 js + q4 lives in image cid / 8 at the swizzled slot cid % 8 of its row.
+  // + 4 js + q4 lives in image cid / 8 at the swizzled slot cid % 8 of its row.  The cls query and the rows past it
+  // have no bias: zero (selected after a clamped load, no branch).
   struct SideRegs { u32x4 r[NJS]; float l, d; };
   const op_t* relb = p.relp + (long)bh * p.Lq * 2 * p.JP;
-  auto side_gload = [&](SideRegs& sr, int row0) {
+  int side_lo[NJS], side_row[NJS], side_col[NJS];              // loop invariants of this thread's chunks
 #pragma unroll
-    for (int e = 0; e < NJS; ++e) {
-      const int cidx = tid + 256 * e;
-      const int row = cidx / (8 * NJS);
-      sr.r[e] = (u32x4){0u, 0u, 0u, 0u};
-      if (row0 + row < p.Lq) sr.r[e] = *reinterpret_cast<const u32x4*>(relb + (long)row0 * 2 * p.JP + (long)cidx * 8);
-    }
-    sr.l = INFINITY; sr.d = 0.f;                           // rows past the last query: exp2(x - inf) = 0
-    if (tid < KT && row0 + tid < Lq1) {
-      sr.l = p.lse[(long)bh * Lq1 + row0 + tid];
-      sr.d = p.delta[(long)bh * Lq1 + row0 + tid];
+  for (int e = 0; e < NJS; ++e) {
+    const int cidx = tid + 256 * e;
+    const int row = cidx / (8 * NJS), cid = cidx - row * (8 * NJS);
+    side_row[e] = row; side_col[e] = cid * 8;
+    side_lo[e] = (cid >> 3) * 4096 + rm_off(row, cid & 7);
+  }
+  auto side_gload = [&](SideRegs& sr, int row0) {             // loads only: the selects wait in side_lstore, after the MFMAs
+#pragma unroll
+    for (int e = 0; e < NJS; ++e)
+      sr.r[e] = *reinterpret_cast<const u32x4*>(relb + (long)min(row0 + side_row[e], p.Lq - 1) * 2 * p.JP + side_col[e]);
+    const long si = (long)bh * Lq1 + min(row0 + (tid & (KT - 1)), Lq1 - 1);
+    sr.l = p.lse[si]; sr.d = p.delta[si];
+  };
+  auto side_lstore = [&](const SideRegs& sr, char* rt, int buf, int row0) {
+#pragma unroll
+    for (int e = 0; e < NJS; ++e)
+      *reinterpret_cast<u32x4*>(rt + side_lo[e]) = row0 + side_row[e] < p.Lq ? sr.r[e] : (u32x4){0u, 0u, 0u, 0u};
+    if (tid < KT) {
+      const bool ok = row0 + tid < Lq1;                        // rows past the last query: exp2(x - inf) = 0
+      lse_s[buf][tid] = ok ? sr.l : INFINITY; dl_s[buf][tid] = ok ? sr.d : 0.f;
     }
   };
-  auto side_lstore = [&](const SideRegs& sr, char* rt, int buf) {
-#pragma unroll
-    for (int e = 0; e < NJS; ++e) {
-      const int cidx = tid + 256 * e;
-      const int row = cidx / (8 * NJS), cid = cidx - row * (8 * NJS);
-      *reinterpret_cast<u32x4*>(rt + (cid >> 3) * 4096 + rm_off(row, cid & 7)) = sr.r[e];
-    }
-    if (tid < KT) { lse_s[buf][tid] = sr.l; dl_s[buf][tid] = sr.d; }
-  };
-  TileRegs rq, rd;
+  PairRegs rqd;
   SideRegs rs;
-  tile_gload(rq, qb, D, tbeg * KT, Lq1, tid);
-  load_do(rd, tbeg * KT);
+  qd_gload(rqd, tbeg * KT);
   side_gload(rs, tbeg * KT);
   {
     char* b0 = smem + (tbeg & 1) * KV_BUF;
-    tile_lstore(rq, b0, tid);
-    tile_lstore(rd, b0 + TILE_BYTES, tid);
-    side_lstore(rs, b0 + 2 * TILE_BYTES, tbeg & 1);
+    pair_lstore(rqd, pm, b0);
+    side_lstore(rs, b0 + 2 * TILE_BYTES, tbeg & 1, tbeg * KT);
   }
   __syncthreads();
 
@@ -447,8 +455,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     const char* Db = Qb + TILE_BYTES;
     const char* Rb = Db + TILE_BYTES;
     if (t + 1 < ntiles) {
-      tile_gload(rq, qb, D, (t + 1) * KT, Lq1, tid);
-      load_do(rd, (t + 1) * KT);
+      qd_gload(rqd, (t + 1) * KT);
       side_gload(rs, (t + 1) * KT);
     }
     float pr[8], ds[8];
@@ -491,9 +498,8 @@ __global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
     }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * KV_BUF;
-      tile_lstore(rq, nb, tid);
-      tile_lstore(rd, nb + TILE_BYTES, tid);
-      side_lstore(rs, nb + 2 * TILE_BYTES, (t + 1) & 1);
+      pair_lstore(rqd, pm, nb);
+      side_lstore(rs, nb + 2 * TILE_BYTES, (t + 1) & 1, (t + 1) * KT);
     }
     __syncthreads();
   }

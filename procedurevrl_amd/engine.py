@@ -79,6 +79,26 @@ class GradStore:
             self._touched.append(key)
         return t, beta
 
+    def prezero(self, params):
+        """An engine that is about to ACCUMULATE into every one of `params` (atomics / beta = 1 kernels): the ones without a
+        gradient yet get their zeroed view now, contiguous runs of the flat buffer in one fill each, instead of one small
+        fill per parameter at its first use.  Only for parameters the caller is certain to write: .grad stops being None."""
+        idx = sorted(self.index[id(p)] for p in params if p.grad is None and id(p) in self.index)
+        runs = []
+        for i in idx:
+            a, b = self.span(i)
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        for a, b in runs:
+            self.flat[a:b].zero_()
+        for i in idx:
+            self.params[i].grad = self.views[i]
+            if self.scale is not None:           # zeros need no conversion to S-scaled units, but are unscaled with the rest
+                self._seen_idx.add(i)
+                self._touched.append(i)
+
     # ---- fp16-operand flavour: gradient scaling inside an engine's backward -------------------------------------------
     # fp16 has 5 exponent bits: the 16-bit gradient operands of the backward GEMMs (rms 1e-6 .. 1e-4 at the benchmark
     # shapes) would underflow.  An engine therefore multiplies the gradient it receives by a power of two S, chosen on the

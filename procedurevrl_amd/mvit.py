@@ -426,6 +426,9 @@ class MViTEngine(GraphReplay):
         gs = self.m.grad_store() if SCALED_GRADS else None
         if gs is not None:
             dfeat = gs.begin_scaled(dfeat.float())     # fp16-operand flavour: backward in S-scaled units (GradStore.begin_scaled)
+        # every encoder parameter receives a gradient below, most of them through accumulating kernels: one fill per
+        # contiguous run of the flat gradient buffer instead of ~320 five-microsecond fills
+        self.m.grad_store().prezero([p for p in enc.parameters() if p.requires_grad])
         dgn, dbn = self._acc_target(enc.norm.weight), self._acc_target(enc.norm.bias)
         dx[Rl:] = om.ln_bwd(dfeat.contiguous().float(), xf[Rl:], Cl, sv["f_mean"], sv["f_rstd"], enc.norm.weight.detach(),
                             dgn, dbn, Cpad=xf.shape[1])
