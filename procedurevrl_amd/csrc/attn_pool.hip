@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void pattn_keymap_kernel(int kt, int kh, int k
 // ------------------------------------------------------------------------------------------------- forward
 constexpr int FWD_BUF = 2 * TILE_BYTES + ET_BYTES;      // [K | V | E] per buffer
 template <int NJS>
-__global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
+__global__ __launch_bounds__(256, 3) void pattn_fwd_kernel(PA p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void pattn_fwd_kernel(PA p) {
 
 // ------------------------------------------------------------------------------------------------- backward: dQ, d rel
 template <int NJS>
-__global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
+__global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p) {
   constexpr int NJT = NJS == 1 ? 2 : 3;                 // 16-column blocks of d rel (J <= 32 / J <= 40)
   __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_q_kernel(PA p) {
 // one wave = 16 keys (lane i owns key column i), workgroup = 64 keys; queries streamed in tiles of 32 (Q, dO and the
 // rel operand rows in LDS); the lane's key-map row E[key][:] is the constant MFMA operand of the bias term
 template <int NJS>
-__global__ __launch_bounds__(256) void pattn_bwd_kv_kernel(PA p) {
+__global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA p) {
   constexpr int RT_BYTES = NJS * 4096;                  // rel tile: [32 queries][hi | lo] rows of 128 B (NJS such images)
   constexpr int KV_BUF = 2 * TILE_BYTES + RT_BYTES;     // [Q | dO | R]
   __shared__ __attribute__((aligned(16))) char smem[2 * KV_BUF];
@@ -580,13 +580,17 @@ extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, c
   return PVRL_OK;
 }
 
-static int kv_splits(int64_t Lq) {   // query tiles are shared out so that a workgroup streams >= ~2048 queries
+// dK / dV: query tiles are shared out so that a workgroup streams >= ~2048 queries.  (Measured: more, smaller workgroups --
+// ~3,000 per launch instead of 896 at Lq = 1568 -- lose 7 %: the extra fp32 partials and their reduction cost more than
+// the fuller last wave of workgroups gains.)
+static int kv_splits(int64_t BH, int64_t Lq, int64_t Lk) {
+  (void)BH; (void)Lk;
   int64_t s = (Lq + 1 + 2047) / 2048;
   return (int)(s < 1 ? 1 : (s > 16 ? 16 : s));
 }
 
 extern "C" int64_t pvrl_mvit_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Lq, int64_t kt, int64_t kh, int64_t kw) {
-  return (int64_t)kv_splits(Lq) * 2 * B * H * (kt * kh * kw + 1) * D * (int64_t)sizeof(float);
+  return (int64_t)kv_splits(B * H, Lq, kt * kh * kw) * 2 * B * H * (kt * kh * kw + 1) * D * (int64_t)sizeof(float);
 }
 
 extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* relp, const void* keymap,
@@ -606,7 +610,7 @@ extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, c
   if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_q_kernel<1>, gq, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(pattn_bwd_q_kernel<2>, gq, dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
-  const int ns = kv_splits(Lq);
+  const int ns = kv_splits(B * H, Lq, p.Lk);
   const dim3 gk((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H), (unsigned)ns);
   if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_kv_kernel<1>, gk, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(pattn_bwd_kv_kernel<2>, gk, dim3(256), 0, s, p);
