@@ -202,15 +202,17 @@ int pvrl_im2col3d_bf16(const float* frames, int64_t B, int64_t Cin, int64_t T, i
 
 /* nn.LayerNorm of any width C <= 768 over fp32 rows with leading dimension ldx (mvit.py:78, attention.py:502,524);
  * y (bf16, or fp32 when y_is_f32) gets zeros in columns [C, Cpad).  Backward: dx = dres + dLN(dy); dgamma / dbeta are
- * ACCUMULATED (atomicAdd) into the given buffers. */
+ * ACCUMULATED into the given buffers from per-workgroup partials summed in a fixed order.  dx16 (optional, 16-bit,
+ * [M][lddx16 >= Cpad]) receives rowscale16[row] * dx (rowscale16 optional) in the same pass: the operand copy the next
+ * backward GEMM reads (DropPath factor folded in), which otherwise costs a pvrl_cast_scale_bf16 pass over dx. */
 int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                          int64_t ldy, int y_is_f32, int64_t M, int64_t C, int64_t Cpad, float* mean, float* rstd,
                          void* stream);
 int64_t pvrl_layernorm_g_bwd_workspace_bytes(int64_t M, int64_t C);
 int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx, const float* mean,
                          const float* rstd, const float* gamma, const float* dres, int64_t ldr, float* dx, int64_t lddx,
-                         int64_t M, int64_t C, int64_t Cpad, float* dgamma, float* dbeta, void* workspace,
-                         int64_t workspace_bytes, void* stream);
+                         void* dx16, int64_t lddx16, const float* rowscale16, int64_t M, int64_t C, int64_t Cpad,
+                         float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* attention_pool (attention.py:14-48) for mode "conv": depthwise Conv3d(96 ch, kernel 3x3x3, padding 1, stride st,sh,sw, no
  * bias; weight fp32 [96][27]) + LayerNorm(96) on one of q / k / v taken in place from the packed qkv activation (bf16

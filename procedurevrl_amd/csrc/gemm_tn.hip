@@ -68,8 +68,12 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   PVRL_LAUNCH_CHECK();
   const long NK = N * K;
   const long nthreads = (NK >> 2) + (dbias ? N : 0);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
-                     (int)splits, NK, (int)N, beta, dW, dbias);
+  if (nthreads < 64 * 256 && splits >= 8)
+    hipLaunchKernelGGL(tn_reduce_small_kernel, dim3((unsigned)cdiv(nthreads, 64)), dim3(256), 0, s, p.part, p.cpart,
+                       (int)splits, NK, (int)N, beta, dW, dbias);
+  else
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
+                       (int)splits, NK, (int)N, beta, dW, dbias);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -446,6 +446,37 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
+// The same for SMALL outputs (MViT's 96..768-wide layers: a 128 x 128 dW is 4,096 float4s = 16 workgroups above, each
+// thread walking up to 256 slices serially): 64 float4s x 4 slice-quarters per workgroup, quarters combined in LDS in a
+// fixed order -- four times the workgroups and a quarter of the serial chain.
+__global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
+                                                              int splits, long NK, int N, float beta,
+                                                              float* __restrict__ out, float* __restrict__ bias_out) {
+  __shared__ f32x4 red[3][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long idx4 = (long)blockIdx.x * 64 + o;
+  const long n4 = NK >> 2;
+  const bool is_w = idx4 < n4, is_b = !is_w && bias_out && idx4 - n4 < N;
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (is_w) {
+    for (int s = sl; s < splits; s += 4) a += reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
+  } else if (is_b) {
+    for (int s = sl; s < splits; s += 4) a[0] += cpart[(long)s * N + (int)(idx4 - n4)];
+  }
+  if (sl > 0) red[sl - 1][o] = a;
+  __syncthreads();
+  if (sl == 0) {
+    a = (a + red[0][o]) + (red[1][o] + red[2][o]);
+    if (is_w) {
+      if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
+      reinterpret_cast<f32x4*>(out)[idx4] = a;
+    } else if (is_b) {
+      const int n = (int)(idx4 - n4);
+      bias_out[n] = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+    }
+  }
+}
+
 // the same for every problem of a grouped launch in ONE kernel (seven 10-us launches per transformer block otherwise)
 constexpr int TN_RED_MAX = 8;
 struct TnReduceGroup {

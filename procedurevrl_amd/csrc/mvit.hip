@@ -106,25 +106,30 @@ __global__ __launch_bounds__(256) void ln_g_fwd_kernel(const float* __restrict__
   }
 }
 
-// out[j] += sum_b part[b][j]  (j < half -> out0[j], else out1[j - half]); fixed order: 16 outputs x 16 slices of the
-// block list per workgroup, slices combined through LDS.  Replaces same-address fp32 atomics (bit-reproducible).
+// out[j] += sum_b part[b][j]  (j < half -> out0[j], else out1[j - half]); fixed order: 8 outputs x 32 slices of the
+// block list per workgroup (four loads in flight per thread: 1,024 - 2,048 partial rows make this a latency chain),
+// slices combined through LDS.  Replaces same-address fp32 atomics (bit-reproducible).
+constexpr int PADD_OUT = 8, PADD_SL = 32;
 __global__ __launch_bounds__(256) void partials_add_kernel(const float* __restrict__ part, int nblk, int n,
                                                            float* __restrict__ out0, float* __restrict__ out1, int half) {
-  __shared__ float red[16][17];
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + o;
-  float a0 = 0.f, a1 = 0.f;
+  __shared__ float red[PADD_SL][PADD_OUT + 1];
+  const int o = threadIdx.x & (PADD_OUT - 1), sl = threadIdx.x / PADD_OUT;
+  const int j = blockIdx.x * PADD_OUT + o;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (j < n) {
     int b = sl;
-    for (; b + 16 < nblk; b += 32) { a0 += part[(long)b * n + j]; a1 += part[(long)(b + 16) * n + j]; }
-    if (b < nblk) a0 += part[(long)b * n + j];
+    for (; b + 3 * PADD_SL < nblk; b += 4 * PADD_SL) {
+      a0 += part[(long)b * n + j]; a1 += part[(long)(b + PADD_SL) * n + j];
+      a2 += part[(long)(b + 2 * PADD_SL) * n + j]; a3 += part[(long)(b + 3 * PADD_SL) * n + j];
+    }
+    for (; b < nblk; b += PADD_SL) a0 += part[(long)b * n + j];
   }
-  red[sl][o] = a0 + a1;
+  red[sl][o] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && j < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][o];
+    for (int k = 0; k < PADD_SL; ++k) t += red[k][o];
     float* dst = j < half ? out0 + j : out1 + (j - half);
     *dst += t;
   }
@@ -136,7 +141,9 @@ __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy
                                                        long ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ dres, long ldr, float* __restrict__ dx,
-                                                       long lddx, int C, int Cpad, float* __restrict__ part, long M) {
+                                                       long lddx, op_t* __restrict__ dx16, long lddx16,
+                                                       const float* __restrict__ rowscale16, int C, int Cpad,
+                                                       float* __restrict__ part, long M) {
   __shared__ float red[2][4][64 * LNG_MAX / 4];   // reduced in four column quarters to stay small
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[LNG_MAX], ab[LNG_MAX];
@@ -162,6 +169,7 @@ __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy
     }
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
+    const float r16 = (dx16 && rowscale16) ? rowscale16[row] : 1.f;
 #pragma unroll
     for (int j = 0; j < LNG_MAX; ++j) {
       const int c = lane + 64 * j;
@@ -169,8 +177,10 @@ __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy
         float o = rs * (g[j] - s1 - xh[j] * s2);
         if (dres) o += dres[row * ldr + c];
         dx[row * lddx + c] = o;
+        if (dx16) dx16[row * lddx16 + c] = (op_t)(o * r16);      // the next GEMM's 16-bit operand: no separate cast pass
       } else if (c < Cpad) {
         dx[row * lddx + c] = 0.f;
+        if (dx16) dx16[row * lddx16 + c] = (op_t)0.f;
       }
     }
   }
@@ -879,11 +889,13 @@ extern "C" int64_t pvrl_layernorm_g_bwd_workspace_bytes(int64_t M, int64_t C) {
 
 extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float* x, int64_t ldx,
                                     const float* mean, const float* rstd, const float* gamma, const float* dres,
-                                    int64_t ldr, float* dx, int64_t lddx, int64_t M, int64_t C, int64_t Cpad,
-                                    float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
+                                    int64_t ldr, float* dx, int64_t lddx, void* dx16, int64_t lddx16,
+                                    const float* rowscale16, int64_t M, int64_t C, int64_t Cpad, float* dgamma, float* dbeta,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (M <= 0) return PVRL_OK;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace || C <= 0 || C > 64 * LNG_MAX ||
-      Cpad < C || Cpad > 64 * LNG_MAX || workspace_bytes < pvrl_layernorm_g_bwd_workspace_bytes(M, C))
+      Cpad < C || Cpad > 64 * LNG_MAX || (dx16 && lddx16 < Cpad) ||
+      workspace_bytes < pvrl_layernorm_g_bwd_workspace_bytes(M, C))
     return PVRL_EINVAL;
   long blocks = (M + 3) / 4;
   if (blocks > 1024) blocks = 1024;
@@ -891,13 +903,13 @@ extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32,
   if (dy_is_f32)
     hipLaunchKernelGGL(ln_g_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (int)C, (int)Cpad, part, (long)M);
+                       (op_t*)dx16, (long)lddx16, rowscale16, (int)C, (int)Cpad, part, (long)M);
   else
     hipLaunchKernelGGL(ln_g_bwd_kernel<op_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const op_t*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (int)C, (int)Cpad, part, (long)M);
+                       (op_t*)dx16, (long)lddx16, rowscale16, (int)C, (int)Cpad, part, (long)M);
   PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partials_add_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(partials_add_kernel, dim3((unsigned)((2 * C + PADD_OUT - 1) / PADD_OUT)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)part, (int)blocks, (int)(2 * C), dgamma, dbeta, (int)C);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -957,7 +969,7 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const op_t*)dy, (const op_t*)conv_out,
                      g, gamma, eps, (op_t*)dc_scratch, (op_t*)dqkv, lnpart);
   PVRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partials_add_kernel, dim3((2 * HD + 15) / 16), dim3(256), 0, s, (const float*)lnpart, (int)blocks,
+  hipLaunchKernelGGL(partials_add_kernel, dim3((2 * HD + PADD_OUT - 1) / PADD_OUT), dim3(256), 0, s, (const float*)lnpart, (int)blocks,
                      2 * HD, dgamma, dbeta, HD);
   PVRL_LAUNCH_CHECK();
   const long nin = (long)B * H * T * Hh * Ww;

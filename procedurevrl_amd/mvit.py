@@ -432,8 +432,11 @@ class MViTEngine(GraphReplay):
         dgn, dbn = self._acc_target(enc.norm.weight), self._acc_target(enc.norm.bias)
         dx[Rl:] = om.ln_bwd(dfeat.contiguous().float(), xf[Rl:], Cl, sv["f_mean"], sv["f_rstd"], enc.norm.weight.detach(),
                             dgn, dbn, Cpad=xf.shape[1])
+        dx16 = None
         for i in range(len(enc.blocks) - 1, -1, -1):
-            dx = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B)
+            # the block's last kernel also writes the 16-bit operand copy the block below starts from (its DropPath factor in)
+            nxt = sv["blocks"][i - 1]["rs_m"] if i > 0 else None
+            dx, dx16 = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B, dx16, i > 0, nxt)
             sv["blocks"][i] = None
             if gs is not None:
                 gs.unscale()
@@ -452,7 +455,7 @@ class MViTEngine(GraphReplay):
         if gs is not None:
             gs.end_scaled()
 
-    def _block_bwd(self, i, blk, pl, s, dx2, B):
+    def _block_bwd(self, i, blk, pl, s, dx2, B, dx2_16=None, want16=False, next_rs=None):
         L = lib()
         eps = self.enc.ln_eps
         dim, dout, H = pl["dim"], pl["dim_out"], pl["heads"]
@@ -463,16 +466,15 @@ class MViTEngine(GraphReplay):
         # ---- MLP
         w1 = self._wpad(blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         w2 = self._wpad(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        dyb = ops.cast_scale(dx2, rowscale=s["rs_m"])
+        dyb = dx2_16 if dx2_16 is not None else ops.cast_scale(dx2, rowscale=s["rs_m"])
         self._wgrad(dyb, s["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias, w2)
         du = ops.gemm_nt(dyb, w2.t, L.PVRL_EPI_DGELU, aux=s["u"])
         self._wgrad(du, s["xn2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias, w1)
         dxn2 = ops.gemm_nt(du, w1.t, L.PVRL_EPI_BF16)
-        dx1 = om.ln_bwd(dxn2, s["x1"], dout, s["mean2"], s["rstd2"], P(blk.norm2.weight), self._acc_target(blk.norm2.weight),
-                        self._acc_target(blk.norm2.bias), dres=dx2, Cpad=Cpo)
+        dx1, dx1b = om.ln_bwd(dxn2, s["x1"], dout, s["mean2"], s["rstd2"], P(blk.norm2.weight), self._acc_target(blk.norm2.weight),
+                              self._acc_target(blk.norm2.bias), dres=dx2, Cpad=Cpo, want16=True, rowscale16=s["rs_a"])
         # ---- attention output projection
         wproj = self._wpad(a.proj.weight, a.proj.bias)
-        dx1b = ops.cast_scale(dx1, rowscale=s["rs_a"])
         self._wgrad(dx1b, s["o"], a.proj.weight, a.proj.bias, wproj)
         d_o = ops.gemm_nt(dx1b, wproj.t, L.PVRL_EPI_BF16)
         # ---- pooling attention, rel-pos terms, pooling convs
@@ -503,8 +505,9 @@ class MViTEngine(GraphReplay):
             dxn = ops.gemm_nt(dxsb, wsk.t, L.PVRL_EPI_RESID_F32, aux=dxn)
         else:
             dres = dxs
-        return om.ln_bwd(dxn, s["x"], dim, s["mean1"], s["rstd1"], P(blk.norm1.weight), self._acc_target(blk.norm1.weight),
-                         self._acc_target(blk.norm1.bias), dres=dres, Cpad=Cpi)
+        out = om.ln_bwd(dxn, s["x"], dim, s["mean1"], s["rstd1"], P(blk.norm1.weight), self._acc_target(blk.norm1.weight),
+                        self._acc_target(blk.norm1.bias), dres=dres, Cpad=Cpi, want16=want16, rowscale16=next_rs)
+        return out if want16 else (out, None)
 
 
 class MViTFn(torch.autograd.Function):

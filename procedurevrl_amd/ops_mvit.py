@@ -39,19 +39,22 @@ def ln_fwd(x, C, gamma, beta, eps, out_dtype=OP16, Cpad=None, stats=True):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, C, mean, rstd, gamma, dgamma, dbeta, dres=None, Cpad=None):
-    """-> dx fp32 [M, Cpad] = dres + dLN(dy); dgamma / dbeta (fp32 [C]) are accumulated into."""
+def ln_bwd(dy, x, C, mean, rstd, gamma, dgamma, dbeta, dres=None, Cpad=None, want16=False, rowscale16=None):
+    """-> dx fp32 [M, Cpad] = dres + dLN(dy); dgamma / dbeta (fp32 [C]) are accumulated into.
+    want16: -> (dx, dx16) with dx16 = (rowscale16[row] *) dx in the operand dtype, written by the same kernel."""
     L = lib()
     M = x.shape[0]
     Cpad = C if Cpad is None else Cpad
     dx = torch.empty((M, Cpad), device=x.device, dtype=F32)
+    dx16 = torch.empty((M, Cpad), device=x.device, dtype=OP16) if want16 else None
     assert dy.dtype in (F32, OP16) and dy.stride(1) == 1 and dgamma.dtype == F32 and dgamma.is_contiguous()
     from .ops import workspace
     ws = workspace(L.call("pvrl_layernorm_g_bwd_workspace_bytes", M, C), x.device, "mvit_ln_g")
     L.call("pvrl_layernorm_g_bwd", _ptr(dy), dy.stride(0), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean),
-           _ptr(rstd), _ptr(gamma), _ptr(dres), dres.stride(0) if dres is not None else 0, _ptr(dx), dx.stride(0), M, C,
-           Cpad, _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream())
-    return dx
+           _ptr(rstd), _ptr(gamma), _ptr(dres), dres.stride(0) if dres is not None else 0, _ptr(dx), dx.stride(0),
+           _ptr(dx16), Cpad if want16 else 0, _ptr(rowscale16) if want16 else None, M, C, Cpad, _ptr(dgamma), _ptr(dbeta),
+           _ptr(ws), ws.numel(), _stream())
+    return (dx, dx16) if want16 else dx
 
 
 def pool_out_thw(thw, stride):

@@ -52,6 +52,16 @@ def check_mvit_im2col_ln():
         out.append((f"ln_g bwd dx C={C}", rel(dx[:, :C], xr.grad + dres[:, :C]), 1e-5))
         out.append((f"ln_g bwd dgamma C={C}", rel(dg, gr.grad), 1e-5))
         out.append((f"ln_g bwd dbeta C={C}", rel(db, br.grad), 1e-5))
+        # the fused 16-bit operand copy (what the next backward GEMM reads): rowscale * dx rounded once, zero padding
+        rsc = 0.5 + torch.rand(M, generator=g)
+        dg2 = torch.zeros(C, device=DEV); db2 = torch.zeros(C, device=DEV)
+        dxb, dx16 = om.ln_bwd(dyp.to(DEV), xx.to(DEV), C, mean, rstd, gm.to(DEV), dg2, db2, dres=dres.to(DEV), Cpad=Cpad,
+                              want16=True, rowscale16=rsc.to(DEV))
+        prod = dxb[:, :C] * rsc.to(DEV)[:, None]            # one rounding of the product (v_fma_mix: not fp32 first)
+        half_ulp = 2.0 ** -8 if BF == torch.bfloat16 else 2.0 ** -11
+        out.append((f"ln_g bwd fused 16-bit copy C={C}", float(((dx16[:, :C].float() - prod).abs() / prod.abs().clamp_min(1e-3)).max()), 1.01 * half_ulp))
+        out.append((f"ln_g bwd fused copy: fp32 dx unchanged, padding zero C={C}",
+                    0.0 if torch.equal(dxb, dx) and (Cpad == C or float(dx16[:, C:].float().abs().max()) == 0.0) else 1.0, 0.0))
         yb, _, _ = om.ln_fwd(xx.to(DEV), C, gm.to(DEV), bt.to(DEV), 1e-6, Cpad=Cpad)
         out.append((f"ln_g fwd bf16 C={C}", rel(yb[:, :C], yr), 4e-3))
     return out
