@@ -485,7 +485,9 @@ class MViTEngine(GraphReplay):
         om.rel_bwd(drel, s["q"], dq, B * H, q_thw, k_thw, P(a.rel_pos_h), P(a.rel_pos_w), P(a.rel_pos_t), ih, iw, it,
                    self._acc_target(a.rel_pos_h), self._acc_target(a.rel_pos_w), self._acc_target(a.rel_pos_t))
         qkv = s["qkv"]
-        dqkv = torch.zeros_like(qkv)
+        dqkv = torch.empty_like(qkv)       # the three pool backwards overwrite every row of their column slices
+        if qkv.shape[1] > 3 * dout:
+            dqkv[:, 3 * dout:].zero_()     # zero padding columns of the GEMM operand
         pw = lambda c: P(c.weight).reshape(HD, 27)
         for (d, c, col0, st, pool, norm) in ((dq, s["cq"], 0, sq, a.pool_q, a.norm_q), (dk, s["ck"], dout, skv, a.pool_k, a.norm_k),
                                              (dv, s["cv"], 2 * dout, skv, a.pool_v, a.norm_v)):

@@ -170,8 +170,9 @@ def rel_bwd(drel, Q, dQ, BH, q_thw, k_thw, Rh, Rw, Rt, ih, iw, it, dRh, dRw, dRt
 def attn_fwd(q, k, v, relp, B, H, Lq, k_thw, scale, ldo):
     """relp = rel_fwd(..., out_scale=1/scale) -> (o bf16 [B*Lq + B, ldo] token-major (zeros beyond H*96), lse fp32 [B*H, Lq+1])"""
     L = lib()
-    o = torch.zeros((B * Lq + B, ldo), device=q.device, dtype=OP16) if ldo > H * HD else \
-        torch.empty((B * Lq + B, ldo), device=q.device, dtype=OP16)
+    o = torch.empty((B * Lq + B, ldo), device=q.device, dtype=OP16)
+    if ldo > H * HD:
+        o[:, H * HD:].zero_()          # the kernel writes the H*96 real columns of every row
     lse = torch.empty((B * H, Lq + 1), device=q.device, dtype=F32)
     assert relp.dtype == OP16 and relp.shape[-1] == 2 * rel_width(k_thw)
     L.call("pvrl_mvit_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(relp), _ptr(keymap(k_thw, q.device)), B, H, Lq, *k_thw,

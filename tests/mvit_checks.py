@@ -104,6 +104,7 @@ def check_mvit_pool():
         out.append((f"pool fwd tokens {thw}/{stride}", rel(y[:, :Lo], yr2[:, 1:]), 6e-3))
         out.append((f"pool fwd cls {thw}/{stride}", rel(y[:, Lo], yr2[:, 0]), 6e-3))
         dqkv = torch.zeros(B * L + B, ld, device=DEV, dtype=BF)
+        dqkv[:, col0:col0 + dout] = 777.0      # the backward OVERWRITES every row of its slice (the engine hands it torch.empty)
         dw = torch.zeros(96, 27, device=DEV); dg = torch.zeros(96, device=DEV); db = torch.zeros(96, device=DEV)
         om.pool_bwd(dy.to(DEV, BF), c, qkv.to(DEV, BF), dqkv, col0, B, H, thw, stride,
                     w.reshape(96, 27).contiguous().to(DEV), gm.to(DEV), 1e-6, dw, dg, db)
