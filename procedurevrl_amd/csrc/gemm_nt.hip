@@ -96,13 +96,17 @@ static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
 }
 
 // Tile selection: 256x256 / 16 waves for the encoder's 50k-row GEMMs (M >= 4096 and N a multiple of 256), 256x128 for
-// mid-sized M, 128x128 / 4 waves (two workgroups per CU) for the small-M stacks (order transformer, CLIP text).
+// mid-sized M, 128x128 / 4 waves (two workgroups per CU) for the small-M stacks (order transformer, CLIP text) and for
+// every N that is not a multiple of 256 (MViT's 128 / 384 / 640 / 1152-wide layers: 128x128 measured 5-16 % ahead of
+// 256x128 on 12 of the 14 such shapes of an MViTv2-S step, tools/probe/mvit_gemm_tiles.py; the two-output GELU
+// epilogue is the exception).
 // (Cutting the ragged last wave of 256x256 tiles off into a 128x128-tile launch was measured 12 % SLOWER: the second
 //  launch serialises behind the first; one launch with a partly idle last wave wins.)
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
+  constexpr bool two_out = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
   if (p.M >= 4096 && p.N % 256 == 0) return launch_tile<EPI, 4, 4>(p, s);
-  if (p.M >= 2048) return launch_tile<EPI, 4, 2>(p, s);
+  if (p.M >= 2048 && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);
 }
 
