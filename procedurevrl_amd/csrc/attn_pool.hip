@@ -82,6 +82,47 @@ __device__ __forceinline__ void pair_lstore(const PairRegs& t, const PairMap& m,
 __device__ __forceinline__ long tok_row(const PA& p, int b, int query) {
   return query < p.Lq ? (long)b * p.Lq + query : (long)p.B * p.Lq + b;
 }
+// Fragment addresses split into a per-lane part (computed once) and a compile-time part (tile row block u, K step, column
+// block): the XOR swizzles of pb_off / bl_off / rm_off only ever flip a lane-dependent bit against an even constant, so
+// every ds_read in the key loop is `buffer base + lane part` with an immediate offset instead of ~30 address VALU ops per tile.
+struct FragLanes {
+  int row96, tr96[2];      // [32][96] tiles (K, V, Q, dO): row fragment; transposed fragment of an even / odd column block
+  int row64, tr64[2];      // [32][64] key-map tile
+  int rm[2];               // [32][64] row-major rel tile(s) of the dK/dV kernel: 16-byte slot group 0 / 1
+};
+__device__ __forceinline__ FragLanes frag_lanes(int lane) {
+  const int i = lane & 15, q4 = lane >> 4;
+  const int b = (i >> 2) & 1, qb = q4 & 1, sw = (i >> 1) & 7;
+  FragLanes f;
+  f.row96 = ((i >> 2) * NCB + ((q4 >> 1) ^ b)) * 128 + (i & 3) * 32 + (q4 & 1) * 16;
+  f.tr96[0] = (q4 * NCB + qb) * 128 + i * 8;
+  f.tr96[1] = (q4 * NCB - qb) * 128 + i * 8;
+  f.row64 = ((i >> 2) * 4 + ((q4 >> 1) ^ b)) * 128 + (i & 3) * 32 + (q4 & 1) * 16;
+  f.tr64[0] = (q4 * 4 + qb) * 128 + i * 8;
+  f.tr64[1] = (q4 * 4 - qb) * 128 + i * 8;
+  f.rm[0] = i * 128 + ((q4 ^ sw) << 4);
+  f.rm[1] = i * 128 + (((4 + q4) ^ sw) << 4);
+  return f;
+}
+// = pb_row_frag(tile, 16 u + i, 4 ks + q4)
+__device__ __forceinline__ opx8 row96_frag(const char* tile, const FragLanes& f, int u, int ks) {
+  return *reinterpret_cast<const opx8*>(tile + f.row96 + u * (4 * NCB * 128) + ks * 256);
+}
+// = pb_tr_frag(tile, ct, lane)
+__device__ __forceinline__ opx8 tr96_frag(const char* tile, const FragLanes& f, int ct) {
+  const int o = f.tr96[ct & 1] + ct * 128;
+  return tr_frag8(tile, o, o + 4 * NCB * 128);
+}
+// = bl_row_frag(tile, 16 u + i, 4 js + q4)
+__device__ __forceinline__ opx8 row64_frag(const char* tile, const FragLanes& f, int u, int js) {
+  return *reinterpret_cast<const opx8*>(tile + f.row64 + u * 2048 + js * 256);
+}
+// = bl_frag(tile, 0, ct, lane)
+__device__ __forceinline__ opx8 tr64_frag(const char* tile, const FragLanes& f, int ct) {
+  const int o = f.tr64[ct & 1] + ct * 128;
+  return tr_frag8(tile, o, o + 2048);
+}
+
 // the (rel / scale) operand of one query: k slots j = 32 js + 8 q4 .. + 8, hi and lo halves; zero for the cls query
 template <int NJS>
 __device__ __forceinline__ void rel_frags(const PA& p, int bh, int query, int q4, opx8 (&rh)[NJS], opx8 (&rl)[NJS]) {
@@ -119,10 +160,11 @@ __global__ __launch_bounds__(256) void pattn_keymap_kernel(int kt, int kh, int k
 // ------------------------------------------------------------------------------------------------- forward
 constexpr int FWD_BUF = 2 * TILE_BYTES + ET_BYTES;      // [K | V | E] per buffer
 template <int NJS>
-__global__ __launch_bounds__(256, 3) void pattn_fwd_kernel(PA p) {
+__global__ __launch_bounds__(256, 4) void pattn_fwd_kernel(PA p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
+  const FragLanes fl = frag_lanes(lane);
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int query = blockIdx.x * 64 + wave * 16 + i;
@@ -166,10 +208,10 @@ __global__ __launch_bounds__(256, 3) void pattn_fwd_kernel(PA p) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks)
-        s = MFMA_16x16x32(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
+        s = MFMA_16x16x32(row96_frag(Kb, fl, u, ks), qf[ks], s, 0, 0, 0);
 #pragma unroll
       for (int js = 0; js < NJS; ++js) {
-        const opx8 ef = bl_row_frag(Eb, u * 16 + i, js * 4 + q4);
+        const opx8 ef = row64_frag(Eb, fl, u, js);
         s = MFMA_16x16x32(ef, rh[js], s, 0, 0, 0);
         s = MFMA_16x16x32(ef, rl[js], s, 0, 0, 0);
       }
@@ -205,7 +247,7 @@ __global__ __launch_bounds__(256, 3) void pattn_fwd_kernel(PA p) {
       for (int dt = 0; dt < 6; ++dt) oacc[dt] *= alpha;
     }
 #pragma unroll
-    for (int dt = 0; dt < 6; ++dt) oacc[dt] = MFMA_16x16x32(pb_tr_frag(Vb, dt, lane), pf.v, oacc[dt], 0, 0, 0);
+    for (int dt = 0; dt < 6; ++dt) oacc[dt] = MFMA_16x16x32(tr96_frag(Vb, fl, dt), pf.v, oacc[dt], 0, 0, 0);
     if (more) {
       char* nb = smem + ((t + 1) & 1) * FWD_BUF;
       pair_lstore(rkv, pm, nb);
@@ -238,6 +280,7 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p
   __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
+  const FragLanes fl = frag_lanes(lane);
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int query = blockIdx.x * 64 + wave * 16 + i;
@@ -296,12 +339,12 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        s = MFMA_16x16x32(pb_row_frag(Kb, u * 16 + i, ks * 4 + q4), qf[ks], s, 0, 0, 0);
-        dp = MFMA_16x16x32(pb_row_frag(Vb, u * 16 + i, ks * 4 + q4), df[ks], dp, 0, 0, 0);
+        s = MFMA_16x16x32(row96_frag(Kb, fl, u, ks), qf[ks], s, 0, 0, 0);
+        dp = MFMA_16x16x32(row96_frag(Vb, fl, u, ks), df[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int js = 0; js < NJS; ++js) {
-        const opx8 ef = bl_row_frag(Eb, u * 16 + i, js * 4 + q4);
+        const opx8 ef = row64_frag(Eb, fl, u, js);
         s = MFMA_16x16x32(ef, rh[js], s, 0, 0, 0);
         s = MFMA_16x16x32(ef, rl[js], s, 0, 0, 0);
       }
@@ -323,10 +366,10 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p
     for (int e = 0; e < 4; ++e) sf.u[e] = pack_opx2(ds[2 * e], ds[2 * e + 1]);
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt)
-      dq[dt] = MFMA_16x16x32(pb_tr_frag(Kb, dt, lane), sf.v, dq[dt], 0, 0, 0);
+      dq[dt] = MFMA_16x16x32(tr96_frag(Kb, fl, dt), sf.v, dq[dt], 0, 0, 0);
     if (qpatch_any) {                                  // d rel[query][j] += sum_key E[key][j] dS[key][query]
 #pragma unroll
-      for (int jt = 0; jt < NJT; ++jt) dracc[jt] = MFMA_16x16x32(bl_frag(Eb, 0, jt, lane), sf.v, dracc[jt], 0, 0, 0);
+      for (int jt = 0; jt < NJT; ++jt) dracc[jt] = MFMA_16x16x32(tr64_frag(Eb, fl, jt), sf.v, dracc[jt], 0, 0, 0);
     }
     if (more) {
       char* nb = smem + ((t + 1) & 1) * FWD_BUF;
@@ -372,6 +415,7 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
   __shared__ __attribute__((aligned(16))) float lse_s[2][KT], dl_s[2][KT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
+  const FragLanes fl = frag_lanes(lane);
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
   const int key = blockIdx.x * 64 + wave * 16 + i;
@@ -464,15 +508,15 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        s = MFMA_16x16x32(pb_row_frag(Qb, u * 16 + i, ks * 4 + q4), kf[ks], s, 0, 0, 0);
-        dp = MFMA_16x16x32(pb_row_frag(Db, u * 16 + i, ks * 4 + q4), vf[ks], dp, 0, 0, 0);
+        s = MFMA_16x16x32(row96_frag(Qb, fl, u, ks), kf[ks], s, 0, 0, 0);
+        dp = MFMA_16x16x32(row96_frag(Db, fl, u, ks), vf[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int js = 0; js < NJS; ++js)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-          const int cid = hl * 4 * NJS + 4 * js + q4;
-          const opx8 rf = *reinterpret_cast<const opx8*>(Rb + (cid >> 3) * 4096 + rm_off(u * 16 + i, cid & 7));
+          // chunk cid = hl * 4 NJS + 4 js + q4 of row 16 u + i: image cid / 8, swizzled slot cid % 8
+          const opx8 rf = *reinterpret_cast<const opx8*>(Rb + fl.rm[NJS == 1 ? hl : js] + u * 2048 + (NJS == 1 ? 0 : hl * 4096));
           s = MFMA_16x16x32(rf, ef[js], s, 0, 0, 0);
         }
       // s[r] = S[query = t*32 + 16u + 4*q4 + r][key] / scale
@@ -493,8 +537,8 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
     }
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
-      dv[dt] = MFMA_16x16x32(pb_tr_frag(Db, dt, lane), pf.v, dv[dt], 0, 0, 0);
-      dk[dt] = MFMA_16x16x32(pb_tr_frag(Qb, dt, lane), sf.v, dk[dt], 0, 0, 0);
+      dv[dt] = MFMA_16x16x32(tr96_frag(Db, fl, dt), pf.v, dv[dt], 0, 0, 0);
+      dk[dt] = MFMA_16x16x32(tr96_frag(Qb, fl, dt), sf.v, dk[dt], 0, 0, 0);
     }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * KV_BUF;
