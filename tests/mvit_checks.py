@@ -11,6 +11,13 @@ from oracle import mvit_oracle as mo
 from procedurevrl_amd._lib import OPERAND
 BF = torch.bfloat16 if OPERAND == "bf16" else torch.float16
 DEV = "cuda:0"
+# End-to-end tolerances per operand flavour, set to <= 2x what is observed on MI355X (gpurun_out/mvit_obs_*.txt, round 2):
+# bf16: features / logits 4.9-6.2e-3, losses <= 1.1e-3, gradients <= 1.8e-2 (rel_pos_h 4.2e-2: signed sums, cancellation);
+# f16 (the flavour held to north_star's 1e-3): features / logits 6.1-7.8e-4, losses <= 1.3e-4, gradients <= 1.8e-3.
+F16 = OPERAND != "bf16"
+TOL_FEAT = 1e-3 if F16 else 1e-2
+TOL_LOSS = 1e-3 if F16 else 2.5e-3
+GSC = 1.0 / 3.0 if F16 else 1.0          # scale of every gradient tolerance below (f16: 8x smaller rounding, ~4x smaller errors)
 
 
 def bf(x):
@@ -279,7 +286,7 @@ def check_mvit_encoder_small_golden():
     out = [("mvit state_dict keys == reference", float(sorted(vt.video_encoder.state_dict().keys()) != g["keys"]), 0.0)]
     model.train()
     feat = vt.forward_features(g["x"].to(DEV))
-    out.append(("mvit small features vs reference", rel(feat, g["feat"]), 1e-2))
+    out.append(("mvit small features vs reference", rel(feat, g["feat"]), TOL_FEAT))
     (feat * g["gout"].to(DEV)).sum().backward()
     params = dict(vt.video_encoder.named_parameters())
     for n, ref in g["grads"].items():
@@ -289,11 +296,11 @@ def check_mvit_encoder_small_golden():
         if n.endswith("norm_k.bias"):
             # a common shift of every key is softmax-invariant: the true gradient is 0 (the reference holds 4e-6 of fp32
             # noise); the bf16 path's residue is bounded against the sibling gain gradient instead
-            tol = 5e-2 * float(g["grads"].get(n.replace("norm_k.bias", "norm_q.weight"), ref).norm()) + 1e-3
+            tol = GSC * (5e-2 * float(g["grads"].get(n.replace("norm_k.bias", "norm_q.weight"), ref).norm()) + 1e-3)
         elif "rel_pos" in n:
-            tol = 6e-2 * float(ref.norm()) + 1e-4 * ref.numel() ** 0.5   # signed sums over all queries: cancellation
+            tol = GSC * (6e-2 * float(ref.norm()) + 1e-4 * ref.numel() ** 0.5)   # signed sums over all queries: cancellation
         else:
-            tol = 3e-2 * float(ref.norm()) + 1e-4 * ref.numel() ** 0.5
+            tol = GSC * (3e-2 * float(ref.norm()) + 1e-4 * ref.numel() ** 0.5)
         out.append((f"mvit small d {n} (abs err / allowed)", err / tol, 1.0))
     return out
 
@@ -327,19 +334,19 @@ def check_mvit_e2e_golden():
     rng = dict(order=dict(mask_inds=f["rng"]["mask_inds"].to(DEV), pad_start=f["rng"]["pad_start"].to(DEV),
                           noises=[n.to(DEV) for n in f["rng"]["noises"]]), rand_inds=f["rng"]["rand_inds"].to(DEV))
     pred, teacher, mse = model([f["inputs"].to(DEV), meta], rng=rng)
-    out += [("mvit e2e pred logits vs reference", rel(pred, f["pred"]), 1.5e-2),
-            ("mvit e2e teacher logits vs reference", rel(teacher, f["teacher"]), 1e-2),
-            ("mvit e2e mse target vs reference", rel(mse[0], f["mse0"]), 1e-2),
-            ("mvit e2e mse pred vs reference", rel(mse[1], f["mse1"]), 1e-2)]
+    out += [("mvit e2e pred logits vs reference", rel(pred, f["pred"]), TOL_FEAT),
+            ("mvit e2e teacher logits vs reference", rel(teacher, f["teacher"]), TOL_FEAT),
+            ("mvit e2e mse target vs reference", rel(mse[0], f["mse0"]), TOL_FEAT),
+            ("mvit e2e mse pred vs reference", rel(mse[1], f["mse1"]), TOL_FEAT)]
     loss, l1, l2 = pretrain_loss(pred, teacher, mse, cfg)
-    out.append(("mvit e2e loss1 (KL)", abs(float(l1.detach()) - f["loss1"]) / abs(f["loss1"]), 2e-2))
-    out.append(("mvit e2e loss2 (MSE)", abs(float(l2.detach()) - f["loss2"]) / abs(f["loss2"]), 2e-2))
+    out.append(("mvit e2e loss1 (KL)", abs(float(l1.detach()) - f["loss1"]) / abs(f["loss1"]), TOL_LOSS))
+    out.append(("mvit e2e loss2 (MSE)", abs(float(l2.detach()) - f["loss2"]) / abs(f["loss2"]), TOL_LOSS))
     for p in model.parameters():
         p.grad = None
     loss.backward()
     named = dict(model.named_parameters())
     for k, g in f["grads"].items():
-        tol = 6e-2 if "rel_pos" in k else 4e-2
+        tol = (6e-2 if "rel_pos" in k else 3e-2) * (0.4 if F16 and "rel_pos" in k else (0.1 if F16 else 1.0))
         out.append((f"mvit e2e grad {k[6:]}", rel(named[k].grad, g), tol))
     return out
 
@@ -355,13 +362,13 @@ def check_mvit_droppath_golden():
     model.train()
     dp = [None if d is None else (d[0].to(DEV), d[1].to(DEV)) for d in tg.mvit_droppath_scales(g)]
     feat = vt.forward_features(g["x"].to(DEV), droppath=dp)
-    out = [("mvit droppath features vs reference", rel(feat, g["feat"]), 1e-2)]
+    out = [("mvit droppath features vs reference", rel(feat, g["feat"]), TOL_FEAT)]
     (feat * g["gout"].to(DEV)).sum().backward()
     params = dict(vt.video_encoder.named_parameters())
     for n, ref in g["grads"].items():
         got = params[n].grad
         got = got[:64] if got.dim() == 2 else got
-        out.append((f"mvit droppath d {n}", rel(got, ref), 3e-2))
+        out.append((f"mvit droppath d {n}", rel(got, ref), 2.5e-3 if F16 else 2e-2))
     return out
 
 
@@ -373,7 +380,7 @@ def check_mvit_s_features():
     x = torch.randn(1, 3, 16, 224, 224, generator=torch.Generator().manual_seed(g["x_seed"]))
     with torch.no_grad():
         feat = model.model.forward_features(x.to(DEV))
-    return [("mvit-S features vs reference", rel(feat, g["feat"]), 1.5e-2)]
+    return [("mvit-S features vs reference", rel(feat, g["feat"]), TOL_FEAT)]
 
 
 def check_mvit_pretrain_steps():
@@ -470,7 +477,7 @@ def check_mvit_s_full_size_step_vs_oracle():
     ref = mo.forward_features(p, x, g["mvit"])
     (ref * gout).sum().backward()
     feat = vt.forward_features(x.to(DEV))
-    out = [("mvit-S full-size features vs oracle", rel(feat, ref), 1.5e-2)]
+    out = [("mvit-S full-size features vs oracle", rel(feat, ref), TOL_FEAT)]
     (feat * gout.to(DEV)).sum().backward()
     params = dict(vt.video_encoder.named_parameters())
     for n in ("patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.pool_q.weight", "blocks.1.proj.weight",
@@ -480,7 +487,7 @@ def check_mvit_s_full_size_step_vs_oracle():
         err = float((params[n].grad.detach().float().cpu() - r).norm())
         # the stem's gradient has passed through all 16 blocks of bf16 activations / gradients: observed 5.9e-2 relative
         # (2.1e-2 after 4 blocks in the reduced geometry); every later parameter is below 3e-2
-        tol = 8e-2 if n.startswith("patch_embed") else 5e-2
+        tol = GSC * (8e-2 if n.startswith("patch_embed") else 5e-2)
         out.append((f"mvit-S full-size d {n} (abs err / allowed)", err / (tol * float(r.norm()) + 1e-5 * r.numel() ** 0.5), 1.0))
     return out
 
