@@ -7,6 +7,7 @@
 //  * decomposed relative-position terms rel[q][j] = q . R_j (attention.py:67-159) and their gradients
 // Token layout everywhere: rows [0, B*L) are the patch tokens ordered (b, t, h, w); rows [B*L, B*L+B) the cls tokens.
 // Channel widths are padded to multiples of 128 (zero columns) so the bf16 MFMA GEMMs of gemm_nt.hip / gemm_tn.hip apply.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/pvrl.h"
 
@@ -226,6 +227,22 @@ __device__ __forceinline__ void ld6(const op_t* p, float* v) {
     op_unpack2(w, v[2 * e], v[2 * e + 1]);
   }
 }
+// the raw 12 bytes / their unpacking, split so that a kernel can issue ALL its neighbour loads before the first use:
+// a load guarded by `if (outside) continue;` makes the compiler wait for each one in turn (s_waitcnt vmcnt(0) per
+// neighbour: nine serial round trips per frame, measured 77 % of the wave cycles waiting); loading a clamped address
+// unconditionally and zeroing the words of an outside neighbour with a select keeps all nine in flight.
+struct Raw6 { unsigned w[3]; };
+__device__ __forceinline__ Raw6 ld6_raw(const op_t* p) {
+  const unsigned* u = reinterpret_cast<const unsigned*>(p);
+  Raw6 r;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) r.w[e] = u[e];
+  return r;
+}
+__device__ __forceinline__ void unpack6(const Raw6& r, bool ok, float* v) {
+#pragma unroll
+  for (int e = 0; e < 3; ++e) op_unpack2(ok ? r.w[e] : 0u, v[2 * e], v[2 * e + 1]);
+}
 __device__ __forceinline__ void st6(op_t* p, const float* v) {
   unsigned* u = reinterpret_cast<unsigned*>(p);
 #pragma unroll
@@ -328,6 +345,7 @@ __device__ __forceinline__ void pool_ln_store(const float (&acc)[6], const float
   st6(ydst, o);
 }
 
+template <bool DENSE>
 __global__ __launch_bounds__(256) void pool_fwd_t_kernel(const op_t* __restrict__ qkv, PoolGeom g,
                                                          const float* __restrict__ w, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, op_t* __restrict__ y,
@@ -370,12 +388,26 @@ __global__ __launch_bounds__(256) void pool_fwd_t_kernel(const op_t* __restrict_
     for (int e = 0; e < 6; ++e) { aP[e] = 0.f; aC[e] = 0.f; aN[e] = 0.f; }
     for (int ti = 0; ti < g.T; ++ti) {
       const op_t* pb = base + (long)ti * plane * g.ld;
+      // DENSE: all nine neighbour loads issued together from clamped addresses, an outside neighbour zeroed by a select --
+      // the form for the strided (k / v) pools, whose few columns cannot hide nine serial round trips (36 -> 23 us);
+      // otherwise the loads are guarded (one wait each, but 118 VGPRs = 4 waves / SIMD: ahead on the dense stride-1 planes)
+      Raw6 raw[9];
+      int wbase = c0;
+      if constexpr (DENSE) {
+#pragma unroll
+        for (int n = 0; n < 9; ++n) raw[n] = ld6_raw(pb + (long)max(noff[n], 0) * g.ld);
+        asm volatile("" : "+v"(wbase));           // opaque per frame: the 162 weights stay in LDS instead of 162 hoisted VGPRs
+      }
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
-        if (noff[n] < 0) continue;
         float v[6];
-        ld6(pb + (long)noff[n] * g.ld, v);
-        const float* w0 = ws + n * HD + c0;                            // tap (a, yy, xx) at [(a*9 + n)][c]
+        if constexpr (DENSE) {
+          unpack6(raw[n], noff[n] >= 0, v);
+        } else {
+          if (noff[n] < 0) continue;
+          ld6(pb + (long)noff[n] * g.ld, v);
+        }
+        const float* w0 = ws + n * HD + wbase;                         // tap (a, yy, xx) at [(a*9 + n)][c]
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
           aN[e] = fmaf(v[e], w0[e], aN[e]);                            // a = 0: this frame is the one BEFORE output ti + 1
@@ -506,6 +538,7 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const op_t* __restrict_
 
 // The same for temporal stride 1, sliding along t (see pool_fwd_t_kernel): 16 lanes own one INPUT column (b, h, yi, xi); the
 // (at most 9) outputs of a frame that touch it are loaded once and feed the running sums of dX at t - 1, t and t + 1.
+template <bool DENSE>
 __global__ __launch_bounds__(256) void pool_dgrad_t_kernel(const op_t* __restrict__ dc, PoolGeom g,
                                                            const float* __restrict__ w, op_t* __restrict__ dqkv) {
   __shared__ float ws[27 * HD];
@@ -536,12 +569,25 @@ __global__ __launch_bounds__(256) void pool_dgrad_t_kernel(const op_t* __restric
     for (int e = 0; e < 6; ++e) { aP[e] = 0.f; aC[e] = 0.f; aN[e] = 0.f; }
     for (int to = 0; to < g.T; ++to) {
       const op_t* pb = base + (long)to * HoWo * HD;
+      // DENSE (spatial stride 1: all nine taps exist away from the border): see pool_fwd_t_kernel; with stride 2 / 4 / 8 an input meets
+      // at most four / one or two outputs and skipping the others (guarded loads) does less work (measured per stride)
+      Raw6 raw[9];
+      int wbase = c0;
+      if constexpr (DENSE) {
+#pragma unroll
+        for (int n = 0; n < 9; ++n) raw[n] = ld6_raw(pb + (long)max(noff[n], 0) * HD);
+        asm volatile("" : "+v"(wbase));
+      }
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
-        if (noff[n] < 0) continue;
         float v[6];
-        ld6(pb + (long)noff[n] * HD, v);
-        const float* w0 = ws + n * HD + c0;
+        if constexpr (DENSE) {
+          unpack6(raw[n], noff[n] >= 0, v);
+        } else {
+          if (noff[n] < 0) continue;
+          ld6(pb + (long)noff[n] * HD, v);
+        }
+        const float* w0 = ws + n * HD + wbase;
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
           aP[e] = fmaf(v[e], w0[e], aP[e]);                            // a = 0: output frame `to` reads input frame to - 1
@@ -663,10 +709,14 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_t_kernel(const op
     f32x4 dP = zero, dC = ld4bf(db), dN = g.T > 1 ? ld4bf(db + (long)HoWo * HD) : zero;   // dc of output frames ti-1, ti, ti+1
     for (int ti = 0; ti < g.T; ++ti) {
       const op_t* pb = xb + (long)ti * plane * g.ld;
+      u32x2 raw[9];
+#pragma unroll
+      for (int n = 0; n < 9; ++n) raw[n] = *reinterpret_cast<const u32x2*>(pb + (long)max(noff[n], 0) * g.ld);   // all nine in flight
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
-        if (noff[n] < 0) continue;
-        const f32x4 xv = ld4bf(pb + (long)noff[n] * g.ld);
+        const bool ok = noff[n] >= 0;
+        f32x4 xv;
+        { float a, b2; op_unpack2(ok ? raw[n][0] : 0u, a, b2); xv[0] = a; xv[1] = b2; op_unpack2(ok ? raw[n][1] : 0u, a, b2); xv[2] = a; xv[3] = b2; }
         acc[n] += dN * xv;                 // tap a = 0: frame ti is the first input frame of output ti + 1
         acc[9 + n] += dC * xv;             // a = 1
         acc[18 + n] += dP * xv;            // a = 2
@@ -936,8 +986,12 @@ extern "C" int pvrl_mvit_pool_fwd(const void* qkv, int64_t ld, int64_t col0, int
   if (ntok >= (1L << 27)) return PVRL_EINVAL;         // 16 lanes per token, 32-bit token arithmetic in the kernel
   if (g.st == 1) {      // temporal stride 1 (every MViTv2 pooling operator): one 16-lane group per output column, sliding along t
     const long ncol = (long)B * H * ((long)g.Ho * g.Wo + 1);
-    hipLaunchKernelGGL(pool_fwd_t_kernel, dim3(grid_for(ncol * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
-                       w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
+    if (g.sh > 1 || g.sw > 1)
+      hipLaunchKernelGGL(pool_fwd_t_kernel<true>, dim3(grid_for(ncol * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv,
+                         g, w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
+    else
+      hipLaunchKernelGGL(pool_fwd_t_kernel<false>, dim3(grid_for(ncol * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv,
+                         g, w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
   } else {
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(ntok * 16)), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, g,
                        w, gamma, beta, eps, (op_t*)y, (op_t*)conv_out);
@@ -978,14 +1032,18 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
     const dim3 dg(grid_for(nin * 16)), db(256);
     const int S = (st == 1 && sh == sw && (sh == 1 || sh == 2 || sh == 4 || sh == 8)) ? (int)sh : 0;
 #define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const op_t*)dc_scratch, g, w, (op_t*)dqkv)
-    if (st == 1)         // temporal stride 1: one 16-lane group per input column, sliding along t
-      hipLaunchKernelGGL(pool_dgrad_t_kernel, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch, g, w,
-                         (op_t*)dqkv);
+    if (st == 1 && sh == 1 && sw == 1)         // temporal stride 1: one 16-lane group per input column, sliding along t
+      hipLaunchKernelGGL(pool_dgrad_t_kernel<true>, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch,
+                         g, w, (op_t*)dqkv);
+    else if (st == 1)
+      hipLaunchKernelGGL(pool_dgrad_t_kernel<false>, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch,
+                         g, w, (op_t*)dqkv);
     else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
 #undef DGRAD
   }
   PVRL_LAUNCH_CHECK();
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
+  { static const long cap = getenv("PVRL_PW_CAP") ? atol(getenv("PVRL_PW_CAP")) : PW_MAX_WG; if (wb > cap) wb = cap; }
   if (wb > PW_MAX_WG) wb = PW_MAX_WG;
   if (wb < 1) wb = 1;
   // measured per block of MViTv2-S (tools/probe/mvit_pool_times.py): the t-sliding form wins on the small planes with spatial

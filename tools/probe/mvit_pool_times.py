@@ -36,7 +36,10 @@ def timeit(fn, reps=5):
 
 
 tot_f = tot_b = 0.0
+ONLY = [int(v) for v in os.environ.get("PVRL_POOL_BLOCKS", "").split(",") if v]      # e.g. PVRL_POOL_BLOCKS=4 under rocprofv3
 for i, pl in enumerate(plan):
+    if ONLY and i not in ONLY:
+        continue
     H, dout, thw = pl["heads"], pl["dim_out"], tuple(pl["in_thw"])
     L = thw[0] * thw[1] * thw[2]
     ld = om.pad128(3 * dout)
