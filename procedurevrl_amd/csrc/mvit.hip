@@ -70,39 +70,58 @@ __device__ __forceinline__ void st_val(op_t* p, float v) { *p = (op_t)v; }
 __device__ __forceinline__ float ld_val(const float* p) { return *p; }
 __device__ __forceinline__ float ld_val(const op_t* p) { return (float)*p; }
 
-template <typename TO>
+// One wave per row, NJ = ceil(C / 64) channels per lane, RPI independent rows per loop iteration: with one row and twelve
+// guarded chunks per iteration (the first version) a wave had two useful loads in flight at C = 96 and walked 440 scalar
+// branch instructions per row.  Loads are unconditional (clamped column / row), masked by selects.
+template <typename TO, int NJ, int RPI>
 __global__ __launch_bounds__(256) void ln_g_fwd_kernel(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, TO* __restrict__ y, long ldy, int C, int Cpad,
                                                        float* __restrict__ mean, float* __restrict__ rstd, long M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-    float v[LNG_MAX];
-    float s = 0.f;
+  float gm[NJ], bt[NJ];
+  int cc[NJ];
 #pragma unroll
-    for (int j = 0; j < LNG_MAX; ++j) {
-      const int c = lane + 64 * j;
-      v[j] = c < C ? x[row * ldx + c] : 0.f;
-      s += v[j];
-    }
-    const float mu = wave_sum(s) / (float)C;
-    float q = 0.f;
+  for (int j = 0; j < NJ; ++j) {
+    cc[j] = min(lane + 64 * j, C - 1);
+    gm[j] = gamma[cc[j]]; bt[j] = beta[cc[j]];
+  }
+  const float invC = 1.f / (float)C;
+  const long stride = (long)gridDim.x * 4;
+  for (long row0 = (long)blockIdx.x * 4 + wave; row0 < M; row0 += stride * RPI) {
+    float v[RPI][NJ];
 #pragma unroll
-    for (int j = 0; j < LNG_MAX; ++j) {
-      const int c = lane + 64 * j;
-      const float d = c < C ? v[j] - mu : 0.f;
-      q += d * d;
-    }
-    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    for (int r = 0; r < RPI; ++r) {
+      const long row = min(row0 + r * stride, M - 1);
 #pragma unroll
-    for (int j = 0; j < LNG_MAX; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) st_val(y + row * ldy + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
-      else if (c < Cpad) st_val(y + row * ldy + c, 0.f);
+      for (int j = 0; j < NJ; ++j) v[r][j] = x[row * ldx + cc[j]];
     }
-    if (lane == 0) {
-      if (mean) mean[row] = mu;
-      if (rstd) rstd[row] = rs;
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const long row = row0 + r * stride;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) s += (lane + 64 * j < C) ? v[r][j] : 0.f;
+      const float mu = wave_sum(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float d = (lane + 64 * j < C) ? v[r][j] - mu : 0.f;
+        q += d * d;
+      }
+      const float rs = rsqrtf(wave_sum(q) * invC + eps);
+      if (row < M) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) st_val(y + row * ldy + c, (v[r][j] - mu) * rs * gm[j] + bt[j]);
+          else if (c < Cpad) st_val(y + row * ldy + c, 0.f);
+        }
+        if (lane == 0) {
+          if (mean) mean[row] = mu;
+          if (rstd) rstd[row] = rs;
+        }
+      }
     }
   }
 }
@@ -137,7 +156,8 @@ __global__ __launch_bounds__(256) void partials_add_kernel(const float* __restri
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gamma * dy ; dgamma += dy * xhat ; dbeta += dy
-template <typename TD>
+// (same row / channel decomposition as the forward: NJ channels per lane, RPI rows in flight, unconditional clamped loads)
+template <typename TD, int NJ, int RPI, bool HAS_RES>
 __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                        long ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -147,58 +167,82 @@ __global__ __launch_bounds__(256) void ln_g_bwd_kernel(const TD* __restrict__ dy
                                                        float* __restrict__ part, long M) {
   __shared__ float red[2][4][64 * LNG_MAX / 4];   // reduced in four column quarters to stay small
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[LNG_MAX], ab[LNG_MAX];
+  float ag[NJ], ab[NJ], gm[NJ];
+  int cc[NJ];
 #pragma unroll
-  for (int j = 0; j < LNG_MAX; ++j) ag[j] = ab[j] = 0.f;
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float g[LNG_MAX], xh[LNG_MAX];
-    float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < NJ; ++j) ag[j] = ab[j] = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNG_MAX; ++j) {
-      const int c = lane + 64 * j;
-      g[j] = 0.f; xh[j] = 0.f;
-      if (c < C) {
-        const float d = ld_val(dy + row * lddy + c);
-        xh[j] = (x[row * ldx + c] - mu) * rs;
-        g[j] = d * gamma[c];
-        ag[j] += d * xh[j];
-        ab[j] += d;
+  for (int j = 0; j < NJ; ++j) {
+    cc[j] = min(lane + 64 * j, C - 1);
+    gm[j] = gamma[cc[j]];
+  }
+  const float invC = 1.f / (float)C;
+  const long stride = (long)gridDim.x * 4;
+  for (long row0 = (long)blockIdx.x * 4 + wave; row0 < M; row0 += stride * RPI) {
+    float d[RPI][NJ], xv[RPI][NJ], dr[RPI][NJ], mu[RPI], rs[RPI], r16[RPI];
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const long row = min(row0 + r * stride, M - 1);
+      mu[r] = mean[row]; rs[r] = rstd[row];
+      r16[r] = (dx16 && rowscale16) ? rowscale16[row] : 1.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        d[r][j] = ld_val(dy + row * lddy + cc[j]);
+        xv[r][j] = x[row * ldx + cc[j]];
+        dr[r][j] = HAS_RES ? dres[row * ldr + cc[j]] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const long row = row0 + r * stride;
+      const bool live = row < M;
+      float g[NJ], xh[NJ];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool ok = live && (lane + 64 * j < C);
+        const float dj = ok ? d[r][j] : 0.f;
+        xh[j] = ok ? (xv[r][j] - mu[r]) * rs[r] : 0.f;
+        g[j] = dj * gm[j];
+        ag[j] += dj * xh[j];
+        ab[j] += dj;
         s1 += g[j];
         s2 += g[j] * xh[j];
       }
-    }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-    const float r16 = (dx16 && rowscale16) ? rowscale16[row] : 1.f;
+      s1 = wave_sum(s1) * invC;
+      s2 = wave_sum(s2) * invC;
+      if (live) {
 #pragma unroll
-    for (int j = 0; j < LNG_MAX; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) {
-        float o = rs * (g[j] - s1 - xh[j] * s2);
-        if (dres) o += dres[row * ldr + c];
-        dx[row * lddx + c] = o;
-        if (dx16) dx16[row * lddx16 + c] = (op_t)(o * r16);      // the next GEMM's 16-bit operand: no separate cast pass
-      } else if (c < Cpad) {
-        dx[row * lddx + c] = 0.f;
-        if (dx16) dx16[row * lddx16 + c] = (op_t)0.f;
+        for (int j = 0; j < NJ; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) {
+            const float o = rs[r] * (g[j] - s1 - xh[j] * s2) + dr[r][j];
+            dx[row * lddx + c] = o;
+            if (dx16) dx16[row * lddx16 + c] = (op_t)(o * r16[r]);      // the next GEMM's 16-bit operand: no separate cast pass
+          } else if (c < Cpad) {
+            dx[row * lddx + c] = 0.f;
+            if (dx16) dx16[row * lddx16 + c] = (op_t)0.f;
+          }
+        }
       }
     }
   }
   // cross-wave reduction of the parameter gradients, three j at a time
-  for (int j0 = 0; j0 < LNG_MAX; j0 += 3) {
+#pragma unroll
+  for (int j0 = 0; j0 < NJ; j0 += 3) {
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      red[0][wave][jj * 64 + lane] = ag[j0 + jj];
-      red[1][wave][jj * 64 + lane] = ab[j0 + jj];
-    }
+    for (int jj = 0; jj < 3; ++jj)
+      if (j0 + jj < NJ) {
+        red[0][wave][jj * 64 + lane] = ag[j0 + jj];
+        red[1][wave][jj * 64 + lane] = ab[j0 + jj];
+      }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
         const int c = lane + 64 * (j0 + jj);
-        if (c < C) {
+        if (j0 + jj < NJ && c < C) {
           const float a = red[0][0][jj * 64 + lane] + red[0][1][jj * 64 + lane] + red[0][2][jj * 64 + lane] + red[0][3][jj * 64 + lane];
           const float b = red[1][0][jj * 64 + lane] + red[1][1][jj * 64 + lane] + red[1][2][jj * 64 + lane] + red[1][3][jj * 64 + lane];
           part[(long)blockIdx.x * 2 * C + c] = a;          // per-workgroup partials, summed by partials_add_kernel
@@ -919,13 +963,23 @@ extern "C" int pvrl_layernorm_g_fwd(const float* x, int64_t ldx, const float* ga
   if (M <= 0) return PVRL_OK;
   if (!x || !gamma || !beta || !y || C <= 0 || C > 64 * LNG_MAX || Cpad < C || Cpad > 64 * LNG_MAX || ldx < C || ldy < Cpad)
     return PVRL_EINVAL;
-  const unsigned grid = grid_for(M, 4);
-  if (y_is_f32)
-    hipLaunchKernelGGL(ln_g_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
-                       eps, (float*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
-  else
-    hipLaunchKernelGGL(ln_g_fwd_kernel<op_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, gamma, beta,
-                       eps, (op_t*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);
+  // NJ = channels per lane (Cpad <= 64 NJ: the zero padding columns are written too); RPI rows in flight per wave
+  const int nj = (int)((Cpad + 63) / 64);
+#define LN_FWD(TO, NJ, RPI)                                                                                              \
+  do {                                                                                                                   \
+    long wgs = (M + 4 * RPI - 1) / (4 * RPI);                                                                            \
+    if (wgs > 8192) wgs = 8192;                                                                                          \
+    hipLaunchKernelGGL((ln_g_fwd_kernel<TO, NJ, RPI>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, x,       \
+                       (long)ldx, gamma, beta, eps, (TO*)y, (long)ldy, (int)C, (int)Cpad, mean, rstd, (long)M);         \
+  } while (0)
+#define LN_FWD_T(TO)                                                                                                     \
+  do {                                                                                                                   \
+    if (nj <= 2) LN_FWD(TO, 2, 4); else if (nj <= 4) LN_FWD(TO, 4, 4); else if (nj <= 6) LN_FWD(TO, 6, 2);               \
+    else LN_FWD(TO, 12, 1);                                                                                              \
+  } while (0)
+  if (y_is_f32) LN_FWD_T(float); else LN_FWD_T(op_t);
+#undef LN_FWD_T
+#undef LN_FWD
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -950,14 +1004,20 @@ extern "C" int pvrl_layernorm_g_bwd(const void* dy, int64_t lddy, int dy_is_f32,
   long blocks = (M + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   float* part = (float*)workspace;
-  if (dy_is_f32)
-    hipLaunchKernelGGL(ln_g_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (op_t*)dx16, (long)lddx16, rowscale16, (int)C, (int)Cpad, part, (long)M);
-  else
-    hipLaunchKernelGGL(ln_g_bwd_kernel<op_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const op_t*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,
-                       (op_t*)dx16, (long)lddx16, rowscale16, (int)C, (int)Cpad, part, (long)M);
+  const int nj = (int)((Cpad + 63) / 64);
+#define LN_BWD(TD, NJ, RPI, RES)                                                                                         \
+  hipLaunchKernelGGL((ln_g_bwd_kernel<TD, NJ, RPI, RES>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,    \
+                     (const TD*)dy, (long)lddy, x, (long)ldx, mean, rstd, gamma, dres, (long)ldr, dx, (long)lddx,        \
+                     (op_t*)dx16, (long)lddx16, rowscale16, (int)C, (int)Cpad, part, (long)M)
+#define LN_BWD_R(TD, RES)                                                                                                \
+  do {                                                                                                                   \
+    if (nj <= 2) LN_BWD(TD, 2, 4, RES); else if (nj <= 4) LN_BWD(TD, 4, 2, RES); else if (nj <= 6) LN_BWD(TD, 6, 2, RES); \
+    else LN_BWD(TD, 12, 1, RES);                                                                                         \
+  } while (0)
+  if (dy_is_f32) { if (dres) LN_BWD_R(float, true); else LN_BWD_R(float, false); }
+  else { if (dres) LN_BWD_R(op_t, true); else LN_BWD_R(op_t, false); }
+#undef LN_BWD_R
+#undef LN_BWD
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(partials_add_kernel, dim3((unsigned)((2 * C + PADD_OUT - 1) / PADD_OUT)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)part, (int)blocks, (int)(2 * C), dgamma, dbeta, (int)C);
