@@ -70,6 +70,26 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     for (int nt = 0; nt < 4; ++nt)
       bv[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw0 + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1))
                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Per-row factors (DropPath) and the second bias are fetched HERE, before the first store: a load issued between the
+    // stores is followed by s_waitcnt vmcnt(0), and on gfx9 that also waits for every earlier store to be acknowledged by
+    // L2 -- four (rowscale) to sixteen (bias2) serial store round trips per thread.  bias2 has no 16 spare registers in the
+    // 128-VGPR budget of the 16-wave tile: each lane keeps ONE column of the wave's 64 and the others come by ds_bpermute.
+    float rs4[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + wm * 64 + mt * 16 + i, p.M - 1)] : 1.f;
+    float b2lane = 0.f;
+    if constexpr (EPI == PVRL_EPI_RESID_F32) {
+      if (p.bias2) {
+        b2lane = p.bias2[nw0 + lane];
+        if (!p.rowscale) {                 // no row factor: rs * (acc + bias) + bias2 = acc + (bias + bias2)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[nt][e] += __shfl(b2lane, 32 * (nt >> 1) + 8 * q + 4 * (nt & 1) + e, 64);
+        }
+      }
+    }
+    const bool b2_late = EPI == PVRL_EPI_RESID_F32 && p.bias2 && p.rowscale;
     // The residual loads of TWO row tiles (32 registers, freed by the MFMA fragments) go out together, twice: two memory
     // round trips per wave instead of four dependent ones (all 16 at once would spill).  With every CU in its epilogue at
     // the same time the loaded latency of a round trip is microseconds.  Rows past M load a clamped row and store nothing.
@@ -90,7 +110,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
       for (int h = 0; h < 2; ++h) {
         const int mt = 2 * half + h;
         const int m = m0 + wm * 64 + mt * 16 + i;
-        const float rs = p.rowscale ? p.rowscale[min(m, p.M - 1)] : 1.f;
+        const float rs = rs4[mt];
         float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 8 * q;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -100,7 +120,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
           for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
           if constexpr (EPI == PVRL_EPI_RESID_F32) {
             ov += rv[h][nt];
-            if (p.bias2) ov += *reinterpret_cast<const f32x4*>(p.bias2 + nw0 + 8 * q + off);
+            if (b2_late) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ov[e] += __shfl(b2lane, 8 * q + off + e, 64);
+            }
           }
           if (m < p.M) *reinterpret_cast<f32x4*>(o + off) = ov;
         }
@@ -113,6 +136,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int e = 0; e < 8; ++e) bv[c][e] = p.bias ? p.bias[nw0 + 32 * c + 8 * q + e] : 0.f;
+    float rs4[4];                      // before the first store (see above)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + wm * 64 + mt * 16 + i, p.M - 1)] : 1.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       opx8 uv[2][2];
@@ -130,7 +156,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
         const int mt = 2 * half + h;
         const int m = m0 + wm * 64 + mt * 16 + i;
         if (m >= p.M) continue;
-        const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+        const float rs = rs4[mt];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           float v[8];
