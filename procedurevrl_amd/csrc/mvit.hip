@@ -7,7 +7,6 @@
 //  * decomposed relative-position terms rel[q][j] = q . R_j (attention.py:67-159) and their gradients
 // Token layout everywhere: rows [0, B*L) are the patch tokens ordered (b, t, h, w); rows [B*L, B*L+B) the cls tokens.
 // Channel widths are padded to multiples of 128 (zero columns) so the bf16 MFMA GEMMs of gemm_nt.hip / gemm_tn.hip apply.
-#include <stdlib.h>
 #include "common.h"
 #include "../../include/pvrl.h"
 
@@ -1103,13 +1102,12 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
   }
   PVRL_LAUNCH_CHECK();
   long wb = (B * H * Lo + PW_LANES * 16 - 1) / (PW_LANES * 16);      // >= 16 tokens per lane: 2,592 global atomics per block
-  { static const long cap = getenv("PVRL_PW_CAP") ? atol(getenv("PVRL_PW_CAP")) : PW_MAX_WG; if (wb > cap) wb = cap; }
   if (wb > PW_MAX_WG) wb = PW_MAX_WG;
   if (wb < 1) wb = 1;
-  // measured per block of MViTv2-S (tools/probe/mvit_pool_times.py): the t-sliding form wins on the small planes with spatial
-  // stride 1 (14 x 14: 271 -> 227 us, 7 x 7: 176 -> 139), loses on 56 x 56 / 28 x 28 and on strided pooling (fewer loads in
-  // flight per lane than the 27-at-once form, which hides the longer misses of the big planes better)
-  if (st == 1 && sh == 1 && sw == 1 && Hh * Ww <= 196)
+  // temporal stride 1 (every MViTv2 pooling operator): the t-sliding form.  Before its nine neighbour loads were issued together
+  // it lost to the 27-loads-at-once form on the big planes and on strided pooling; now it is ahead on every block of
+  // MViTv2-S (tools/probe/mvit_pool_times.py: 56 x 56 stride 1 880 -> 578 us, 28 x 28 stride 2 332 -> 252, 14 x 14 stride 2 116 -> 91)
+  if (st == 1)
     hipLaunchKernelGGL(pool_wgrad_t_kernel, dim3((unsigned)wb), dim3(PW_CQ * PW_LANES), 0, s, (const op_t*)dc_scratch,
                        (const op_t*)qkv, g, (float*)workspace);
   else
