@@ -71,6 +71,12 @@ int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
 int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,
                       void* stream);
+/* The same product reduced straight into an UN-PADDED destination: dW[n][k] (leading dimension ldw) for n < n_valid,
+ * k < k_valid only, dbias[n] for n < n_valid (its own beta_bias) -- zero-padded operands (MViT widths 96 / 288 / 441 ...
+ * padded to the tile multiples) write their weight gradient directly into parameter.grad. */
+int pvrl_gemm_tn_into_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
+                           int64_t splits, float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid,
+                           float* dbias, float beta_bias, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Several weight gradients of the same backward pass in ONE launch (a transformer block's seven nn.Linear dW,
  * loss.backward(), tools/train_net.py:176-181): the (row slice, 256x256 tile) work items of all problems share the 256 CUs,

@@ -35,9 +35,31 @@ extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t sp
   return splits * (N * K + N) * (int64_t)sizeof(float) + 256;   // + a zero page for out-of-range rows
 }
 
+namespace {
+int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K, int64_t splits,
+                 float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid, float* dbias, float beta_bias,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+}
+
 extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
                                  int64_t K, int64_t splits, float beta, float* dW, float* dbias, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
+  return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, splits, beta, dW, K, N, K, dbias, beta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pvrl_gemm_tn_into_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
+                                      int64_t K, int64_t splits, float beta, float* dW, int64_t ldw, int64_t n_valid,
+                                      int64_t k_valid, float* dbias, float beta_bias, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  if (n_valid < 1 || n_valid > N || k_valid < 1 || k_valid > K || ldw < k_valid) return PVRL_EINVAL;
+  return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, splits, beta, dW, ldw, n_valid, k_valid, dbias, beta_bias, workspace,
+                      workspace_bytes, stream);
+}
+
+namespace {
+int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K, int64_t splits,
+                 float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid, float* dbias, float beta_bias,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
   if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
     return PVRL_EINVAL;
   const bool use_rt = tn_use_rt(N, K);
@@ -68,7 +90,18 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   PVRL_LAUNCH_CHECK();
   const long NK = N * K;
   const long nthreads = (NK >> 2) + (dbias ? N : 0);
-  if (nthreads < 64 * 256 && splits >= 8)
+  const bool into = ldw != K || n_valid != N || k_valid != K || beta_bias != beta;
+  if (into) {
+    if (beta_bias != beta && dbias) {       // one beta per launch: the bias gets its own pass of the small kernel
+      hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(NK >> 2, 64)), dim3(256), 0, s, p.part, p.cpart,
+                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, (float*)nullptr);
+      hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, s, p.part, p.cpart,
+                         (int)splits, 0L, (int)N, (int)K, beta_bias, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias);
+    } else {
+      hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(nthreads, 64)), dim3(256), 0, s, p.part, p.cpart,
+                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias);
+    }
+  } else if (nthreads < 64 * 256 && splits >= 8)
     hipLaunchKernelGGL(tn_reduce_small_kernel, dim3((unsigned)cdiv(nthreads, 64)), dim3(256), 0, s, p.part, p.cpart,
                        (int)splits, NK, (int)N, beta, dW, dbias);
   else
@@ -77,6 +110,7 @@ extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int6
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
 // grouped weight gradients

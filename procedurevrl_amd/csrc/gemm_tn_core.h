@@ -477,6 +477,44 @@ __global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __res
   }
 }
 
+// The reduction writing straight into an UN-PADDED destination: out[n][k] for n < nv, k < kv with leading dimension ldo
+// (any alignment: scalar stores), bias_out[n] for n < nv.  The MViT engine's padded weight gradients (96 -> 128, 441 -> 512
+// ...) land in parameter.grad this way instead of through a padded temporary and two 5-us copy kernels per weight.
+__global__ __launch_bounds__(256) void tn_reduce_into_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
+                                                             int splits, long NK, int N, int K, float beta,
+                                                             float* __restrict__ out, long ldo, int nv, int kv,
+                                                             float* __restrict__ bias_out) {
+  __shared__ f32x4 red[3][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long idx4 = (long)blockIdx.x * 64 + o;
+  const long n4 = NK >> 2;
+  const bool is_w = idx4 < n4, is_b = !is_w && bias_out && idx4 - n4 < N;
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (is_w) {
+    for (int s = sl; s < splits; s += 4) a += reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
+  } else if (is_b) {
+    for (int s = sl; s < splits; s += 4) a[0] += cpart[(long)s * N + (int)(idx4 - n4)];
+  }
+  if (sl > 0) red[sl - 1][o] = a;
+  __syncthreads();
+  if (sl == 0) {
+    a = (a + red[0][o]) + (red[1][o] + red[2][o]);
+    if (is_w) {
+      const int k4 = K >> 2;
+      const int n = (int)(idx4 / k4), k = (int)(idx4 - (long)n * k4) * 4;
+      if (n < nv) {
+        float* dst = out + (long)n * ldo + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < kv) dst[e] = beta != 0.f ? a[e] + beta * dst[e] : a[e];
+      }
+    } else if (is_b) {
+      const int n = (int)(idx4 - n4);
+      if (n < nv) bias_out[n] = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+    }
+  }
+}
+
 // the same for every problem of a grouped launch in ONE kernel (seven 10-us launches per transformer block otherwise)
 constexpr int TN_RED_MAX = 8;
 struct TnReduceGroup {

@@ -295,15 +295,10 @@ class MViTEngine(GraphReplay):
         return self.m.grad_target(p)
 
     def _wgrad(self, P, Q, weight, bias, e):
-        """dW = P^T Q on the padded operands -> the [N, K] block into weight.grad (+ bias.grad from the column sums)"""
-        dWp = torch.empty((e.w.shape[0], e.w.shape[1]), device=P.device, dtype=F32)
-        dbp = torch.empty(e.w.shape[0], device=P.device, dtype=F32) if bias is not None else None
-        ops.gemm_tn(P, Q, dWp, dbp, beta=0.0)
+        """dW = P^T Q on the padded operands, reduced straight into the [N, K] weight.grad (+ bias.grad from the column sums)"""
         gw, bw = self._grad(weight)
-        om.copy2d(dWp, gw.view(e.N, e.K), e.N, e.K, beta=bw)
-        if bias is not None:
-            gb, bb = self._grad(bias)
-            om.copy2d(dbp.view(1, -1), gb.view(1, -1), 1, e.N, beta=bb)
+        gb, bb = self._grad(bias) if bias is not None else (None, 0.0)
+        ops.gemm_tn_into(P, Q, gw.view(e.N, e.K), e.N, e.K, dbias=None if gb is None else gb.view(-1), beta=bw, beta_bias=bb)
 
     def _acc_target(self, p):
         """fp32 buffer that a kernel ACCUMULATES into (atomicAdd): zeroed first unless it already holds this step's sum"""

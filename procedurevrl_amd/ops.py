@@ -155,6 +155,24 @@ def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
     return dW
 
 
+def gemm_tn_into(P, Q, dW, n_valid, k_valid, dbias=None, beta=0.0, beta_bias=0.0, ws_tag="tn"):
+    """dW[:n_valid, :k_valid] (fp32, row stride dW.stride(0)) = beta*dW + (P^T Q)[:n_valid, :k_valid] for zero-padded
+    operands P [M, Np], Q [M, Kp]; dbias[:n_valid] likewise with beta_bias."""
+    L = lib()
+    _chk2d(P, OP16); _chk2d(Q, OP16)
+    M, N = P.shape
+    K = Q.shape[1]
+    assert Q.shape[0] == M and dW.dtype == F32 and dW.dim() == 2 and dW.stride(1) == 1
+    assert dW.shape[0] >= n_valid and dW.shape[1] >= k_valid and n_valid <= N and k_valid <= K
+    assert dbias is None or (dbias.dtype == F32 and dbias.is_contiguous() and dbias.numel() >= n_valid)
+    splits = tn_splits(M, N, K)
+    ws = workspace(L.call("pvrl_gemm_tn_workspace_bytes", N, K, splits), P.device, ws_tag)
+    _timed("gemm_tn_kernel+reduce", 2.0 * M * N * K, lambda: L.call(
+        "pvrl_gemm_tn_into_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), dW.stride(0),
+        n_valid, k_valid, _ptr(dbias), float(beta_bias), _ptr(ws), ws.numel(), _stream()))
+    return dW
+
+
 TN_GROUP_MAX = 8
 
 

@@ -140,6 +140,26 @@ def check_gemm_tn():
     return out
 
 
+def check_gemm_tn_into():
+    """zero-padded operands reduced straight into an un-padded, odd-width destination (pvrl_gemm_tn_into_bf16): the MViT
+    engine's weight gradients (96 -> 128, 441 -> 512 columns); separate betas for weight and bias"""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(31)
+    out = []
+    for (M, Nv, Kv, Np, Kp, bw, bb) in [(700, 96, 441, 128, 512, 0.0, 0.0), (333, 288, 96, 384, 128, 1.0, 1.0),
+                                        (5000, 192, 192, 256, 256, 0.0, 1.0), (64, 768, 384, 768, 384, 1.0, 0.0)]:
+        P = torch.zeros(M, Np); P[:, :Nv] = torch.randn(M, Nv, generator=g)
+        Q = torch.zeros(M, Kp); Q[:, :Kv] = torch.randn(M, Kv, generator=g)
+        w0 = torch.randn(Nv, Kv, generator=g); b0 = torch.randn(Nv, generator=g)
+        ref_w = bw * w0 + (bf(P).t() @ bf(Q))[:Nv, :Kv]
+        ref_b = bb * b0 + bf(P).sum(0)[:Nv]
+        dW = w0.to(dev()).clone(); db = b0.to(dev()).clone()
+        ops.gemm_tn_into(P.to(dev(), BF), Q.to(dev(), BF), dW, Nv, Kv, dbias=db, beta=bw, beta_bias=bb)
+        out.append((f"gemm_tn_into dW {M}x{Nv}({Np})x{Kv}({Kp}) beta={bw}", rel(dW, ref_w), 1e-4))
+        out.append((f"gemm_tn_into dbias {M}x{Nv} beta={bb}", rel(db, ref_b), 1e-4))
+    return out
+
+
 def check_gemm_tn_grouped():
     """several weight gradients in one launch (pvrl_gemm_tn_grouped_bf16): ragged and differing M, bias / no bias,
     accumulate, bit-identical across repeats, and the per-problem fallback for shapes the grouped kernel refuses"""
@@ -541,5 +561,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
