@@ -152,12 +152,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_persist_kernel(GemmNT p)
   }
 }
 
-template <int EPI, int WM, int WN>
+template <int EPI, int WM, int WN, int WPC = 1>
 int launch_tile_persist(GemmNT p, hipStream_t s) {
   p.tiles_n = p.N / (64 * WN);
   p.tiles_m = cdiv(p.M, 64 * WM);
   const int per_xcd = cdiv(p.tiles_m, 8) * p.tiles_n;          // longest per-XCD tile list
-  const int cus_per_xcd = 32;                                  // MI355X: 256 CUs in 8 XCDs, one 16-wave workgroup per CU
+  const int cus_per_xcd = 32 * WPC;                            // MI355X: 256 CUs in 8 XCDs, WPC resident workgroups per CU
   p.nwg = 8 * (per_xcd < cus_per_xcd ? per_xcd : cus_per_xcd);
   hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
   PVRL_LAUNCH_CHECK();
@@ -1260,6 +1260,8 @@ int launch_w4x32(GemmNT p, hipStream_t s) {
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s, int t) {
   if (t == 14 && p.N % 256 == 0) return launch_tile_persist<EPI, 4, 4>(p, s);      // persistent 256x256 (gemm_nt_core.h)
+  if (t == 15) return launch_tile_persist<EPI, 2, 2, 2>(p, s);                       // persistent 128x128, two workgroups per CU
+  if (t == 16) return launch_tile_persist<EPI, 2, 2, 4>(p, s);                       // the same, 4 lists per CU (2 resident at a time)
   if (t == 10 && p.N % 256 == 0) return launch_w4x32<EPI>(p, s);
   if (t == 11 && p.N % 256 == 0) {
     GemmNT q = p;

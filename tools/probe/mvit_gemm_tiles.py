@@ -49,7 +49,7 @@ for name, M, N, K, epi in shapes:
     else:
         kw["bias"] = rnd(N)
     row = [f"{name:5s} M {M:7d} N {N:5d} K {K:5d} epi {epi}: product {timeit(lambda: ops.gemm_nt(A, W, epi, **kw)):7.1f}"]
-    for t in (1, 2, 3, 7, 8, 9):
+    for t in (1, 2, 3, 7, 8, 15, 16):
         if t == 3 and N % 256:
             row.append("  t3    -  ")
             continue
