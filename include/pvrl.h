@@ -285,7 +285,8 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* 
                        float* drel, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* pvrl_cast_weight_bf16 into caller-zeroed padded buffers: out bf16 [>=R][ldo], out_t bf16 [>=C][ldt] (MViT widths 96,
- * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns). */
+ * 192, 288, 441, 576 are padded to the GEMM tile multiples with zero rows / columns); `bias` (optional, fp32 [R]) is copied into the
+ * caller-zeroed padded `bias_out` by the same launch. */
 /* y[r] = beta * y[r] + sum_c W[r][c] * x[c] for a small dense matrix W (fp32, or bf16 when w_is_bf16), fp32 x and y:
  * the bias products of the fused temporal branch, b_e = W_fc b_proj and db_proj = W_fc^T db_e (the latter on the
  * transposed bf16 operand copy), vit.py:131-134. */
@@ -302,7 +303,7 @@ typedef struct pvrl_cast_problem {
 } pvrl_cast_problem;
 int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* problems, void* stream);
 int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R, int64_t C,
-                              void* stream);
+                              const float* bias, float* bias_out, void* stream);
 
 /* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
 int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);

@@ -199,10 +199,13 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 // W fp32 [R][C] -> Wb bf16 [R][C] and Wt bf16 [C][R] in one pass (both GEMM operand copies of a weight matrix)
 // (ldo / ldt: leading dimensions of the two copies -- larger than C / R when the copies live in zero-padded buffers)
 __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ in, op_t* __restrict__ out,
-                                                          op_t* __restrict__ out_t, int R, int C, long ldo, long ldt) {
+                                                          op_t* __restrict__ out_t, int R, int C, long ldo, long ldt,
+                                                          const float* __restrict__ bias, float* __restrict__ bias_out) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (bias && blockIdx.x == 0 && threadIdx.x < 32 && r0 + threadIdx.x < R)     // the layer's bias rides along: fp32 copy into its padded buffer
+    bias_out[r0 + threadIdx.x] = bias[r0 + threadIdx.x];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + 8 * k, c = c0 + tx;
@@ -387,7 +390,8 @@ extern "C" int pvrl_cast_transpose_bf16(const float* in, void* out, int64_t R, i
 extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream) {
   if (!in || !out || R <= 0 || C <= 0) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)C, (long)R);
+                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)C, (long)R,
+                     (const float*)nullptr, (float*)nullptr);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -428,10 +432,10 @@ extern "C" int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* prob
 }
 
 extern "C" int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R,
-                                         int64_t C, void* stream) {
-  if (!in || !out || R <= 0 || C <= 0 || ldo < C || (out_t && ldt < R)) return PVRL_EINVAL;
+                                         int64_t C, const float* bias, float* bias_out, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || ldo < C || (out_t && ldt < R) || (bias && !bias_out)) return PVRL_EINVAL;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
-                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)ldo, (long)ldt);
+                     (hipStream_t)stream, in, (op_t*)out, (op_t*)out_t, (int)R, (int)C, (long)ldo, (long)ldt, bias, bias_out);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -277,9 +277,9 @@ class MViTEngine(GraphReplay):
                 e.t = torch.zeros((Kp, Np), device=weight.device, dtype=OP16)
                 e.b = torch.zeros(Np, device=weight.device, dtype=F32)
                 self._pw[id(weight)] = e
-            lib().call("pvrl_cast_weight_pad_bf16", ops._ptr(w2), ops._ptr(e.w), Kp, ops._ptr(e.t), Np, N, K, ops._stream())
-            if bias is not None:
-                e.b[:N].copy_(bias.detach())
+            lib().call("pvrl_cast_weight_pad_bf16", ops._ptr(w2), ops._ptr(e.w), Kp, ops._ptr(e.t), Np, N, K,
+                       ops._ptr(bias.detach()) if bias is not None else None, ops._ptr(e.b) if bias is not None else None,
+                       ops._stream())
             e.N, e.K, e.ver = N, K, ver
         return e
 
