@@ -431,7 +431,7 @@ class MViTEngine(GraphReplay):
         for i in range(len(enc.blocks) - 1, -1, -1):
             # the block's last kernel also writes the 16-bit operand copy the block below starts from (its DropPath factor in)
             nxt = sv["blocks"][i - 1]["rs_m"] if i > 0 else None
-            dx, dx16 = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B, dx16, i > 0, nxt)
+            dx, dx16 = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B, dx16, True, nxt)
             sv["blocks"][i] = None
             if gs is not None:
                 gs.unscale()
@@ -442,7 +442,7 @@ class MViTEngine(GraphReplay):
         R = dx.shape[0] - B
         pw = enc.patch_embed.proj.weight      # same padded shape as the forward asked for (one cache entry, not two that evict each other)
         wpe = self._wpad(pw, enc.patch_embed.proj.bias, Np=om.pad128(e0), Kp=512 * ((pw[0].numel() + 511) // 512))
-        dxb = ops.cast_scale(dx[:R])
+        dxb = dx16[:R] if dx16 is not None else ops.cast_scale(dx[:R])     # block 0's last LayerNorm backward wrote the 16-bit copy
         self._wgrad(dxb, sv["a_pe"], enc.patch_embed.proj.weight, enc.patch_embed.proj.bias, wpe)
         gc, bc = self._grad(enc.cls_token)
         s = ops.batch_sum(dx[R:], B, 1)
