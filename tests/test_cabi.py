@@ -67,3 +67,24 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_lib.PvrlError):
         ops.layernorm_fwd(torch.zeros(4, 768), torch.ones(768), torch.zeros(768), 1e-6)
+
+
+def test_rel_operand_form_round_trips_on_the_host():
+    """ops_mvit.rel_pack / rel_unpack (the hi | lo 16-bit pair pvrl_mvit_rel_fwd writes and pvrl_mvit_attn_* read): width from
+    the C side, padding columns zero, value recovered to ~2^-16 -- pure host code plus two size queries."""
+    import torch
+    from procedurevrl_amd import ops_mvit as om
+    assert om.rel_width((8, 7, 7)) == 32 and om.rel_width((8, 14, 14)) == 64
+    L = _lib.lib()
+    assert L.call("pvrl_mvit_attn_keymap_bytes", 8, 7, 7) == 13 * 4096 and L.call("pvrl_mvit_attn_keymap_bytes", 8, 14, 14) == 50 * 4096
+    g = torch.Generator().manual_seed(0)
+    for k_thw in ((8, 7, 7), (8, 14, 14)):
+        J = sum(k_thw)
+        rel = torch.randn(3, 10, J, generator=g) * 3
+        for osc in (1.0, 96 ** 0.5):
+            relp = om.rel_pack(rel, k_thw, osc)
+            JP = om.rel_width(k_thw)
+            assert relp.shape == (3, 10, 2 * JP)
+            assert float(relp[..., J:JP].float().abs().max()) == 0.0 and float(relp[..., JP + J:].float().abs().max()) == 0.0
+            back = om.rel_unpack(relp, k_thw, osc)
+            assert float((back - rel).abs().max() / rel.abs().max()) < 2e-5
