@@ -146,12 +146,29 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
     f32x4 a[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) a[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // The kernel is bound by its vector-memory instruction count, not by latency (batching the loads of eight j changed
+    // nothing): the TPQ = 8 lanes of a query share each d rel value and table index -- lane k of the group loads entry
+    // j0 + k of a chunk of eight, ds_bpermute hands them round -- so a chunk costs 2 + 8 NV loads per lane instead of 16 + 8 NV.
+    static_assert(TPQ == 8, "one query = one aligned group of eight lanes");
+    const int k8 = threadIdx.x & 7;
     auto axis = [&](const float* R, const int* ix, int kn, const float* dj) {
-      for (int j = 0; j < kn; ++j) {
-        const float w = dj[j];
-        const f32x4* row = reinterpret_cast<const f32x4*>(R + (long)ix[j] * HD + c);
+      for (int j0 = 0; j0 < kn; j0 += 8) {
+        const int jk = min(j0 + k8, kn - 1);
+        const float wk = j0 + k8 < kn ? dj[jk] : 0.f;
+        const int rk = ix[jk];
+        f32x4 rows[8][NV];
+        float w[8];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) a[e] += w * row[e];
+        for (int e = 0; e < 8; ++e) {
+          w[e] = __shfl(wk, e, 8);
+          const f32x4* row = reinterpret_cast<const f32x4*>(R + (long)__shfl(rk, e, 8) * HD + c);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) rows[e][v] = row[v];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) a[v] += w[e] * rows[e][v];
       }
     };
     axis(Rh, ih + y * g.kh, g.kh, d);
@@ -344,8 +361,9 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
     return PVRL_EINVAL;
   if (workspace_bytes < pvrl_mvit_rel_bwd_workspace_bytes(BH, qt, qh, qw, kt, kh, kw)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // 8 channels per thread: measured 4 / 8 / 16 / 32 -> 2.4 / 1.9 / 2.8 / 4.2 ms per MViTv2-S step
-  hipLaunchKernelGGL(rel_bwd_q_kernel<8>, dim3(grid_for((long)BH * qt * qh * qw * (HD / 8))), dim3(256), 0, s, drel, g, Rh, Rw,
+  // 12 channels per thread = 8 lanes per query (with per-thread d rel / index loads: 4 / 8 / 16 / 32 channels measured
+  // 2.4 / 1.9 / 2.8 / 4.2 ms per MViTv2-S step)
+  hipLaunchKernelGGL(rel_bwd_q_kernel<12>, dim3(grid_for((long)BH * qt * qh * qw * (HD / 12))), dim3(256), 0, s, drel, g, Rh, Rw,
                      Rt, idx_h, idx_w, idx_t, (op_t*)dQ);
   PVRL_LAUNCH_CHECK();
   RelAxes ax = {};
