@@ -217,8 +217,8 @@ class _PW:
 class MViTEngine(GraphReplay):
     """Kernel schedule of MViT_encoder.forward (slowfast_mvit/mvit.py:346-407) and its hand-written backward.
     Token matrices are fp32 [B*L + B, pad128(C)]: patch tokens (b, t, h, w) first, the B cls tokens last.
-    The ~3,000 launches of a step are replayed from HIP graphs (engine.GraphReplay; backward unstaged: with a
-    data-parallel gradient hook installed the backward is launched eagerly)."""
+    The ~3,000 launches of a step are replayed from HIP graphs (engine.GraphReplay; with a data-parallel gradient hook
+    installed the backward is one graph per block, the hook running between them)."""
 
     _weight = EncoderEngine._weight      # un-padded bf16 copies for the width-512 stacks (order transformer, text tower)
 
@@ -405,8 +405,10 @@ class MViTEngine(GraphReplay):
         return x2
 
     # -------------------------------------------------------------- backward
-    def _backward(self, dfeat):
-        L = lib()
+    # The backward in three kinds of stages -- begin (final norm), one per block, end (stem) -- so that engine.GraphReplay can
+    # capture one HIP graph per block and run the data-parallel reducer's hook between them (staged capture); without a
+    # hook the whole backward is one graph.
+    def _bwd_begin(self, dfeat):
         enc = self.enc
         sv = self.saved
         if sv is None:
@@ -427,17 +429,21 @@ class MViTEngine(GraphReplay):
         dgn, dbn = self._acc_target(enc.norm.weight), self._acc_target(enc.norm.bias)
         dx[Rl:] = om.ln_bwd(dfeat.contiguous().float(), xf[Rl:], Cl, sv["f_mean"], sv["f_rstd"], enc.norm.weight.detach(),
                             dgn, dbn, Cpad=xf.shape[1])
-        dx16 = None
-        for i in range(len(enc.blocks) - 1, -1, -1):
-            # the block's last kernel also writes the 16-bit operand copy the block below starts from (its DropPath factor in)
-            nxt = sv["blocks"][i - 1]["rs_m"] if i > 0 else None
-            dx, dx16 = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], dx, B, dx16, True, nxt)
-            sv["blocks"][i] = None
-            if gs is not None:
-                gs.unscale()
-            if self.grad_hook is not None:
-                self.grad_hook(i)
+        return dict(sv=sv, B=B, dx=dx, dx16=None, gs=gs)
+
+    def _bwd_block(self, st, i):
+        enc, sv = self.enc, st["sv"]
+        # the block's last kernel also writes the 16-bit operand copy the block below starts from (its DropPath factor in)
+        nxt = sv["blocks"][i - 1]["rs_m"] if i > 0 else None
+        st["dx"], st["dx16"] = self._block_bwd(i, enc.blocks[i], enc.plan[i], sv["blocks"][i], st["dx"], st["B"], st["dx16"],
+                                               True, nxt)
+        sv["blocks"][i] = None
+        if st["gs"] is not None:
+            st["gs"].unscale()
+
+    def _bwd_end(self, st):
         # patch embed (weight gradient only: the input needs none) and cls token
+        enc, sv, B, dx, dx16 = self.enc, st["sv"], st["B"], st["dx"], st["dx16"]
         e0 = enc.plan[0]["dim"]
         R = dx.shape[0] - B
         pw = enc.patch_embed.proj.weight      # same padded shape as the forward asked for (one cache entry, not two that evict each other)
@@ -447,8 +453,19 @@ class MViTEngine(GraphReplay):
         gc, bc = self._grad(enc.cls_token)
         s = ops.batch_sum(dx[R:], B, 1)
         om.copy2d(s.view(1, -1), gc.view(1, -1), 1, e0, beta=bc)
-        if gs is not None:
-            gs.end_scaled()
+        if st["gs"] is not None:
+            st["gs"].end_scaled()
+
+    def join_side_stream(self):
+        pass                                   # this engine issues everything on one stream
+
+    def _backward(self, dfeat):
+        st = self._bwd_begin(dfeat)
+        for i in range(len(self.enc.blocks) - 1, -1, -1):
+            self._bwd_block(st, i)
+            if self.grad_hook is not None:
+                self.grad_hook(i)
+        self._bwd_end(st)
 
     def _block_bwd(self, i, blk, pl, s, dx2, B, dx2_16=None, want16=False, next_rs=None):
         L = lib()

@@ -457,6 +457,20 @@ def check_mvit_hip_graph_replay():
         pred, grads = step(xs[i])                # (a captured hipMemsetAsync did not re-zero a max-pool gradient buffer)
         out.append((f"mvit graph replay {k}, input {i}: logits differ (count)", float((pred != ref[i][0]).sum()), 0.0))
         out.append((f"mvit graph replay {k}, input {i}: gradients differ (count)", float((grads != ref[i][1]).sum()), 0.0))
+    # with a per-block gradient hook (the data-parallel reducer): one graph per block, the hook between them, same bits
+    calls = []
+    eng.grad_hook = lambda blk: calls.append(blk)
+    nb = len(model.model.video_encoder.blocks)
+    for k, i in enumerate((0, 1, 0, 1)):
+        del calls[:]
+        pred, grads = step(xs[i])
+        out.append((f"mvit staged graph replay {k}, input {i}: gradients differ (count)", float((grads != ref[i][1]).sum()), 0.0))
+        out.append((f"mvit staged graph replay {k}: hook order (0 = last block first, every block once)",
+                    0.0 if calls == list(range(nb - 1, -1, -1)) else 1.0, 0.0))
+    gk = next(iter(eng._graphs.values()))
+    out.append(("mvit staged backward was captured as one graph per block (0 = yes)",
+                0.0 if gk.get("bwd_staged") and len(gk["bwd_staged"]["graphs"]) == nb else 1.0, 0.0))
+    eng.grad_hook = None
     return out
 
 
