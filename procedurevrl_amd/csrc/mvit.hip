@@ -750,22 +750,42 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_t_kernel(const op
     const op_t* db = dc + (bh * (Lo + 1) + pos) * HD + c0;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 dP = zero, dC = ld4bf(db), dN = g.T > 1 ? ld4bf(db + (long)HoWo * HD) : zero;   // dc of output frames ti-1, ti, ti+1
-    for (int ti = 0; ti < g.T; ++ti) {
-      const op_t* pb = xb + (long)ti * plane * g.ld;
-      u32x2 raw[9];
+    // two frames per iteration: 18 neighbour loads (+ the two dc rows that come into reach) in flight instead of 9 -- at 2 waves
+    // per SIMD (108 accumulator registers) the kernel is bound by its memory round trips, one per iteration
+    for (int ti = 0; ti < g.T; ti += 2) {
+      const int t1 = min(ti + 1, g.T - 1), t2 = min(ti + 2, g.T - 1), t3 = min(ti + 3, g.T - 1);
+      const bool has1 = ti + 1 < g.T;
+      const op_t* pb0 = xb + (long)ti * plane * g.ld;
+      const op_t* pb1 = xb + (long)t1 * plane * g.ld;
+      u32x2 raw0[9], raw1[9];
 #pragma unroll
-      for (int n = 0; n < 9; ++n) raw[n] = *reinterpret_cast<const u32x2*>(pb + (long)max(noff[n], 0) * g.ld);   // all nine in flight
+      for (int n = 0; n < 9; ++n) {
+        const long o = (long)max(noff[n], 0) * g.ld;
+        raw0[n] = *reinterpret_cast<const u32x2*>(pb0 + o);
+        raw1[n] = *reinterpret_cast<const u32x2*>(pb1 + o);
+      }
+      const f32x4 l2 = ld4bf(db + (long)t2 * HoWo * HD), l3 = ld4bf(db + (long)t3 * HoWo * HD);
+      const f32x4 d2 = ti + 2 < g.T ? l2 : zero, d3 = ti + 3 < g.T ? l3 : zero;
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
         const bool ok = noff[n] >= 0;
         f32x4 xv;
-        { float a, b2; op_unpack2(ok ? raw[n][0] : 0u, a, b2); xv[0] = a; xv[1] = b2; op_unpack2(ok ? raw[n][1] : 0u, a, b2); xv[2] = a; xv[3] = b2; }
+        { float a, b2; op_unpack2(ok ? raw0[n][0] : 0u, a, b2); xv[0] = a; xv[1] = b2; op_unpack2(ok ? raw0[n][1] : 0u, a, b2); xv[2] = a; xv[3] = b2; }
         acc[n] += dN * xv;                 // tap a = 0: frame ti is the first input frame of output ti + 1
         acc[9 + n] += dC * xv;             // a = 1
         acc[18 + n] += dP * xv;            // a = 2
       }
-      dP = dC; dC = dN;
-      dN = ti + 2 < g.T ? ld4bf(db + (long)(ti + 2) * HoWo * HD) : zero;
+      dP = dC; dC = dN; dN = d2;
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        const bool ok = has1 && noff[n] >= 0;
+        f32x4 xv;
+        { float a, b2; op_unpack2(ok ? raw1[n][0] : 0u, a, b2); xv[0] = a; xv[1] = b2; op_unpack2(ok ? raw1[n][1] : 0u, a, b2); xv[2] = a; xv[3] = b2; }
+        acc[n] += dN * xv;
+        acc[9 + n] += dC * xv;
+        acc[18 + n] += dP * xv;
+      }
+      dP = dC; dC = dN; dN = d3;
     }
   }
   __syncthreads();
