@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient instead of one per block")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (configs[3] T=32 and configs[4] MViTv2-S) "
                                                            "that the default single-GPU run appends to its JSON line")
+    ap.add_argument("--parity-probe", action="store_true",
+                    help="after the timed region: 2 clips of the SAME full-size model (12 blocks, 8x224^2, K=9871), one training "
+                         "step vs the CPU oracle (checker only) -> `parity` in the JSON line (logits / loss / worst gradient error)")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
     args = ap.parse_args()
@@ -67,6 +70,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import OPERAND            # the loaded library's 16-bit operand type: "bf16" | "f16"
     from procedurevrl_amd.config import get_cfg
     from procedurevrl_amd.build import build_model
     from procedurevrl_amd.datasets import synthetic_label_emb
@@ -229,7 +233,7 @@ def main():
             "metric": f"training clips/sec ({args.frames}f x 224^2, ViT-B TimeSformer)" if args.arch == "vit" else
                       f"training clips/sec ({args.frames}f x 224^2, MViTv2-S)", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": OPERAND, "data": "synthetic",
             "config": {"workload": ("MViTv2-S " if args.arch == "mvit" else "TimeSformer ViT-B ") +
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
@@ -254,6 +258,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # noqa
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
+        if args.parity_probe and world == 1 and args.arch == "vit":
+            del model, vt, optimizer, reducer, frames, teacher
+            torch.cuda.empty_cache()
+            try:
+                out["parity"] = parity_probe()
+            except Exception as e:  # noqa
+                out["parity"] = {"error": repr(e)[:200]}
+            args.no_side = True
         if world == 1 and args.arch == "vit" and args.frames == 8 and not args.no_side and not args.no_cpu_baseline:
             # the other single-GPU configurations BASELINE names, timed by the same script in child processes (their own
             # model, graphs and memory): configs[3] long clips (T = 32) and configs[4] MViTv2-S.  Informational: `value` above
@@ -267,19 +279,44 @@ def main():
         dist.destroy_process_group()
 
 
+def parity_probe():
+    """north_star's contract (step logits and loss within 1e-3 of the reference's CPU path) checked in THIS process on the
+    library flavour that was just timed: tests/e2e_checks builds the full-size model (12 blocks, 8x224^2, K = 9871), runs one
+    training step on 2 clips through the HIP path and through the CPU oracle (oracle/ = checker, pinned to the reference by
+    tests/golden) and returns relative L2 errors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_checks as ec
+    res = ec.check_bench_config_two_clips()
+    get = lambda key: next(e for l, e, _ in res if key in l)
+    return {"logits_rel_err": float(f"{get('logits vs oracle'):.3e}"), "loss_rel_err": float(f"{get('loss vs oracle'):.3e}"),
+            "worst_grad_rel_err": float(f"{get('all parameter gradients'):.3e}"), "north_star_tol": 1e-3,
+            "meets_1e-3_on_logits_and_loss": bool(get("logits vs oracle") <= 1e-3 and get("loss vs oracle") <= 1e-3),
+            "sample": "2 clips, full-size model, one training step vs oracle/timesformer_oracle.py (fp32 CPU)"}
+
+
 def side_measurements():
+    """The other single-GPU lines, each a child process of this same script under the driver's clock: the fp16-operand
+    flavour of configs[1] (the flavour held to north_star's 1e-3, with its measured error), configs[3] and configs[4]."""
     import subprocess
     res = []
-    for name, extra in (("configs[3]: TimeSformer ViT-B 32x224^2, 8 clips/GPU", ["--frames", "32", "--batch", "8"]),
-                        ("configs[4]: MViTv2-S 16x224^2, 32 clips/GPU", ["--arch", "mvit"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
-               "--no-kernel-timing", "--no-side"] + extra
+    base = ["--no-cpu-baseline", "--no-side"]
+    for name, extra, env in (
+            ("configs[1] with fp16 operands (PVRL_OPERAND=f16, libpvrl_hip_f16.so): TimeSformer ViT-B 8x224^2, 32 clips/GPU",
+             ["--steps", "20", "--warmup", "5", "--parity-probe"], {"PVRL_OPERAND": "f16"}),
+            ("configs[3]: TimeSformer ViT-B 32x224^2, 8 clips/GPU", ["--steps", "10", "--warmup", "3", "--frames", "32", "--batch", "8"], {}),
+            ("configs[4]: MViTv2-S 16x224^2, 32 clips/GPU", ["--steps", "10", "--warmup", "3", "--arch", "mvit"], {})):
+        cmd = [sys.executable, os.path.abspath(__file__)] + base + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=dict(os.environ, **env))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
-            res.append({"config": name, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                        "steps": d["steps"], "frac_of_bf16_peak": d["end_to_end"]["frac_of_bf16_peak"]})
+            e = {"config": name, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"],
+                 "ms_per_step": d["ms_per_step"], "steps": d["steps"], "frac_of_bf16_peak": d["end_to_end"]["frac_of_bf16_peak"]}
+            if "roofline" in d:
+                e["roofline"] = d["roofline"]
+            if "parity" in d:
+                e["parity"] = d["parity"]
+            res.append(e)
         except Exception as e:  # noqa
             res.append({"config": name, "error": repr(e)[:160]})
     return res
@@ -310,7 +347,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r2_b_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
     A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r2_b_traffic.json", "r1_j_traffic.json"))
+    path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r3_traffic.json", "r2_b_traffic.json", "r1_j_traffic.json"))
                  if os.path.exists(q)), None)
     if path is None:
         return None
@@ -323,12 +360,11 @@ def pmc_traffic(kernel):
             return None
         want = max(cands, key=lambda k: t[k].get("launches", 0))
         b = t[want]["hbm_bytes_per_launch"]
-        red = t.get("tn_reduce_kernel")
+        # a grouped launch is followed by ONE grouped reduce of its fp32 partials (tn_reduce_grouped_kernel); a lone
+        # weight gradient by its own tn_reduce_kernel
+        red = t.get("tn_reduce_grouped_kernel" if "grouped" in kernel else "tn_reduce_kernel")
         if red:
-            nmain = sum(v.get("launches", 0) for k, v in t.items() if k.startswith("gemm_tn_"))
-            per = red.get("launches", 0) / nmain if nmain else 1.0      # reduces per weight gradient problem
-            nprob = 7.0 if "grouped" in kernel else 1.0                 # a transformer block's seven nn.Linear
-            b += red["hbm_bytes_per_launch"] * (nprob if per > 1.5 else 1.0)
+            b += red["hbm_bytes_per_launch"]
         return round(b, 0)
     e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
     keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]

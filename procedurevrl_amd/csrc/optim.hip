@@ -13,12 +13,15 @@ namespace {
 // floats 1 - lr*wd, 1 - beta1, 1 - beta2, lr / bias_correction1, sqrt(bias_correction2) handed to fp32 tensor ops):
 //   p *= decay (AdamW) | g += wd * p (Adam);  m = m + w1 * (g - m)  [Tensor.lerp_];  v = b2 * v + w2 * g * g;
 //   p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)
+// Two places where torch itself is not one arithmetic: `sqrt(v) / bc2_sqrt` is a true division in torch's CPU kernels (what
+// tests/test_optimizer_gpu.py pins against, <= 1e-6) and a multiply by the fp32 reciprocal in its CUDA/HIP kernels -- <= 1 ulp
+// apart, the division is kept; Tensor.lerp_ switches formula at weight 0.5, mirrored below (beta1 < 0.5 takes the other one).
 struct AdamConst { float decay, wd, w1, b2, w2, step_size, bc2_sqrt, eps, gscale; int decoupled; };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamConst& c) {
   float gg = g * c.gscale;
   if (c.decoupled) p *= c.decay; else gg += c.wd * p;
-  m = m + c.w1 * (gg - m);
+  m = c.w1 < 0.5f ? m + c.w1 * (gg - m) : gg - (gg - m) * (1.f - c.w1);
   v = c.b2 * v + c.w2 * gg * gg;
   const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
   p -= c.step_size * (m / denom);

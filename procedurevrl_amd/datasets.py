@@ -77,6 +77,30 @@ class SyntheticTestClips(torch.utils.data.Dataset):
         return frames, torch.tensor(label), torch.tensor(index), {}
 
 
+class SyntheticValClips(torch.utils.data.Dataset):
+    """Validation split for `eval_epoch` (tools/train_net.py:251): labelled inputs in the layout the model's eval forward
+    takes under `cfg` -- [m, 3, T, S, S] with m labels per video when DEV.ORDER_PRETRAIN_ENABLED regroups `b m c t h w`
+    (vit.py:290-291), one [3, T, S, S] clip with one label otherwise."""
+
+    def __init__(self, cfg, num_videos=8, seed=1, clips=9):
+        self.cfg = cfg
+        self.n = num_videos
+        self.seed = seed
+        self.clips = clips if cfg.DEV.ORDER_PRETRAIN_ENABLED else 0
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(self.seed * 100003 + 17 * index + 5)
+        T, S = self.cfg.DATA.NUM_FRAMES, self.cfg.DATA.TRAIN_CROP_SIZE
+        K = max(1, int(self.cfg.MODEL.NUM_CLASSES))
+        if self.clips:
+            return (torch.randn(self.clips, 3, T, S, S, generator=g), torch.randint(0, K, (self.clips,), generator=g),
+                    torch.tensor(index), {})
+        return torch.randn(3, T, S, S, generator=g), torch.randint(0, K, (1,), generator=g)[0], torch.tensor(index), {}
+
+
 def create_sampler(dataset, shuffle, cfg):
     """lib/datasets/utils.py:358-370: a DistributedSampler whenever the job has more than one GPU process."""
     if cfg.NUM_GPUS * max(1, cfg.NUM_SHARDS) > 1 and dist.is_available() and dist.is_initialized():
@@ -93,10 +117,14 @@ def construct_loader(cfg, split="train", num_videos=None, batch_size=None):
         ds = SyntheticTestClips(cfg, n)
         bs = batch_size or max(1, int(cfg.TEST.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
         shuffle, drop_last = False, False
+    elif split == "val":
+        ds = SyntheticValClips(cfg, max(1, n // 2))
+        bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
+        shuffle, drop_last = False, False
     else:
         ds = SyntheticHowTo100M(cfg, n)
         bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
-        shuffle, drop_last = split == "train", split == "train"
+        shuffle, drop_last = True, True
     sampler = create_sampler(ds, shuffle, cfg)
     return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(False if sampler else shuffle), sampler=sampler,
                                        num_workers=0, drop_last=drop_last,

@@ -140,25 +140,45 @@ class GradReducer:
     `find_unused` (the reference builds DDP with find_unused_parameters=True, lib/models/build.py:51): a parameter
     that received no gradient on ANY rank keeps `.grad is None`, so the optimiser skips it exactly as torch.optim
     does; one that was used on some rank gets the summed gradient on every rank.  The per-parameter "used" flags ride
-    in the tail of the flat buffer (no extra collective); reading them back costs one host sync per step.  With
-    `find_unused=False` (every parameter is known to be used every step) there is no sync.
+    in the tail of the flat buffer (no extra collective).  Modes:
+      True / "sync"   read the reduced flags back every step (one host sync per step: the host cannot run ahead);
+      "cached"        (train() default, env PVRL_FIND_UNUSED) the reduced flags are read back on the FIRST step with a
+                      given local used-pattern; later steps with that pattern reuse the decision without a sync, and
+                      every step's flags are checked one step late from a pinned host copy (a changed pattern on some
+                      other rank is then seen: warning + the mode drops to "sync" for the rest of the run);
+      False / "off"   every parameter is known to be used every step: no flags, no sync (bench.py).
+
+    `grad_comm` (env PVRL_GRAD_COMM = "f32" | "bf16"): payload type of the all-reduce.  "bf16" casts each chunk on the
+    communication stream, reduces the 16-bit copy (269 instead of 538 MB per step for ViT-B) and writes the sum back
+    into the fp32 buffer -- SURVEY 8e's half-payload option as a switch.
     """
 
-    def __init__(self, vt, enabled=None, find_unused=True):
+    def __init__(self, vt, enabled=None, find_unused=True, grad_comm=None):
         self.vt = vt
         self.enabled = (get_world_size() > 1) if enabled is None else enabled
-        self.find_unused = find_unused
+        fu = {True: "sync", False: "off", None: "sync"}.get(find_unused, find_unused)
+        assert fu in ("sync", "cached", "off"), fu
+        self.find_unused = fu
+        self.grad_comm = (grad_comm or os.environ.get("PVRL_GRAD_COMM", "f32")).lower()
+        assert self.grad_comm in ("f32", "bf16"), self.grad_comm
         self.sync = True
         self.handles = []
         self.done = []
         self._comm = None
         self._masks = {}
+        self._decided = {}       # "cached": local used-pattern -> the reduced (global) pattern seen with it
+        self._pending = None     # "cached": (event, pinned flags, assumed pattern) of the last unchecked step
+        self.host_syncs = 0      # flag read-backs that blocked the host (tests / diagnostics)
         vt.engine.grad_hook = self._hook if self.enabled else None
+
+    def _block_params(self, i):
+        gs = self.vt.grad_store()
+        pre = f"{getattr(self.vt, 'block_prefix', 'blocks.')}{i}."
+        return [k for k, n in enumerate(gs.names) if n.startswith(pre)]
 
     def _block_range(self, i):
         gs = self.vt.grad_store()
-        pre = f"{getattr(self.vt, 'block_prefix', 'blocks.')}{i}."
-        idx = [k for k, n in enumerate(gs.names) if n.startswith(pre)]
+        idx = self._block_params(i)
         return gs.span(idx[0])[0], gs.span(idx[-1])[1]
 
     def _comm_stream(self, device):
@@ -169,8 +189,14 @@ class GradReducer:
     def _reduce(self, t):
         """async all-reduce of a slice of the flat buffer, ordered after everything enqueued so far on the main stream
         and on the engine's weight-gradient side stream"""
+        half = self.grad_comm == "bf16"
         if not t.is_cuda:
-            self.handles.append(dist.all_reduce(t, async_op=True))
+            if half:
+                c = t.to(torch.bfloat16)
+                dist.all_reduce(c)
+                t.copy_(c)
+            else:
+                self.handles.append((dist.all_reduce(t, async_op=True), None, None))
             return
         comm = self._comm_stream(t.device)
         comm.wait_event(torch.cuda.current_stream().record_event())
@@ -178,22 +204,76 @@ class GradReducer:
         if side is not None:
             comm.wait_event(side.record_event())
         with torch.cuda.stream(comm):
-            self.handles.append(dist.all_reduce(t, async_op=True))
+            if half:
+                c = t.to(torch.bfloat16)         # allocated, reduced and consumed on the communication stream
+                self.handles.append((dist.all_reduce(c, async_op=True), t, c))
+            else:
+                self.handles.append((dist.all_reduce(t, async_op=True), None, None))
+
+    def _wait_all(self, device):
+        if device.type != "cuda":
+            for h, _, _ in self.handles:
+                h.wait()
+        else:
+            comm = self._comm_stream(device)
+            with torch.cuda.stream(comm):
+                for h, t, c in self.handles:
+                    h.wait()                    # the communication stream waits for the collective ...
+                    if c is not None:
+                        t.copy_(c)              # ... and widens the 16-bit sum back into the fp32 buffer
+            torch.cuda.current_stream().wait_stream(comm)
+        self.handles = []
+
+    def _settle(self, gs, k):
+        """parameter k is about to be all-reduced: its slot of the flat buffer must hold THIS step's gradient of this rank
+        -- zeros when the rank produced none (zero_grad(set_to_none=True) does not clear the buffer), the values of a
+        gradient tensor somebody else allocated otherwise"""
+        p, v = gs.params[k], gs.views[k]
+        if p.grad is None:
+            v.zero_()
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
 
     def _hook(self, i):
         if not self.sync:
             return
-        a, b = self._block_range(i)
-        self._reduce(self.vt.grad_store().flat[a:b])
+        gs = self.vt.grad_store()
+        idx = self._block_params(i)
+        for k in idx:           # (on the main stream, i.e. before the event the all-reduce is ordered behind)
+            self._settle(gs, k)
+        a, b = gs.span(idx[0])[0], gs.span(idx[-1])[1]
+        self._reduce(gs.flat[a:b])
         self.done.append((a, b))
+
+    def _check_pending(self, block=False):
+        """"cached" mode: compare the flags of an earlier step (pinned host copy) with the pattern that step assumed"""
+        if self._pending is None:
+            return
+        ev, host, assumed = self._pending
+        if not block and not ev.query():
+            return
+        ev.synchronize()
+        self._pending = None
+        if tuple(bool(x) for x in (host > 0).tolist()) != assumed:
+            import warnings
+            warnings.warn("GradReducer(find_unused='cached'): the set of parameters used on SOME rank changed between steps; "
+                          "one optimiser step ran with the previous set.  Falling back to find_unused='sync' (one host sync "
+                          "per step).")
+            self.find_unused = "sync"
+            self._decided = {}
 
     def finish(self):
         if not self.enabled:
             return
-        gs0 = self.vt.grad_store()
-        had = [p.grad is not None for p in gs0.params]          # host-side knowledge, before the buffer is adopted
-        gs = self.vt.adopt_grads(keep_none=True)
-        if self.find_unused:
+        gs = self.vt.grad_store()
+        had = [p.grad is not None for p in gs.params]           # host-side knowledge, before the buffer is adopted
+        reduced = sorted(self.done)
+        in_done = lambda a: any(x <= a < y for x, y in reduced)
+        for k in range(len(gs.params)):                         # block parameters were settled (and sent) by the hook
+            if not in_done(gs.offsets[k]):
+                self._settle(gs, k)
+        if self.find_unused != "off":
             key = tuple(had)                 # a pageable host->device copy would block the host until the backward has
             m = self._masks.get(key)         # drained: the handful of distinct patterns are cached on the device
             if m is None or m.device != gs.used.device:
@@ -201,13 +281,27 @@ class GradReducer:
                 self._masks[key] = m
             gs.used.copy_(m)
         cur = 0
-        for a, b in sorted(self.done) + [(gs.flat.numel(), gs.flat.numel())]:
+        for a, b in reduced + [(gs.flat.numel(), gs.flat.numel())]:
             if a > cur:
                 self._reduce(gs.flat[cur:a])
             cur = max(cur, b)
-        for h in self.handles:
-            h.wait()                                            # the current (main) stream waits for the collectives
-        self.handles, self.done = [], []
-        used = (gs.used > 0).tolist() if self.find_unused else [True] * len(had)
+        self._wait_all(gs.flat.device)                          # the current (main) stream waits for the collectives
+        self.done = []
+        if self.find_unused == "off":
+            used = [True] * len(had)
+        else:
+            if self.find_unused == "cached":
+                self._check_pending()
+            used = self._decided.get(tuple(had)) if self.find_unused == "cached" else None
+            if used is None:
+                self._check_pending(block=True)
+                used = tuple(bool(x) for x in (gs.used > 0).tolist())          # host sync
+                self.host_syncs += 1
+                if self.find_unused == "cached":
+                    self._decided[tuple(had)] = used
+            elif gs.used.is_cuda:
+                host = torch.empty(gs.used.shape, dtype=gs.used.dtype, pin_memory=True)
+                host.copy_(gs.used, non_blocking=True)
+                self._pending = (torch.cuda.current_stream().record_event(), host, used)
         for p, v, u in zip(gs.params, gs.views, used):
             p.grad = v if u else None

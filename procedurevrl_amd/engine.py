@@ -109,8 +109,11 @@ class GradStore:
 
     def begin_scaled(self, g):
         """g: the fp32 gradient entering the engine -> g * S; registers S for target() / unscale()"""
-        amax = g.detach().abs().max().clamp_min(1e-30)
-        self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)))
+        # a non-finite incoming gradient (amax = inf / nan) must not turn S into 0 and 1/S into inf: S stays a finite power
+        # of two, so the non-finite values flow through to the loss check (train_epoch) instead of poisoning gradients
+        # accumulated by earlier micro-iterations
+        amax = torch.nan_to_num(g.detach().abs().max(), nan=1.0, posinf=3e38).clamp(1e-30, 3e38)
+        self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)).clamp(-100.0, 100.0))
         self._touched, self._seen_idx, self._seen_ptr = [], set(), set()
         return g * self.scale
 
@@ -263,14 +266,14 @@ class GraphReplay:
             return self._eager_backward(dfeat)
         gb = g[slot]
         gb["dfeat"].copy_(dfeat)
+        for p, v in gb["touched"]:      # before the hooks run: the reducer treats a parameter without .grad as unused
+            p.grad = v
         if not staged:
             gb["graphs"][0].replay()
         else:
             for k, graph in enumerate(gb["graphs"]):
                 graph.replay()
                 self.grad_hook(nb - 1 - k)
-        for p, v in gb["touched"]:
-            p.grad = v
         self.saved = None
         self._gkey = None
 

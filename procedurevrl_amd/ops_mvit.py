@@ -150,6 +150,11 @@ def keymap(k_thw, device):
     key = (tuple(k_thw), str(device), str(OP16))
     km = _KEYMAPS.get(key)
     if km is None:
+        # a buffer cached process-wide must not be born inside a HIP-graph capture (it would live in the graph's private
+        # pool and only be filled on replay): MViTEngine builds every geometry's map in its eager warm-up calls
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops_mvit.keymap(): first use of a key geometry inside a HIP-graph capture; run the shape "
+                               "eagerly once first (GraphReplay.GRAPH_WARMUP >= 1)")
         L = lib()
         km = torch.empty(L.call("pvrl_mvit_attn_keymap_bytes", *k_thw), device=device, dtype=torch.uint8)
         L.call("pvrl_mvit_attn_keymap", *k_thw, _ptr(km), _stream())

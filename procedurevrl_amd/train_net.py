@@ -91,14 +91,101 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
     return None
 
 
+class ValMeter:
+    """lib/utils/meters.py:420-580 (single-label branch): windowed-median minibatch errors for the `val_iter` lines,
+    sample-weighted epoch errors and their running minima for the `val_epoch` line."""
+
+    def __init__(self, max_iter, cfg):
+        self._cfg = cfg
+        self.max_iter = max_iter
+        self.min_top1_err = 100.0
+        self.min_top5_err = 100.0
+        self.reset()
+
+    def reset(self):
+        self.win1, self.win5 = [], []
+        self.num_top1_mis = 0.0
+        self.num_top5_mis = 0.0
+        self.num_samples = 0
+        self.all_preds, self.all_labels = [], []
+        self.t0 = time.perf_counter()
+
+    def update_stats(self, top1_err, top5_err, mb_size):
+        p = self._cfg.LOG_PERIOD
+        self.win1 = (self.win1 + [top1_err])[-p:]
+        self.win5 = (self.win5 + [top5_err])[-p:]
+        self.num_top1_mis += top1_err * mb_size
+        self.num_top5_mis += top5_err * mb_size
+        self.num_samples += mb_size
+
+    def update_predictions(self, preds, labels):
+        self.all_preds.append(preds)
+        self.all_labels.append(labels)
+
+    def log_iter_stats(self, cur_epoch, cur_iter):
+        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
+            return
+        med = lambda w: float(torch.tensor(w).median())
+        log_json_stats({"_type": "val_iter", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
+                        "iter": "{}/{}".format(cur_iter + 1, self.max_iter), "top1_err": med(self.win1),
+                        "top5_err": med(self.win5)})
+
+    def log_epoch_stats(self, cur_epoch):
+        top1_err = self.num_top1_mis / self.num_samples
+        top5_err = self.num_top5_mis / self.num_samples
+        self.min_top1_err = min(self.min_top1_err, top1_err)
+        self.min_top5_err = min(self.min_top5_err, top5_err)
+        self.stats = {"_type": "val_epoch", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
+                      "time_diff": time.perf_counter() - self.t0, "top1_err": top1_err, "top5_err": top5_err,
+                      "min_top1_err": self.min_top1_err, "min_top5_err": self.min_top5_err}
+        log_json_stats(self.stats)
+        return self.stats
+
+
+@torch.no_grad()
+def eval_epoch(val_loader, model, val_meter, cur_epoch, cfg):
+    """tools/train_net.py:251-350 (single-label branch; the EPIC verb/noun branch is outside SURVEY 8): eval-mode forward
+    (softmax probabilities, vit.py:355-356), top-1 / top-5 error of the minibatch, averaged over ranks (`du.all_reduce`,
+    here as ONE two-float collective), fed to the ValMeter; `val_iter` / `val_epoch` json lines."""
+    model.eval()
+    dev = next(model.parameters()).device
+    world = du.get_world_size()
+    for cur_iter, (inputs, labels, _index, _meta) in enumerate(val_loader):
+        inputs = inputs.to(dev, non_blocking=True)
+        labels = labels.to(dev)
+        preds = model(inputs)
+        if labels.dim() > 1 and labels.numel() == preds.size(0):       # [b, clips] labels of a clips-per-video batch
+            labels = labels.reshape(-1)
+        k5 = min(5, preds.shape[1])
+        c1, c5 = topks_correct(preds, labels, (1, k5))
+        errs = du.all_reduce_scalars([(1.0 - c1 / preds.size(0)) * 100.0, (1.0 - c5 / preds.size(0)) * 100.0])
+        top1_err, top5_err = errs.tolist()                             # train_net.py:340: the reference syncs here too
+        val_meter.update_stats(top1_err, top5_err, inputs.size(0) * max(world, 1))
+        val_meter.update_predictions(preds, labels)
+        val_meter.log_iter_stats(cur_epoch, cur_iter)
+    stats = val_meter.log_epoch_stats(cur_epoch)
+    val_meter.reset()
+    return stats
+
+
+def is_eval_epoch(cfg, cur_epoch):
+    """lib/utils/misc.py:189-210 without the multigrid schedule (no shipped ViT / MViT config uses it)"""
+    if cur_epoch + 1 == cfg.SOLVER.MAX_EPOCH:
+        return True
+    return (cur_epoch + 1) % cfg.TRAIN.EVAL_PERIOD == 0
+
+
 def train(cfg, max_iters=None):
     du.init_distributed_training(cfg)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg)
     optimizer = optim.construct_optimizer(model, cfg)
     start_epoch = cu.load_train_checkpoint(cfg, model, optimizer)
-    reducer = du.GradReducer(model.model)
+    # DDP(find_unused_parameters=True) of lib/models/build.py:51 without a host sync per step: see GradReducer
+    reducer = du.GradReducer(model.model, find_unused=os.environ.get("PVRL_FIND_UNUSED", "cached"))
     train_loader = construct_loader(cfg, "train")
+    val_loader = construct_loader(cfg, "val")
+    val_meter = ValMeter(len(val_loader), cfg)
     dev = next(model.parameters()).device
     if dev.type == "cuda":
         train_loader = DevicePrefetcher(train_loader, dev)       # H2D copy of batch i+1 under step i
@@ -107,4 +194,6 @@ def train(cfg, max_iters=None):
         train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_iters)
         if cu.is_checkpoint_epoch(cfg, cur_epoch):
             cu.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch, cfg)
+        if is_eval_epoch(cfg, cur_epoch):                      # train_net.py:516-518
+            train.last_val_stats = eval_epoch(val_loader, model, val_meter, cur_epoch, cfg)
     return model, optimizer

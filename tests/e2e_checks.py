@@ -75,7 +75,7 @@ def make_cfg(depth, crop, K, text=False, text_layers=2, order=False, drop_path=0
 def build(cfg, label_emb, state=None):
     from procedurevrl_amd.build import build_model
     cfg.TRAIN.LABEL_EMB = label_emb
-    model = build_model(cfg, gpu_id=0)
+    model = build_model(cfg, gpu_id=torch.device(DEV).index or 0)
     if state is not None:
         missing, unexpected = model.load_state_dict(state, strict=True), None
     return model
@@ -302,6 +302,12 @@ def check_timed_config_train_step():
     return _hip_vs_oracle(12, 224, 9871, 32, seed=17, tag="32 clips (timed config): ", rounding_model=False, micro=4)
 
 
+def check_bench_config_two_clips():
+    """bench.py --parity-probe: the benchmark's model (12 blocks, 8 x 224^2, K = 9871) on 2 clips, one training step vs the
+    oracle -- cheap enough (a few seconds of CPU) to ride along with a timed run of either library flavour"""
+    return _hip_vs_oracle(12, 224, 9871, 2, seed=19, tag="2 clips (bench model): ", rounding_model=False)
+
+
 def check_text_tower_full_size():
     """Row T1 at real size: the frozen CLIP-text teacher as the reference instantiates it (ViT-B/16 text half: 12 layers,
     width 512, 8 heads, context 77, vocabulary 49,408, causal mask; lib/models/vit.py:258-261,425-433) on 36 narrations
@@ -366,7 +372,7 @@ def check_forecast_eval_golden():
         cfg.DEV.TEST_LANG_EMB = path
         cfg.TRAIN.LABEL_EMB = ""
         from procedurevrl_amd.build import build_model
-        model = build_model(cfg, gpu_id=0)
+        model = build_model(cfg, gpu_id=torch.device(DEV).index or 0)
     model.load_state_dict(orc.seeded_state(tg.forecast_state(f), f["seed"]), strict=True)
     model.to(DEV).eval()
     with torch.no_grad():

@@ -94,6 +94,47 @@ def _worker(rank, world, port, results):
     out["unused_none"] = gs.params[i_none].grad is None
     out["half_used"] = sorted(set(gs.params[i_half].grad.reshape(-1).tolist()))    # rank 0's 1.0 + rank 1's zeros
     out["others_3"] = all(bool(torch.all(p.grad == 3.0)) for k, p in enumerate(gs.params) if k not in (i_none, i_half))
+    # --- a BLOCK parameter unused on one rank: its slot still holds the previous step's values (zero_grad
+    # (set_to_none) never clears the flat buffer) and is sent by the per-block hook, before finish(): the hook must zero it
+    for p in gs.params:
+        p.grad = None
+    gs.flat[:gs.end].fill_(777.0)                                        # stale values from "the previous step"
+    i_blk = names.index("blocks.1.mlp.fc1.weight")
+    for k, (p, view) in enumerate(zip(gs.params, gs.views)):
+        if k == i_blk and rank == 1:
+            continue
+        view.fill_(float(rank + 1))
+        p.grad = view
+    for i in reversed(range(len(vt.blocks))):
+        vt.engine.grad_hook(i)
+    red.finish()
+    out["blk_half_used"] = sorted(set(gs.params[i_blk].grad.reshape(-1).tolist()))   # rank 0's 1.0 + zeros, not + 777
+    out["blk_others_3"] = all(bool(torch.all(p.grad == 3.0)) for k, p in enumerate(gs.params) if k != i_blk)
+    # --- find_unused="cached": the reduced flags are read back once per local pattern, not once per step
+    red_c = du.GradReducer(vt, find_unused="cached")
+    for step in range(4):
+        for p in gs.params:
+            p.grad = None
+        for k, (p, view) in enumerate(zip(gs.params, gs.views)):
+            if k == i_none:
+                continue
+            view.fill_(float(rank + 1))
+            p.grad = view
+        for i in reversed(range(len(vt.blocks))):
+            vt.engine.grad_hook(i)
+        red_c.finish()
+    out["cached_syncs"] = red_c.host_syncs
+    out["cached_none"] = gs.params[i_none].grad is None and all(p.grad is not None for k, p in enumerate(gs.params) if k != i_none)
+    # --- 16-bit gradient payload (PVRL_GRAD_COMM=bf16): cast, reduce, widen back
+    red_h = du.GradReducer(vt, find_unused=False, grad_comm="bf16")
+    for p, view in zip(gs.params, gs.views):
+        p.grad = view
+    gs.flat[:gs.end].fill_(0.375 * (rank + 1))                            # exactly representable: the sum must be exact
+    for i in reversed(range(len(vt.blocks))):
+        vt.engine.grad_hook(i)
+    red_h.finish()
+    out["bf16_comm"] = sorted(set(torch.cat([v.reshape(-1) for v in gs.views]).tolist()))
+    du.GradReducer(vt)                                                    # (re-installs the default hook)
     # --- per-rank data sharding (lib/datasets/utils.py:358-370 DistributedSampler, loader.py:140-157 set_epoch)
     from procedurevrl_amd.config import get_cfg
     from procedurevrl_amd import datasets as ds
@@ -126,6 +167,9 @@ def test_two_rank_gloo():
         assert r["reducer_all_3"] and r["head_adopted"], r
         assert r["accum_sum"] == [333.0], r["accum_sum"]
         assert r["unused_none"] and r["half_used"] == [1.0] and r["others_3"], r
+        assert r["blk_half_used"] == [1.0] and r["blk_others_3"], r
+        assert r["cached_syncs"] == 1 and r["cached_none"], r
+        assert r["bf16_comm"] == [1.125], r
         assert r["batch"] == 2
     for epoch in range(2):      # the two ranks see disjoint videos that together cover the dataset; epochs are shuffled differently
         a, b = results[0]["seen"][epoch], results[1]["seen"][epoch]

@@ -105,3 +105,34 @@ def test_device_prefetcher_yields_the_loaders_batches_on_the_device(tmp_path):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
         for k in b[3]:
             assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.gpu
+def test_eval_epoch_runs_every_eval_period_and_matches_recomputation(tmp_path, capsys):
+    """tools/train_net.py:251-350, 516-518: train() evaluates every TRAIN.EVAL_PERIOD epochs (and after the last one); the
+    logged `val_epoch` top-1 / top-5 errors equal a recomputation from the model's own eval forward on the val split."""
+    import json
+    from procedurevrl_amd import train_net as tn
+    from procedurevrl_amd.datasets import construct_loader
+    cfg = _cfg(tmp_path)
+    cfg.SOLVER.MAX_EPOCH = 3
+    cfg.TRAIN.EVAL_PERIOD = 2
+    cfg.TRAIN.CHECKPOINT_PERIOD = 10
+    model, _ = tn.train(cfg, max_iters=1)
+    lines = [json.loads(l.split("json_stats: ", 1)[1]) for l in capsys.readouterr().out.splitlines() if "json_stats: " in l]
+    val = [l for l in lines if l["_type"] == "val_epoch"]
+    assert [l["epoch"] for l in val] == ["2/3", "3/3"], val          # epoch 2 (period) and epoch 3 (last)
+    # recomputation on the final weights: per-batch errors weighted by batch size, as the meter does
+    model.eval()
+    mis1 = mis5 = n = 0.0
+    with torch.no_grad():
+        for inputs, labels, _, _ in construct_loader(cfg, "val"):
+            p = model(inputs.cuda())
+            lab = labels.cuda().reshape(-1)
+            top = p.topk(5, dim=1).indices
+            e1 = 100.0 * (1.0 - float((top[:, 0] == lab).float().mean()))
+            e5 = 100.0 * (1.0 - float((top == lab[:, None]).any(1).float().mean()))
+            mis1 += e1 * inputs.size(0); mis5 += e5 * inputs.size(0); n += inputs.size(0)
+    assert abs(val[-1]["top1_err"] - mis1 / n) < 1e-3 and abs(val[-1]["top5_err"] - mis5 / n) < 1e-3, (val[-1], mis1 / n, mis5 / n)
+    assert val[-1]["min_top1_err"] <= val[0]["top1_err"] + 1e-9
+    assert tn.train.last_val_stats["_type"] == "val_epoch"

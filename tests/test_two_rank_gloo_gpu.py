@@ -11,7 +11,9 @@ import pytest
 import torch
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo", grad_comm="f32"):
+    """backend "gloo": both ranks on cuda:0 (one GPU is enough); "nccl": REAL RCCL, rank r on cuda:r
+    (tests/test_rccl_multi_gpu.py, needs >= 2 GPUs)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -20,18 +22,23 @@ def _worker(rank, world, port, out_dir):
     from procedurevrl_amd import distributed as du
     from procedurevrl_amd.datasets import synthetic_label_emb
     from procedurevrl_amd.functional import kl_topk_loss
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    ec.DEV = dev
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     cfg = ec.make_cfg(2, 32, 64)
-    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1)).to("cuda:0").train()
+    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1)).to(dev).train()
     vt = model.model
     with torch.no_grad():
         for blk in vt.blocks:
             torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
-    g = torch.Generator(device="cuda:0").manual_seed(100 + rank)            # a different batch per rank
-    x = torch.randn(4, 3, 8, 32, 32, device="cuda:0", generator=g)
-    teacher = torch.randn(4, 64, device="cuda:0", generator=g) * 3
+    g = torch.Generator(device=dev).manual_seed(100 + rank)                 # a different batch per rank
+    x = torch.randn(4, 3, 8, 32, 32, device=dev, generator=g)
+    teacher = torch.randn(4, 64, device=dev, generator=g) * 3
 
     def step(reducer):
         model.zero_grad(set_to_none=True)
@@ -42,13 +49,14 @@ def _worker(rank, world, port, out_dir):
         return gs.flat[:gs.end].clone()
 
     own = step(None)                                                         # this rank's gradients, no communication
-    reducer = du.GradReducer(vt)
-    assert reducer.enabled and vt.engine.grad_hook is not None
+    reducer = du.GradReducer(vt, grad_comm=grad_comm)
+    assert reducer.enabled and vt.engine.grad_hook is not None and dist.get_world_size() == world
     res = []
     for _ in range(vt.engine.GRAPH_WARMUP + 3):                              # eager, eager, capture (staged), replay, replay
         res.append(step(reducer))
     staged = any("bwd_staged" in g for g in vt.engine._graphs.values())
-    torch.save(dict(own=own.cpu(), reduced=[r.cpu() for r in res], staged=staged), os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(dict(own=own.cpu(), reduced=[r.cpu() for r in res], staged=staged, backend=dist.get_backend(),
+                    device=str(x.device)), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
