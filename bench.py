@@ -249,7 +249,9 @@ def main():
         }
         if timing:
             out["roofline"] = timing["roofline"]
-            out["roofline"]["traffic"] = pmc_traffic(timing["roofline"]["kernel"])
+            # HBM bytes per launch come from the committed PMC passes of THIS configuration (profiles/): configs[1] only
+            base_cfg = args.arch == "vit" and args.frames == 8 and B == 32
+            out["roofline"]["traffic"] = pmc_traffic(timing["roofline"]["kernel"]) if base_cfg else None
             if isolated:
                 out["roofline"]["isolated"] = isolated
             out["kernels"] = timing["summary"]
@@ -300,18 +302,23 @@ def side_measurements():
     import subprocess
     res = []
     base = ["--no-cpu-baseline", "--no-side"]
-    for name, extra, env in (
+    full = os.path.join(ROOT, "tools", "bench_full_step.py")
+    for name, extra, env, script in (
             ("configs[1] with fp16 operands (PVRL_OPERAND=f16, libpvrl_hip_f16.so): TimeSformer ViT-B 8x224^2, 32 clips/GPU",
-             ["--steps", "20", "--warmup", "5", "--parity-probe"], {"PVRL_OPERAND": "f16"}),
-            ("configs[3]: TimeSformer ViT-B 32x224^2, 8 clips/GPU", ["--steps", "10", "--warmup", "3", "--frames", "32", "--batch", "8"], {}),
-            ("configs[4]: MViTv2-S 16x224^2, 32 clips/GPU", ["--steps", "10", "--warmup", "3", "--arch", "mvit"], {})):
-        cmd = [sys.executable, os.path.abspath(__file__)] + base + extra
+             ["--steps", "20", "--warmup", "5", "--parity-probe"], {"PVRL_OPERAND": "f16"}, None),
+            ("configs[3]: TimeSformer ViT-B 32x224^2, 8 clips/GPU", ["--steps", "10", "--warmup", "3", "--frames", "32", "--batch", "8"], {}, None),
+            ("configs[4]: MViTv2-S 16x224^2, 32 clips/GPU", ["--steps", "10", "--warmup", "3", "--arch", "mvit"], {}, None),
+            ("the reference's FULL pre-training step (vit.py:283-352, train_net.py:152-181): 4 videos x 9 clips of 8x224^2, frozen "
+             "12-layer CLIP-text teacher + order / diffusion transformer + top-5 KL + MSE + AdamW, head replayed from HIP graphs",
+             ["--steps", "10", "--warmup", "6"], {}, full)):
+        cmd = [sys.executable, script] + extra if script else [sys.executable, os.path.abspath(__file__)] + base + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=dict(os.environ, **env))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
             e = {"config": name, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"],
-                 "ms_per_step": d["ms_per_step"], "steps": d["steps"], "frac_of_bf16_peak": d["end_to_end"]["frac_of_bf16_peak"]}
+                 "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                 "frac_of_bf16_peak": d.get("end_to_end", {}).get("frac_of_bf16_peak")}
             if "roofline" in d:
                 e["roofline"] = d["roofline"]
             if "parity" in d:

@@ -17,6 +17,8 @@ OPERAND = os.environ.get("PVRL_OPERAND", "bf16").lower()
 if OPERAND not in ("bf16", "f16"):
     raise RuntimeError(f"PVRL_OPERAND={OPERAND!r}: expected 'bf16' or 'f16'")
 LIB_PATH = os.path.join(_HERE, "csrc", "libpvrl_hip.so" if OPERAND == "bf16" else "libpvrl_hip_f16.so")
+# A/B runs of a differently-built library (tools/build_variant.py: same sources, extra -D switches); never set in production
+LIB_PATH = os.environ.get("PVRL_LIB_PATH", LIB_PATH)
 
 
 def operand_torch_dtype():

@@ -40,8 +40,16 @@ struct GemmNT {
 };
 
 constexpr int BK = 64;
-// rasterisation group height: measured on MI355X, 2 tile rows per group is 1-3 % ahead of 8-32 (A rows stay hot while W cycles)
-constexpr int NT_GM = 2;
+// rasterisation group height (tile rows per group).  Round 3 sweep with the variants interleaved in random order
+// (profiles/r3_nt_cache_policy.txt): 2, 3, 4, 6, 8 are within +-1.5 % on every 50k-row shape; 4 fetches 10-16 % fewer bytes
+// than 2 on the wide outputs (N >= 2304: the group's 2 A panels no longer cycle the whole W through L2 per 24 tiles) and
+// 5-10 % more on N = 768, where 2 keeps both the A panels and the 1.2-4.7 MB W resident.  In-step (same box, interleaved):
+// gm 4 everywhere 579-581 clips/s, gm 2 575-576, gm 3 573-575 -> 4 for wide outputs, 2 otherwise.
+#ifndef PVRL_NT_GM
+#define PVRL_NT_GM 0
+#endif
+constexpr int NT_GM = PVRL_NT_GM;       // 0 = by shape (nt_gm_for), otherwise forced (probe builds)
+static inline int nt_gm_for(int tiles_n) { return NT_GM ? NT_GM : (tiles_n >= 8 ? 4 : 2); }
 
 __device__ __forceinline__ int swz_x(int row) { return (row >> 1) & 7; }
 // W rows are read in a permuted order so that the lanes of one epilogue store instruction write contiguous bytes:
@@ -57,12 +65,43 @@ template <bool F32OUT> __device__ __forceinline__ int swz_w(int row) {
   return ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
 }
 
+// ---- cache policy of the epilogue's memory traffic (gfx950 `aux` bits of the raw buffer instructions: 1 = sc0, 2 = nt,
+// 16 = sc1).  An epilogue GEMM streams hundreds of MB exactly once -- the fp32 residual / stored pre-activation in, the
+// outputs out (consumed by a LATER kernel) -- through a 4 MiB XCD L2 that should be holding the W tiles and A panels the
+// main loop re-reads: with default-policy stores every output line is kept in L2 and evicts them (round 2: the GELU GEMM
+// fetched 480 MB per launch against 82 MB of operands).  `sc1` stores are written through and dropped (MI355X guide,
+// "stores of each flavour"); `nt` marks the read-once loads as streaming.  Swept on MI355X: profiles/r3_nt_cache_policy.txt.
+#ifndef PVRL_NT_ST_AUX
+#define PVRL_NT_ST_AUX 0
+#endif
+#ifndef PVRL_NT_LD_AUX
+#define PVRL_NT_LD_AUX 0
+#endif
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// descriptor over `rows` rows of a row-major matrix starting at `base` (all arguments wave-uniform: kernel arguments and
+// blockIdx-derived tile origins).  Offsets past the last row are dropped (stores) / read as zero (loads) by the hardware
+// bounds check: the ragged last M-tile needs no per-row guard.
+__device__ __forceinline__ rsrc_t tile_rsrc(const void* base, long row0, long ld, int elem, int rows) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + row0 * ld * elem), 0, (int)(rows * ld * elem), 0x00020000);
+}
+template <int AUX> __device__ __forceinline__ void bst16(rsrc_t r, unsigned off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX);
+}
+template <int AUX> __device__ __forceinline__ void bst16(rsrc_t r, unsigned off, opx8 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX);
+}
+template <int AUX, typename T> __device__ __forceinline__ T bld16(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
+}
+
 template <int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
   constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr int ST = PVRL_NT_ST_AUX, LD = PVRL_NT_LD_AUX;
   // ---- epilogue ----
   const int q = lane >> 4, i = lane & 15;
   const int nw0 = n0 + wn * 64;
+  const int rows = min(1024, p.M - m0);    // rows of the matrices from the tile's first row on (any bound >= the tile height that keeps the byte count in 31 bits)
   if constexpr (F32OUT) {
     // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
     f32x4 bv[4];
@@ -90,30 +129,38 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
       }
     }
     const bool b2_late = EPI == PVRL_EPI_RESID_F32 && p.bias2 && p.rowscale;
+    const rsrc_t ro = tile_rsrc(p.out0, m0, p.ld0, 4, rows);
+    const unsigned ocol = (unsigned)(nw0 + 8 * q) * 4u;
+    // the residual: rows of the tile (streamed once: LD policy), or rows modulo aux_rowmod of a small table every clip
+    // re-reads (pos / time embedding prologue: default policy)
+    const bool tab = EPI == PVRL_EPI_RESID_F32 && p.aux_rowmod != 0;
+    const rsrc_t ra = EPI == PVRL_EPI_RESID_F32 ? (tab ? tile_rsrc(p.aux, 0, p.aux_ld, 4, p.aux_rowmod) : tile_rsrc(p.aux, m0, p.aux_ld, 4, rows)) : ro;
     // (Measured and rejected: finishing all 16 tiles in place and storing last, so that the second half's residual loads are
     //  not queued behind the first half's stores: -0.4 % on the step -- the early stores start the write traffic sooner.)
     // The residual loads of TWO row tiles (32 registers, freed by the MFMA fragments) go out together, twice: two memory
     // round trips per wave instead of four dependent ones (all 16 at once would spill).  With every CU in its epilogue at
-    // the same time the loaded latency of a round trip is microseconds.  Rows past M load a clamped row and store nothing.
+    // the same time the loaded latency of a round trip is microseconds.
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x4 rv[2][4];
       if constexpr (EPI == PVRL_EPI_RESID_F32) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int m = min(m0 + wm * 64 + (2 * half + h) * 16 + i, p.M - 1);
-          const int mr = p.aux_rowmod ? ((m + p.m_off) % p.aux_rowmod) : m;
-          const float* r = (const float*)p.aux + (long)mr * p.aux_ld + nw0 + 8 * q;
+          const int ml = wm * 64 + (2 * half + h) * 16 + i;                     // row inside the tile
+          const int mr = tab ? ((min(m0 + ml, p.M - 1) + p.m_off) % p.aux_rowmod) : ml;
+          const unsigned ab = (unsigned)mr * (unsigned)p.aux_ld * 4u + ocol;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) rv[h][nt] = *reinterpret_cast<const f32x4*>(r + 32 * (nt >> 1) + 4 * (nt & 1));
+          for (int nt = 0; nt < 4; ++nt) {
+            const unsigned off = ab + (unsigned)(32 * (nt >> 1) + 4 * (nt & 1)) * 4u;
+            rv[h][nt] = tab ? bld16<0, f32x4>(ra, off) : bld16<LD, f32x4>(ra, off);
+          }
         }
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int mt = 2 * half + h;
-        const int m = m0 + wm * 64 + mt * 16 + i;
         const float rs = rs4[mt];
-        float* o = (float*)p.out0 + (long)m * p.ld0 + nw0 + 8 * q;
+        const unsigned ob = (unsigned)(wm * 64 + mt * 16 + i) * (unsigned)p.ld0 * 4u + ocol;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int off = 32 * (nt >> 1) + 4 * (nt & 1);
@@ -127,7 +174,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
               for (int e = 0; e < 4; ++e) ov[e] += __shfl(b2lane, 8 * q + off + e, 64);
             }
           }
-          if (m < p.M) *reinterpret_cast<f32x4*>(o + off) = ov;
+          bst16<ST>(ro, ob + (unsigned)off * 4u, ov);                          // rows past M: dropped by the bounds check
         }
       }
     }
@@ -141,23 +188,27 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     float rs4[4];                      // before the first store (see above)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + wm * 64 + mt * 16 + i, p.M - 1)] : 1.f;
+    constexpr bool TWO = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
+    constexpr bool DACT = EPI == PVRL_EPI_DGELU || EPI == PVRL_EPI_DQGELU;
+    const rsrc_t r0 = tile_rsrc(p.out0, m0, p.ld0, 2, rows);
+    const rsrc_t r1 = TWO ? tile_rsrc(p.out1, m0, p.ld1, 2, rows) : r0;
+    const rsrc_t ra = DACT ? tile_rsrc(p.aux, m0, p.aux_ld, 2, rows) : r0;
+    const unsigned ccol = (unsigned)(nw0 + 8 * q) * 2u;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       opx8 uv[2][2];
-      if constexpr (EPI == PVRL_EPI_DGELU || EPI == PVRL_EPI_DQGELU) {   // the stored pre-activations of two row tiles: one round trip
+      if constexpr (DACT) {   // the stored pre-activations of two row tiles: one round trip
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int m = min(m0 + wm * 64 + (2 * half + h) * 16 + i, p.M - 1);
+          const unsigned ab = (unsigned)(wm * 64 + (2 * half + h) * 16 + i) * (unsigned)p.aux_ld * 2u + ccol;
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
-            uv[h][c] = *reinterpret_cast<const opx8*>((const op_t*)p.aux + (long)m * p.aux_ld + nw0 + 32 * c + 8 * q);
+          for (int c = 0; c < 2; ++c) uv[h][c] = bld16<LD, opx8>(ra, ab + 64u * c);
         }
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int mt = 2 * half + h;
-        const int m = m0 + wm * 64 + mt * 16 + i;
-        if (m >= p.M) continue;
+        const unsigned ml = (unsigned)(wm * 64 + mt * 16 + i);
         const float rs = rs4[mt];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -167,21 +218,21 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
             v[e] = acc[mt][2 * c][e] + bv[c][e];
             v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
           }
-          const long col = nw0 + 32 * c + 8 * q;
+          const unsigned o0off = ml * (unsigned)p.ld0 * 2u + ccol + 64u * c;
           if constexpr (EPI == PVRL_EPI_BF16) {
             opx8 o0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o0[e] = (op_t)(rs * v[e]);
-            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
-          } else if constexpr (EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) {
+            bst16<ST>(r0, o0off, o0);
+          } else if constexpr (TWO) {
             opx8 u0, g0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               u0[e] = (op_t)v[e];
               g0[e] = (op_t)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
             }
-            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = u0;
-            *reinterpret_cast<opx8*>((op_t*)p.out1 + (long)m * p.ld1 + col) = g0;
+            bst16<ST>(r0, o0off, u0);
+            bst16<ST>(r1, ml * (unsigned)p.ld1 * 2u + ccol + 64u * c, g0);
           } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
             const opx8 ua = uv[h][c];
             opx8 o0;
@@ -190,7 +241,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
               const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
               o0[e] = (op_t)(rs * v[e] * d);
             }
-            *reinterpret_cast<opx8*>((op_t*)p.out0 + (long)m * p.ld0 + col) = o0;
+            bst16<ST>(r0, o0off, o0);
           }
         }
       }
@@ -321,6 +372,7 @@ template <int EPI, int WM, int WN>
 int launch_tile(GemmNT p, hipStream_t s) {
   p.tiles_n = p.N / (64 * WN);
   p.tiles_m = cdiv(p.M, 64 * WM);
+  if (p.gm <= 0) p.gm = nt_gm_for(p.tiles_n);
   p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;   // per-XCD tile lists padded to equal length (surplus blocks exit)
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
   PVRL_LAUNCH_CHECK();

@@ -9,6 +9,7 @@ kernel schedule of `engine.EncoderEngine` / `tfm_engine.StackEngine` over libpvr
 no PyTorch fallback: calling the model on CPU tensors raises.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -18,6 +19,7 @@ from . import ops
 from .build import MODEL_REGISTRY
 from .engine import EncoderEngine, GradStore
 from .functional import EncoderFn, kl_topk_loss, l2norm, linear_f32, mse_loss, step_logits
+from .head_engine import PretrainHeadEngine, PretrainHeadFn
 from .tfm_model import ClipTextModel, DiffusionTransformer as OrderTransformer
 
 
@@ -122,6 +124,8 @@ class VisionTransformer(nn.Module):
             self.order_tfm.bind(self)
         if hasattr(self, "text_model"):
             self.text_model.bind(self)
+
+    head_engine = None      # PretrainHeadEngine, created on the first pre-training forward
 
     def _init_heads(self, embed_dim, label_emb, mlp, text_model, num_seg, num_classes, cfg):
         """Projection head, step embeddings, order transformer and frozen text tower (vit.py:228-267; the MViT wrapper
@@ -279,11 +283,16 @@ class VisionTransformer(nn.Module):
 
     def _pretrain_forward(self, feat, text, rng, batch_size):
         teacher_x = self.get_pseudo_labels(feat.device, text)                 # frozen text tower: its own HIP graph
-        # The head below (~1,000 small launches forward + backward) stays eager.  Replaying it from a HIP graph needs
-        # torch.autograd inside a stream capture; on ROCm 7.x that crashes in hipStreamEndCapture as soon as a leaf created on
-        # the default stream takes part (its AccumulateGrad node is bound to the default stream) -- tried in round 2,
-        # DESIGN.md section 7.  On an idle host the step time is the same either way (the host runs ahead of the GPU).
-        return self._pretrain_head(feat, teacher_x, rng, batch_size)
+        if os.environ.get("PVRL_HEAD_ENGINE", "1") != "1":
+            return self._pretrain_head(feat, teacher_x, rng, batch_size)     # the same head wired through torch.autograd (eager)
+        # One autograd node with a hand-written backward (head_engine.PretrainHeadEngine): its ~1,000 small launches are
+        # replayed from two HIP graphs.  (Capturing the autograd-wired head crashes hipStreamEndCapture on ROCm 7.x: an
+        # AccumulateGrad node is bound to the default stream -- round 2)
+        if self.head_engine is None:
+            self.head_engine = PretrainHeadEngine(self)
+        dr = self.head_engine.draws(rng, batch_size, feat.shape[0], feat.device)
+        pred, teacher_out, x0_rep, inter = PretrainHeadFn.apply(self.anchor(), feat, teacher_x, self, dr)
+        return pred, teacher_out, [x0_rep, inter]
 
     def forward(self, x, rng=None):
         """`rng` (optional) pins the random draws of the pre-training forward:

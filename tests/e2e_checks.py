@@ -172,6 +172,75 @@ def check_e2e_golden():
     return out
 
 
+def _e2e_step(model, cfg, f, zero=True):
+    from procedurevrl_amd.vit import pretrain_loss
+    meta = {"clip_text_ids": f["clip_text_ids"].to(DEV), "clip_vis_feat": f["clip_vis_feat"].to(DEV)}
+    rng = dict(order=dict(mask_inds=f["rng"]["mask_inds"].to(DEV), pad_start=f["rng"]["pad_start"].to(DEV),
+                          noises=[n.to(DEV) for n in f["rng"]["noises"]]), rand_inds=f["rng"]["rand_inds"].to(DEV))
+    if zero:
+        for p in model.parameters():
+            p.grad = None
+    pred, teacher, mse = model([f["inputs"].to(DEV), meta], rng=rng)
+    loss, l1, l2 = pretrain_loss(pred, teacher, mse, cfg)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    return dict(pred=pred.detach().clone(), teacher=teacher.detach().clone(), mse0=mse[0].detach().clone(),
+                mse1=mse[1].detach().clone(), l1=float(l1), l2=float(l2), grads=grads)
+
+
+def check_pretrain_head_engine():
+    """head_engine.PretrainHeadEngine (hand-written backward, HIP-graph replay) on the reference's full pre-training
+    step with every random draw pinned (tests/golden/e2e.pt):
+      * against the SAME head wired through torch.autograd (PVRL_HEAD_ENGINE=0): outputs and every gradient;
+      * replayed from its graphs (3rd call on) against the reference's golden outputs, losses and gradients -- the
+        replay must be bit-identical to the eager launches of the engine;
+      * accumulation into existing gradients (second backward without zeroing) = 2x the gradients."""
+    f = load("e2e")
+    cfg, model, full = _e2e_model(f)
+    model.train()
+    vt = model.model
+    os.environ["PVRL_HEAD_ENGINE"] = "0"
+    try:
+        ref = _e2e_step(model, cfg, f)
+    finally:
+        os.environ["PVRL_HEAD_ENGINE"] = "1"
+    eager = _e2e_step(model, cfg, f)                      # engine, eager launches (warm-up call 1)
+    out = [("head engine vs autograd head: pred", rel(eager["pred"], ref["pred"]), 1e-6),
+           ("head engine vs autograd head: mse operands", max(rel(eager["mse0"], ref["mse0"]), rel(eager["mse1"], ref["mse1"])), 1e-6),
+           ("head engine vs autograd head: parameters with a gradient (0 = same set)",
+            float(set(eager["grads"]) != set(ref["grads"])), 0.0)]
+    worst, wk = 0.0, ""
+    for k, g in ref["grads"].items():
+        e = rel(eager["grads"][k], g) if k in eager["grads"] else float("inf")
+        if e > worst:
+            worst, wk = e, k
+    # same kernels on the same operands; only fp32 summation orders of the small glue differ (16-bit operand rounding of the
+    # stack's backward GEMMs can flip on a last-bit difference, hence not 1e-6)
+    out.append((f"head engine vs autograd head: all gradients (worst: {wk})", worst, 2e-3 if OPERAND == "bf16" else 3e-4))
+    _e2e_step(model, cfg, f)                              # warm-up call 2
+    rep = [_e2e_step(model, cfg, f) for _ in range(3)]    # capture + replay, replay, replay
+    he = vt.head_engine
+    out.append(("head engine graphs captured (0 = forward and backward)",
+                0.0 if he is not None and len(he._graphs) == 1 and next(iter(he._graphs.values()))["bwd"] is not None else 1.0, 0.0))
+    for i, r in enumerate(rep):
+        out.append((f"head replay {i}: pred differs from eager engine (count)", float((r["pred"] != eager["pred"]).sum()), 0.0))
+        out.append((f"head replay {i}: gradients differ from eager engine (count)",
+                    float(sum(int((r["grads"][k] != eager["grads"][k]).sum()) for k in eager["grads"])), 0.0))
+    r = rep[-1]
+    out += [("replayed head: pred logits vs reference", rel(r["pred"], f["pred"]), TOL_ACT),
+            ("replayed head: teacher logits vs reference", rel(r["teacher"], f["teacher"]), TOL_ACT),
+            ("replayed head: mse target vs reference", rel(r["mse0"], f["mse0"]), TOL_ACT),
+            ("replayed head: mse pred vs reference", rel(r["mse1"], f["mse1"]), TOL_ACT),
+            ("replayed head: loss1 (KL)", abs(r["l1"] - f["loss1"]) / abs(f["loss1"]), TOL_LOSS),
+            ("replayed head: loss2 (MSE)", abs(r["l2"] - f["loss2"]) / abs(f["loss2"]), TOL_LOSS)]
+    for k, g in f["grads"].items():
+        out.append((f"replayed head: grad {k[6:]}", rel(r["grads"][k], g), TOL_GRAD))
+    acc = _e2e_step(model, cfg, f, zero=False)            # gradients already there: accumulate (eager beta = 1 launches)
+    worst = max(rel(acc["grads"][k], 2.0 * eager["grads"][k]) for k in eager["grads"])
+    out.append(("head engine: second backward accumulates (worst gradient vs 2x)", worst, 1e-5))
+    return out
+
+
 def _oracle_step_micro(sd_cpu, frames, label, teacher, depth, micro):
     """the oracle's step on a batch too large for one autograd graph in host memory (32 clips of 8x224^2 through 12 blocks
     keep ~70 GB of fp32 activations): micro-batches of `micro` clips, gradients accumulated.  KLDivLoss(batchmean) over
@@ -541,6 +610,6 @@ def check_hip_graph_replay():
     return out
 
 
-ALL_CHECKS = [check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
+ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
               check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
               check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step]
