@@ -293,6 +293,10 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* 
 int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float* x, float beta, float* y,
                        void* stream);
 
+/* out[r][c] += a[r] * b[c] (fp32; C and ld multiples of 4): the bias term of the fused temporal branch's chain rule,
+ * dW_fc += db_e b_proj^T -- what autograd adds to temporal_fc.weight.grad through proj's bias, vit.py:131-134. */
+int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, void* stream);
+
 /* pvrl_cast_weight_bf16 for many weight matrices in one launch (the bf16 operand copies of every nn.Linear of the
  * encoder after an optimiser step): out [R][C] and, when out_t is not null, out_t [C][R], both dense. */
 typedef struct pvrl_cast_problem {

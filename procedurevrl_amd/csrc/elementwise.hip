@@ -469,4 +469,28 @@ extern "C" int pvrl_group_bcast_bf16(const float* in, int64_t ldi, int64_t group
   return PVRL_OK;
 }
 
+namespace {
+// out[r][c] += a[r] * b[c]   (torch.addr_ spends 54 us on this 768 x 768 update: a broadcast iterator, 4 bytes per thread)
+__global__ __launch_bounds__(256) void rank1_add_kernel(float* __restrict__ out, long ld, const float* __restrict__ a,
+                                                        const float* __restrict__ b, int R, int C4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)R * C4) return;
+  const int r = (int)(idx / C4), c = (int)(idx - (long)r * C4) * 4;
+  const float av = a[r];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
+  f32x4* o = reinterpret_cast<f32x4*>(out + (long)r * ld + c);
+  *o = *o + av * bv;
+}
+}  // namespace
+
+extern "C" int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, void* stream) {
+  if (R <= 0 || C <= 0) return PVRL_OK;
+  if (!out || !a || !b || (C % 4) || (ld % 4)) return PVRL_EINVAL;
+  const long n = (long)R * (C / 4);
+  hipLaunchKernelGGL(rank1_add_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)ld, a, b, (int)R,
+                     (int)(C / 4));
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
 extern "C" int pvrl_operand_dtype(void) { return PVRL_OPERAND_CODE; }

@@ -1,5 +1,6 @@
 // bf16 MFMA GEMM, "NT" form: the C-ABI entry points.  The kernel, its epilogues and the tile launcher live in
 // gemm_nt_core.h (shared with the measured-and-rejected variants kept under tools/probe/, which are NOT part of this library).
+#include <cstdlib>
 #include "gemm_nt_core.h"
 
 namespace {
@@ -102,6 +103,30 @@ static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
 // epilogue is the exception).
 // (Cutting the ragged last wave of 256x256 tiles off into a 128x128-tile launch was measured 12 % SLOWER: the second
 //  launch serialises behind the first; one launch with a partly idle last wave wins.)
+// CUs per XCD of the current device (MI355X: 256 / 8 = 32) -- sizes the last-round split (gemm_nt_core.h nt_tail_plan)
+int nt_cus_per_xcd() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    cus = n / 8;
+  }
+  return cus;
+}
+#ifndef PVRL_NT_TAILS_DEFAULT
+#define PVRL_NT_TAILS_DEFAULT 1
+#endif
+// PVRL_NT_TAILS=0 switches the sub-tiling of the ragged last round off (A/B runs; read once)
+int nt_tails_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_NT_TAILS");
+    on = e ? (e[0] == '0' ? 0 : 1) : PVRL_NT_TAILS_DEFAULT;
+  }
+  return on;
+}
+
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   constexpr bool two_out = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
@@ -129,6 +154,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
   p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = 0;      // 0: launch_tile picks the rasterisation group height for the shape
+  p.cus = nt_cus_per_xcd(); p.tails = nt_tails_enabled();
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s);

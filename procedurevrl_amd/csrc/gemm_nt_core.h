@@ -18,6 +18,7 @@
 // lane ends up owning 16 consecutive output columns of one output row: the
 // epilogue streams 16-/32-/64-byte contiguous pieces per lane.
 #pragma once
+#include <algorithm>
 #include "common.h"
 #include "../../include/pvrl.h"
 
@@ -35,6 +36,7 @@ struct GemmNT {
   void* out0; long ld0;
   void* out1; long ld1;
   int tiles_m, tiles_n, nwg;
+  int cus, tails;   // CUs per XCD; 1 = cut the tiles of the ragged last round into sub-tiles (256x256 kernel, nt_tail_plan)
   int m_off;   // global row of local row 0 (a launch may cover a row range of the logical GEMM)
   int gm;      // rasterisation group height in tiles
 };
@@ -101,7 +103,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
   // ---- epilogue ----
   const int q = lane >> 4, i = lane & 15;
   const int nw0 = n0 + wn * 64;
-  const int rows = min(1024, p.M - m0);    // rows of the matrices from the tile's first row on (any bound >= the tile height that keeps the byte count in 31 bits)
+  const int rows = max(0, min(1024, p.M - m0));    // rows of the matrices from the tile's first row on (any bound >= the tile height that keeps the byte count in 31 bits)
   if constexpr (F32OUT) {
     // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
     f32x4 bv[4];
@@ -249,6 +251,29 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
   }
 }
 
+// ---- the ragged last round (256x256 tiles only) --------------------------------------------------------------------
+// An XCD owns T = panels x tiles_n tiles and has C CUs (one 16-wave workgroup each): after floor(T / C) full rounds, L = T mod C
+// tiles are left for a last round that keeps L of C CUs busy for a whole tile time -- at M = 50,208: N = 768 -> 2 rounds + 11
+// tiles, N = 2304 -> 7 rounds + ONE tile, N = 3072 -> 9 rounds + 12.  Those L tiles are cut along M into f = 4 (if 4 L <= C) or 2
+// (if 2 L <= C) sub-tiles of 64 / 128 rows x 256 columns, one workgroup each, in the SAME launch (a separate launch for the tail
+// serialises behind the first: round 1, -12 %).  A sub-tile is computed by the first 4 / 8 waves of its workgroup with the
+// unchanged 64x64 wave block (same fragments, MFMA loop and epilogue); all 16 waves keep staging.  No partial sums, no fix-up.
+struct NtTail { int full, L, f, nblk; };
+__host__ __device__ inline NtTail nt_tail_plan(int cm, int tiles_n, int cus, int enable) {
+  NtTail t;
+  const int T = cm * tiles_n;
+  t.full = enable ? (T / cus) * cus : T;
+  t.L = T - t.full;
+  t.f = 1;
+  if (t.L > 0) {
+    if (4 * t.L <= cus) t.f = 4;
+    else if (2 * t.L <= cus) t.f = 2;
+  }
+  if (t.f == 1) { t.full = T; t.L = 0; }
+  t.nblk = t.full + t.f * t.L;
+  return t;
+}
+
 // WM x WN waves per workgroup, each owning a 64x64 output block: tile = (64*WM) x (64*WN).
 //   <2,2>: 128x128, 4 waves, 64 KiB LDS, 2 workgroups / CU   (small M: order transformer, CLIP text)
 //   <4,4>: 256x256, 16 waves, 128 KiB LDS, 1 workgroup / CU  (the encoder's 50k-row GEMMs: half the L2->LDS
@@ -257,6 +282,7 @@ template <int EPI, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
   constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
+  constexpr bool TAILS = WM == 4 && WN == 4;      // sub-tiles of the last round: 256x256 tiles only
   constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
   constexpr int NINST = (BM + BN) / 8;          // 1 KiB LDS-DMA instructions per stage
   constexpr int PER = NINST / NW;               // per wave
@@ -269,41 +295,64 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   // contiguous range of M-panels and walks it in groups of GM panels x all N-tiles, panel index fastest, so the
   // ~64 tiles resident on an XCD share GM activation panels and a few weight tiles instead of sweeping the whole
   // weight matrix per panel.
-  const int GM = p.gm;   // tile rows per rasterisation group (benchmark knob, default 8)
+  const int GM = p.gm;   // tile rows per rasterisation group
   int tm, tn;
+  int f = 1, sub = 0;    // this workgroup computes rows [sub * BM / f, (sub + 1) * BM / f) of its tile
   {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
     const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
     const int cm = qm + (xcd < rm ? 1 : 0);                 // panels owned by this XCD
     const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
-    if (j >= cm * p.tiles_n) return;
+    if constexpr (TAILS) {
+      const NtTail t = nt_tail_plan(cm, p.tiles_n, p.cus, p.tails);
+      if (j >= t.nblk) return;
+      if (j >= t.full) {
+        const int s = j - t.full;
+        f = t.f;
+        j = t.full + s / f;
+        sub = s - (s / f) * f;
+      }
+    } else {
+      if (j >= cm * p.tiles_n) return;
+    }
     const int gsz = GM * p.tiles_n;
     const int g = j / gsz, r = j - g * gsz;
     const int gm = min(GM, cm - g * GM);
     tn = r / gm;
     tm = mbase + g * GM + (r - tn * gm);
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int bm = BM / f;                                    // rows of this workgroup's (sub-)tile
+  const int m0 = tm * BM + sub * bm, n0 = tn * BN;
+  if (m0 >= p.M) return;                                    // a sub-tile past the ragged end of the last panel (block-uniform)
+  const bool active = wm < WM / f;                          // waves that own a 64x64 block of the (sub-)tile
+  const int xbytes = bm * BK * 2;                           // the W tile follows the X rows in each stage
   // ---- staging: instruction `it` of a stage copies 8 tile rows (X rows first, then W rows) ----
+  // full tile: wave w issues instructions 4 w .. 4 w + 3; sub-tile ((bm + 256) / 8 = 48 / 40 instructions): it = 16 j + w
   const op_t* gsrc[PER];
+  bool gval[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int it = wave * PER + j;
+    const int it = f == 1 ? wave * PER + j : j * NW + wave;
+    gval[j] = it < (bm + BN) / 8;
     const int pc = lane & 7;
-    if (it < BM / 8) {
+    if (it < bm / 8) {
       const int row = it * 8 + (lane >> 3);
       int grow = m0 + row;
       grow = grow < p.M ? grow : p.M - 1;
       gsrc[j] = p.A + (long)grow * p.lda + ((pc ^ swz_x(row)) << 3);
     } else {
-      const int row = (it - BM / 8) * 8 + (lane >> 3);
+      const int row = ((gval[j] ? it : bm / 8) - bm / 8) * 8 + (lane >> 3);
       gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
     }
   }
   auto stage = [&](int buf, int k0) {
     char* b = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);   // W tile follows the X tile
+    for (int j = 0; j < PER; ++j) {
+      const int it = f == 1 ? wave * PER + j : j * NW + wave;
+      if (!TAILS || gval[j]) glds16(gsrc[j] + k0, b + it * 1024);
+    }
   };
 
   // ---- fragment read offsets (bytes inside an operand tile), ks = 0; ks = 1 is ^64 ----
@@ -330,8 +379,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
     if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    if (TAILS && !active) continue;                          // (sub-tiles: the upper waves only stage)
     const char* bx = smem + (kt & 1) * STAGE;
-    const char* bw = bx + XBYTES;
+    const char* bw = bx + xbytes;
     // all 16 fragment reads of the K-step are issued up front; the MFMAs of the first half overlap the
     // LDS latency of the second half (the compiler otherwise serialises read -> wait(0) -> 8 MFMAs)
     opx8 xf0[4], wf0[4], xf1[4], wf1[4];
@@ -365,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   }
 
-  nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  if (!TAILS || active) nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int EPI, int WM, int WN>
@@ -374,6 +424,12 @@ int launch_tile(GemmNT p, hipStream_t s) {
   p.tiles_m = cdiv(p.M, 64 * WM);
   if (p.gm <= 0) p.gm = nt_gm_for(p.tiles_n);
   p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;   // per-XCD tile lists padded to equal length (surplus blocks exit)
+  if (WM == 4 && WN == 4) {                     // XCDs own ceil or floor(tiles_m / 8) panels: the longer block list sizes the grid
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    int nb = nt_tail_plan(qm + (rm ? 1 : 0), p.tiles_n, p.cus, p.tails).nblk;
+    if (qm > 0) nb = std::max(nb, nt_tail_plan(qm, p.tiles_n, p.cus, p.tails).nblk);
+    p.nwg = 8 * nb;
+  }
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN>), dim3(p.nwg), dim3(64 * WM * WN), 0, s, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;

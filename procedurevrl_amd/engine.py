@@ -470,7 +470,7 @@ class EncoderEngine(GraphReplay):
             else:
                 ops.gemm_nt(A, W, L.PVRL_EPI_RESID_F32, aux=g, out0=g)
         # proj's bias rides through temporal_fc too (b_e = W_fc b_proj): its share of dW_fc is the outer product db_e x b_proj
-        gs.target(wf)[0].addr_(dbe, blk.temporal_attn.proj.bias.detach())
+        ops.rank1_add(gs.target(wf)[0], dbe, blk.temporal_attn.proj.bias.detach())
         gb, beta = gs.target(blk.temporal_attn.proj.bias)
         ops.gemv_rows(ef.t, dbe, out=gb, beta=beta)                           # [mid] = W_fc^T db_e (bf16 operand copy)
 

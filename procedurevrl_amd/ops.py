@@ -527,6 +527,15 @@ def milnce(x, n, C, grad_scale=None):
     return nom, den, dx
 
 
+def rank1_add(out, a, b):
+    """out[r][c] += a[r] * b[c]  (fp32 [R, C] row-major, in place)"""
+    L = lib()
+    _chk2d(out, F32)
+    assert a.dtype == F32 and b.dtype == F32 and a.numel() == out.shape[0] and b.numel() == out.shape[1]
+    L.call("pvrl_rank1_add_f32", _ptr(out), _ld(out), _ptr(a.contiguous()), _ptr(b.contiguous()), out.shape[0], out.shape[1], _stream())
+    return out
+
+
 def softmax_rows(x):
     """fp32 [M, N] -> row softmax (eval-mode probabilities)"""
     L = lib()

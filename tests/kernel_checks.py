@@ -443,6 +443,11 @@ def check_elementwise():
     wb, wtt = ops.cast_weight(w.to(dev()))
     out.append(("cast_weight bf16", rel(wb, w), 5e-3))
     out.append(("cast_weight transposed", rel(wtt, w.t()), 5e-3))
+    o1 = torch.randn(768, 772, generator=g); av = torch.randn(768, generator=g); bv = torch.randn(768, generator=g)
+    o1d = o1.to(dev())
+    ops.rank1_add(o1d[:, :768], av.to(dev()), bv.to(dev()))            # a strided view: ld 772
+    ref1 = o1.clone(); ref1[:, :768] += av[:, None] * bv[None, :]
+    out.append(("rank1_add (addr_)", rel(o1d, ref1), TOL_F32))
     groups, Gs = 5, 8
     xin = torch.randn(groups * Gs, C, generator=g)
     sc = torch.rand(groups * Gs, generator=g)

@@ -1323,7 +1323,7 @@ extern "C" int pvrl_probe_gemm_nt_bf16(int tile, int gm, const void* A, int64_t 
   p.A = (const op_t*)A; p.lda = lda; p.W = (const op_t*)W; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.bias2 = bias2; p.rowscale = rowscale; p.aux = aux; p.aux_ld = aux_ld; p.aux_rowmod = (int)aux_rowmod;
-  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = gm < 1 ? 2 : gm;
+  p.out0 = out0; p.ld0 = ld0; p.out1 = out1; p.ld1 = ld1; p.m_off = 0; p.gm = gm < 1 ? 2 : gm; p.cus = 32; p.tails = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case PVRL_EPI_BF16: return launch_nt<PVRL_EPI_BF16>(p, s, tile);

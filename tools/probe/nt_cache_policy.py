@@ -18,19 +18,18 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(HERE, "cpol")
 #            tag            ST  LD  GM
-VARIANTS = [("st0_ld0_gm2", 0, 0, 2), ("st0_ld0_gm3", 0, 0, 3), ("st0_ld0_gm4", 0, 0, 4), ("st0_ld0_gm6", 0, 0, 6), ("st0_ld0_gm8", 0, 0, 8),
-            ("st0_nt_gm2", 0, 2, 2), ("st0_nt_gm4", 0, 2, 4), ("nt_nt_gm2", 2, 2, 2), ("sc1_nt_gm2", 16, 2, 2), ("sc1_ld0_gm2", 16, 0, 2),
-            ("sc1_nt_gm4", 16, 2, 4), ("sc1nt_nt_gm2", 18, 2, 2)]
+VARIANTS = [("tails0", 0, 0, 0, 0), ("tails1", 0, 0, 0, 1)]      # round-3 sweep list: see profiles/r3_nt_cache_policy.txt
+#  (tag, store aux, load aux, GM (0 = by shape), last-round sub-tiles)
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "procedurevrl_amd", "csrc", "gemm_nt.hip")
     procs = []
-    for tag, st, ld, gm in VARIANTS:
+    for tag, st, ld, gm, tails in VARIANTS:
         so = os.path.join(OUT, f"libnt_{tag}.so")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-result",
-               f"-DPVRL_NT_ST_AUX={st}", f"-DPVRL_NT_LD_AUX={ld}", f"-DPVRL_NT_GM={gm}", src, "-o", so]
+               f"-DPVRL_NT_ST_AUX={st}", f"-DPVRL_NT_LD_AUX={ld}", f"-DPVRL_NT_GM={gm}", f"-DPVRL_NT_TAILS_DEFAULT={tails}", src, "-o", so]
         procs.append((tag, subprocess.Popen(cmd)))
         if len(procs) % 4 == 0:
             for t, p in procs[-4:]:
@@ -72,7 +71,7 @@ def run(tags):
     import random
     want = [v for v in VARIANTS if not tags or v[0] in tags]
     fns = {}
-    for tag, st, ld, gm in want:
+    for tag, *_ in want:
         so = ctypes.CDLL(os.path.join(OUT, f"libnt_{tag}.so"))
         fn = so.pvrl_gemm_nt_bf16
         fn.restype = _RET[proto[0]]
@@ -114,7 +113,7 @@ def run(tags):
     results = {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
     names = [s[0] for s in shapes]
     print(f"{'variant':16s} " + " ".join(f"{n.split()[0] + ' ' + n.split()[1]:>12s}" for n in names) + "      sum")
-    for tag, st, ld, gm in want:
+    for tag, *_ in want:
         row = [results[(tag, n)] for n in names]
         print(f"{tag:16s} " + " ".join(f"{u:12.1f}" for u in row) + f" {sum(row):8.1f}")
 
