@@ -109,7 +109,7 @@ __device__ __forceinline__ void tile_commit(const TileRegs<NT>& t, char* bl, int
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int NKT, bool GEN, int NW>
+template <int NKT, bool GEN, int NW, int SC = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
   const int xj = blockIdx.x >> 3;
   const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
   if (seq >= p.nseq) return;
-  const int S = p.mp.S;
+  const int S = SC ? SC : p.mp.S;     // SC: the sequence length as a compile-time constant (0 = run time)
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
   constexpr int MAXT = (NKT + NW - 1) / NW;   // query tiles per wave
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
 // ------------------------------------------------------------------------------------------
 // backward, pass 1: dQ (and D = rowsum(dO * O)); waves own query tiles exactly as in the forward.
 // ------------------------------------------------------------------------------------------
-template <int NKT, bool GEN, int NW>
+template <int NKT, bool GEN, int NW, int SC = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
   const int xj = blockIdx.x >> 3;
   const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
   if (seq >= p.nseq) return;
-  const int S = p.mp.S;
+  const int S = SC ? SC : p.mp.S;     // SC: the sequence length as a compile-time constant (0 = run time)
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
   constexpr int MAXT = (NKT + NW - 1) / NW;   // query tiles per wave
@@ -337,8 +337,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * q4 + r;
           float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2_t));
-          if (GEN || kt * 16 + 15 >= S || qt * 16 + 15 >= S) {
-            bool msk = key >= S || query >= S;
+          // (a padded query, query >= S, needs no mask: its lane's dS only feeds that lane's own dq, which is never stored)
+          if (GEN || kt * 16 + 15 >= S) {
+            bool msk = key >= S || (GEN && query >= S);
             if constexpr (GEN) msk = msk || ((pbits >> (kt * 4 + r)) & 1ull) || (p.causal && key > query);
             if (msk) pr = 0.f;
           }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
 // backward, pass 2: dK and dV.  Waves own KEY tiles; the query dimension is the MFMA reduction.
 // Needs lse and dvec from the forward / pass 1.
 // ------------------------------------------------------------------------------------------
-template <int NKT, bool GEN, int NW>
+template <int NKT, bool GEN, int NW, int SC = 0>
 __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int ROWS = NKS2 * 32;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
   const int xj = blockIdx.x >> 3;
   const int seq = (xj / p.H) * 8 + (blockIdx.x & 7), h = xj % p.H;
   if (seq >= p.nseq) return;
-  const int S = p.mp.S;
+  const int S = SC ? SC : p.mp.S;     // SC: the sequence length as a compile-time constant (0 = run time)
   const int HD = p.H * 64;
   const SeqRows sr = seq_rows(p.mp, seq);
   constexpr int MAXT = (NKT + NW - 1) / NW;   // key tiles per wave
@@ -493,10 +494,19 @@ int check_common(const AttnArgs& p) {
   return PVRL_OK;
 }
 
+// The two sequence lengths of the TimeSformer path at its benchmark geometry -- 197 (196 patches + cls, spatial) and 32 (temporal,
+// long clips) -- are instantiated with S as a compile-time constant: `key >= S` is then false for every key tile but the last
+// (none at S = 32), so 12 of 13 tiles lose their per-score compare + select, and the 52 64-bit lane masks that spilled the
+// kernels' scalar registers into v_writelane / v_readlane pairs (SGPR spills 66 / 58 -> 0) disappear with them.
+#ifndef PVRL_ATTN_SFIX
+#define PVRL_ATTN_SFIX 1      // 0: A/B builds without the compile-time sequence lengths (tools/build_variant.py)
+#endif
 template <int NKT, int NW>
 int launch_fwd(const AttnArgs& p, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((p.nseq + 7) / 8) * p.H)), blk(64 * NW);
+  constexpr int SFIX = PVRL_ATTN_SFIX ? (NKT == 13 ? 197 : NKT == 2 ? 32 : 0) : 0;
   if (p.causal || p.kpm) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true, NW>), grid, blk, 0, s, p);
+  else if (SFIX && p.mp.S == SFIX) hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, NW, SFIX>), grid, blk, 0, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, NW>), grid, blk, 0, s, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -505,10 +515,15 @@ int launch_fwd(const AttnArgs& p, hipStream_t s) {
 template <int NKT, int NW>
 int launch_bwd(const AttnArgs& p, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((p.nseq + 7) / 8) * p.H)), blk(64 * NW);
+  constexpr int SFIX = PVRL_ATTN_SFIX ? (NKT == 13 ? 197 : NKT == 2 ? 32 : 0) : 0;
   if (p.causal || p.kpm) {
     hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, true, NW>), grid, blk, 0, s, p);
     PVRL_LAUNCH_CHECK();
     hipLaunchKernelGGL((attn_bwd_kv_kernel<NKT, true, NW>), grid, blk, 0, s, p);
+  } else if (SFIX && p.mp.S == SFIX) {
+    hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, false, NW, SFIX>), grid, blk, 0, s, p);
+    PVRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<NKT, false, NW, SFIX>), grid, blk, 0, s, p);
   } else {
     hipLaunchKernelGGL((attn_bwd_q_kernel<NKT, false, NW>), grid, blk, 0, s, p);
     PVRL_LAUNCH_CHECK();

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   constexpr int NINST = (BM + BN) / 8;          // 1 KiB LDS-DMA instructions per stage
   constexpr int PER = NINST / NW;               // per wave
   static_assert(NINST % NW == 0, "stage instructions must divide evenly over the waves");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int SUB_STAGE = 48 * 1024;          // sub-tiles of the last round: (128 + 256) x 128 B per stage, THREE slots
+  __shared__ __attribute__((aligned(16))) char smem[TAILS ? 3 * SUB_STAGE : 2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -346,13 +347,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
       gsrc[j] = p.W + (long)(n0 + row) * p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3);
     }
   }
-  auto stage = [&](int buf, int k0) {
+  auto stage = [&](int buf, int k0) {            // full tiles: two slots, the compiler orders the LDS-DMA (vmcnt(0) at the barrier)
     char* b = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int it = f == 1 ? wave * PER + j : j * NW + wave;
-      if (!TAILS || gval[j]) glds16(gsrc[j] + k0, b + it * 1024);
-    }
+    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);
   };
 
   // ---- fragment read offsets (bytes inside an operand tile), ks = 0; ks = 1 is ^64 ----
@@ -375,13 +373,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    if (TAILS && !active) continue;                          // (sub-tiles: the upper waves only stage)
-    const char* bx = smem + (kt & 1) * STAGE;
-    const char* bw = bx + xbytes;
+  // one K = 64 step of this wave's 64x64 block from the stage at bx (X rows) / bw (W rows)
+  auto kstep = [&](const char* bx, const char* bw) {
     // all 16 fragment reads of the K-step are issued up front; the MFMAs of the first half overlap the
     // LDS latency of the second half (the compiler otherwise serialises read -> wait(0) -> 8 MFMAs)
     opx8 xf0[4], wf0[4], xf1[4], wf1[4];
@@ -413,6 +406,49 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+  };
+
+  if (!TAILS || f == 1) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute
+      if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+      const char* bx = smem + (kt & 1) * STAGE;
+      kstep(bx, bx + XBYTES);
+    }
+  } else {
+    // Sub-tile: 4 or 8 computing waves = 1 or 2 per SIMD, 512 / 1,024 MFMA cycles per K-step -- less than the latency of the next
+    // stage's LDS-DMA, which a two-slot ring exposes every step (measured: a 64-row sub-tile cost ~0.7 of a full tile).  Three
+    // slots, stages issued TWO steps ahead as raw LDS-DMA with counted waits: stage kt + 1 stays in flight across the barrier.
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    int nv = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) nv += gval[j] ? 1 : 0;
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    auto stage3 = [&](int kt) {
+      const unsigned b = sbase + (kt % 3) * SUB_STAGE;
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if (gval[j]) glds16_raw_v(gsrc[j] + kt * BK, b + (j * NW + wave) * 1024);
+    };
+    stage3(0);
+    if (nk > 1) stage3(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {              // this wave's nv instructions of stage kt + 1 may stay in flight
+        if (nv >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nv == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // stage kt has landed for every wave; slot (kt + 2) % 3 = (kt - 1) % 3 is no longer read
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) stage3(kt + 2);
+      if (active) {
+        const char* bx = smem + (kt % 3) * SUB_STAGE;
+        kstep(bx, bx + xbytes);      // (its fragment reads are consumed by its MFMAs: done before the wave reaches the next barrier)
+      }
+    }
   }
 
   if (!TAILS || active) nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
