@@ -69,7 +69,9 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16_raw(const void* uniform_base, unsigned lane_off, unsigned lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+  // (s_nop 4: the base may have been produced by v_readfirstlane right in front of the statement -- a VALU-written SGPR needs five
+  //  wait states before a vector-memory instruction reads it as an address; hipcc pads nothing inside an asm string)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
                :: "v"(lane_off), "s"(uniform_base), "s"(lds_wave_base) : "memory", "m0");
 }
 // per-lane 64-bit source address form of the same raw LDS-DMA copy

@@ -127,10 +127,31 @@ int nt_tails_enabled() {
   return on;
 }
 
+#if PVRL_NT_PERSIST_BUILD
+// probe builds only (gemm_nt_core.h, "MEASURED AND NOT SHIPPED"): PVRL_NT_PERSIST = bit mask over the epilogue codes whose 256x256
+// shapes take the persistent kernel; read once
+#ifndef PVRL_NT_PERSIST_DEFAULT
+#define PVRL_NT_PERSIST_DEFAULT 0
+#endif
+int nt_persist_mask() {
+  static int mask = -1;
+  if (mask < 0) {
+    const char* e = getenv("PVRL_NT_PERSIST");
+    mask = e ? (int)strtol(e, nullptr, 0) : PVRL_NT_PERSIST_DEFAULT;
+  }
+  return mask;
+}
+#endif
+
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   constexpr bool two_out = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
-  if (p.M >= 4096 && p.N % 256 == 0) return launch_tile<EPI, 4, 4>(p, s);
+  if (p.M >= 4096 && p.N % 256 == 0) {
+#if PVRL_NT_PERSIST_BUILD
+    if ((nt_persist_mask() >> EPI) & 1) return launch_pers<EPI>(p, s);
+#endif
+    return launch_tile<EPI, 4, 4>(p, s);
+  }
   if (p.M >= 2048 && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);
 }

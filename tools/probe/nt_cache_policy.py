@@ -18,18 +18,18 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(HERE, "cpol")
 #            tag            ST  LD  GM
-VARIANTS = [("tails0", 0, 0, 0, 0), ("tails1", 0, 0, 0, 1)]      # round-3 sweep list: see profiles/r3_nt_cache_policy.txt
-#  (tag, store aux, load aux, GM (0 = by shape), last-round sub-tiles)
+VARIANTS = [("pers0", ["-DPVRL_NT_PERSIST_BUILD=1", "-DPVRL_NT_PERSIST_DEFAULT=0"]),
+            ("pers_all", ["-DPVRL_NT_PERSIST_BUILD=1", "-DPVRL_NT_PERSIST_DEFAULT=0x7f"])]
+#  (tag, extra compiler switches); the round-3 policy / rasterisation / tails lists: profiles/r3_nt_cache_policy.txt, r3_nt_tail_subtiles.txt
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "procedurevrl_amd", "csrc", "gemm_nt.hip")
     procs = []
-    for tag, st, ld, gm, tails in VARIANTS:
+    for tag, flags in VARIANTS:
         so = os.path.join(OUT, f"libnt_{tag}.so")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-result",
-               f"-DPVRL_NT_ST_AUX={st}", f"-DPVRL_NT_LD_AUX={ld}", f"-DPVRL_NT_GM={gm}", f"-DPVRL_NT_TAILS_DEFAULT={tails}", src, "-o", so]
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-result"] + flags + [src, "-o", so]
         procs.append((tag, subprocess.Popen(cmd)))
         if len(procs) % 4 == 0:
             for t, p in procs[-4:]:
@@ -96,6 +96,17 @@ def run(tags):
                 ref = cur
             else:
                 assert torch.equal(ref[0], cur[0]) and (ref[1] is None or torch.equal(ref[1], cur[1])), (tag, name)
+        if os.environ.get("NT_STRESS"):           # races show as run-to-run differences: 12 more launches per variant, every bit compared
+            for tag, *_ in want:
+                for r in range(12):
+                    d = ss[r % NSET]
+                    d["out0"].fill_(0)
+                    call(fns[tag], d)
+                    call(fns[want[0][0]], dict(d, out0=d.setdefault("chk0", torch.empty_like(d["out0"])),
+                                               out1=(d.setdefault("chk1", torch.empty_like(d["out1"])) if d["out1"] is not None else None)))
+                    torch.cuda.synchronize()
+                    assert torch.equal(d["out0"], d["chk0"]), (tag, name, r)
+                    assert d["out1"] is None or torch.equal(d["out1"], d["chk1"]), (tag, name, r)
         for rnd_i in range(ROUNDS):               # variants interleaved in a fresh random order every round: no first-runner bias
             order = [t for t, *_ in want]
             rng.shuffle(order)
