@@ -99,7 +99,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // and five FMAs instead of the ~40-instruction ocml erff; `e` returns exp(-x^2) for reuse by the derivative.
 __device__ __forceinline__ float erf_as(float x, float& e) {
   const float ax = fabsf(x);
+  // v_rcp_f32 (1 ulp), NOT __frcp_rn / a division: those expand to the IEEE sequence (2 v_div_scale, v_rcp, 4 FMA, v_div_fmas,
+  // v_div_fixup = 10 of the GELU epilogue's 21 VALU instructions per element -- round 3: the two-output GELU and the dGELU GEMMs spent
+  // ~10 us of VALU time per 256x256 tile there, what had been booked as store time)
+#if defined(PVRL_GELU_IEEE_DIV)      // A/B builds only (tools/build_variant.py)
   const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+#else
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+#endif
   e = __expf(-ax * ax);
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
@@ -118,10 +125,10 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
   return fmaf(u * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float quick_gelu(float u) {
-  return u / (1.0f + __expf(-1.702f * u));
+  return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
 }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
-  const float s = 1.0f / (1.0f + __expf(-1.702f * u));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
   return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
