@@ -16,10 +16,17 @@ namespace {
 constexpr int PITCH = 144;  // 128 B row + 16 B pad: conflict-free ds_read_b128 across rows
 constexpr int TILE = 8 * PITCH;
 
-__device__ __forceinline__ float dot8(const opx8 a, const opx8 b) {
-  float s = 0.f;
+// 8-element dot product of 16-bit operands as four v_dot2 (two exact products + the fp32 accumulator per instruction) instead of
+// eight conversions pairs + eight FMAs: round 3 found both kernels VALU-bound, not HBM-bound (backward: 821 VALU instructions per
+// 7 KB item = 8.5 B/clk/CU = the 4.6 TB/s it ran at)
+__device__ __forceinline__ float dot8(const opx8 a, const opx8 b, float s = 0.f) {
+#if defined(PVRL_T8_NO_DOT2)        // A/B builds only (tools/build_variant.py)
 #pragma unroll
   for (int e = 0; e < 8; ++e) s = fmaf((float)a[e], (float)b[e], s);
+#else
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = FDOT2_F32((opx2){a[2 * e], a[2 * e + 1]}, (opx2){b[2 * e], b[2 * e + 1]}, s, false);
+#endif
   return s;
 }
 __device__ __forceinline__ opx8 lds8(const char* p) { return *reinterpret_cast<const opx8*>(p); }
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const op_t* __restrict__ q
   // scores: lane (i = r8, j = c8)
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) s += dot8(lds8(sq + r8 * PITCH + c * 16), lds8(sk + c8 * PITCH + c * 16));
+  for (int c = 0; c < 8; ++c) s = dot8(lds8(sq + r8 * PITCH + c * 16), lds8(sk + c8 * PITCH + c * 16), s);
   s *= scale;
   float mx = s;
   mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_t8_kernel(const op_t* __restrict__ q
   } else {
     float dp = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dp += dot8(lds8(sd + r8 * PITCH + c * 16), lds8(sv + c8 * PITCH + c * 16));
+    for (int c = 0; c < 8; ++c) dp = dot8(lds8(sd + r8 * PITCH + c * 16), lds8(sv + c8 * PITCH + c * 16), dp);
     float dd = pr * dp;
     dd += __shfl_xor(dd, 1, 64);
     dd += __shfl_xor(dd, 2, 64);

@@ -8,6 +8,7 @@ one fused kernel per contiguous parameter range of the model's flat buffers (csr
 instead of torch.optim's per-tensor foreach loops; numerics follow torch.optim.{SGD, Adam, AdamW}.
 """
 import ctypes
+import os
 
 import torch
 
@@ -79,7 +80,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         L = lib()
         gs0 = self.vt.grad_store()
         had_grad = [p.grad is not None for p in gs0.params]
-        self.vt.adopt_grads()
+        self.vt.adopt_grads(keep_none=True, zero_unused=bool(os.environ.get("PVRL_ZERO_UNUSED")))   # parameters without a gradient are skipped below, as torch.optim does (PVRL_ZERO_UNUSED=1: A/B switch, zero their slots anyway)
         gs = self._ensure_flat()
         self.steps += 1
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
