@@ -88,11 +88,23 @@ __device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const op_t* base, lo
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + NT * it;
     const int row = idx >> 3, c = idx & 7;
+    // BRANCH-FREE: every lane loads (rows past the sequence re-read its last row) and the padding is zeroed by a select.  A load
+    // inside `if (row < S)` is followed by s_waitcnt vmcnt(0) at the join: the two guarded iterations of
+    // this loop cost the workgroup two extra serial memory round trips in front of its first barrier.
+#if defined(PVRL_ATTN_GUARDED_LOADS)      // A/B builds only: the round-1 form
     t.v[it] = (u32x4){0u, 0u, 0u, 0u};
     if (row < S && row < rows) {
       const op_t* src = (row == 0 && src0) ? src0 : base + row_of(sr, row) * ld;
       t.v[it] = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
     }
+#else
+    const int rc = min(row, S - 1);
+    const op_t* src = (rc == 0 && src0) ? src0 : base + row_of(sr, rc) * ld;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + col0 + c * 8);
+    const unsigned keep = row < S ? 0xffffffffu : 0u;
+    t.v[it] = v & (u32x4){keep, keep, keep, keep};
+    (void)rows;
+#endif
   }
 }
 template <int NT>
