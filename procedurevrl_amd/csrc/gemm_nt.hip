@@ -34,12 +34,22 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += SG_K) {
+    // sixteen loads per thread, UNCONDITIONAL from clamped indices and masked by selects: inside `cond ? load : 0` each one is
+    // followed by s_waitcnt vmcnt(0) (16 serial round trips per 32-deep K chunk, round 3 audit)
     float va[8], vb[8];
+    const float* ar = A + (long)min(m0 + lrow, M - 1) * lda;
+    const float* br = B + (long)min(n0 + lrow, N - 1) * ldb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k = k0 + lk + e;
-      va[e] = (m0 + lrow < M && k < kend) ? A[(long)(m0 + lrow) * lda + k] : 0.f;
-      vb[e] = (n0 + lrow < N && k < kend) ? B[(long)(n0 + lrow) * ldb + k] : 0.f;
+      const int k = min(k0 + lk + e, K - 1);
+      va[e] = ar[k];
+      vb[e] = br[k];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool kin = k0 + lk + e < kend;
+      va[e] = (m0 + lrow < M && kin) ? va[e] : 0.f;
+      vb[e] = (n0 + lrow < N && kin) ? vb[e] : 0.f;
     }
     __syncthreads();
 #pragma unroll

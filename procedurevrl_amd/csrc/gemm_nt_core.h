@@ -414,6 +414,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   };
 
   if (!TAILS || f == 1) {
+    // (Round 3, measured and dropped: issuing stages 0 AND 1 together before the first barrier.  The barrier's vmcnt(0) then waits
+    //  for both, so no latency is hidden -- ViT-B step -2 %, MViT +0.4 % -- gpurun_out/r3_r_*.json.)
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and fences the previous compute

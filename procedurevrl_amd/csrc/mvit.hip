@@ -26,38 +26,128 @@ struct Conv3dGeom {
   int B, Cin, T, H, W, kt, kh, kw, st, sh, sw, pt, ph, pw, To, Ho, Wo, K;   // K = Cin*kt*kh*kw
 };
 
-// out bf16 [(b, to, ho, wo)][ldo]; column k = ((c*kt + a)*kh + y)*kw + x (the flatten order of Conv3d.weight), zero for k >= K
+// out bf16 [(b, to, ho, wo)][ldo]; column k = ((c*kt + a)*kh + y)*kw + x (the flatten order of Conv3d.weight), zero for k >= K.
+// Round 3.  The first form (1.0 ms for the stem of a 32-clip step) decomposed k with three run-time integer divisions per ELEMENT
+// and fetched each tap inside `if (inside)`: eight guarded loads per thread = eight serial memory round trips.
+// Generic kernel below: the (c, a, y, x) of every column come from an LDS table built once per workgroup, the eight taps of a
+// thread are loaded unconditionally from clamped coordinates and masked by selects, 32-bit index arithmetic: 713 us -- now bound
+// by its access pattern (every lane of a load touches a different input row: 64 cache lines per wave instruction).
+constexpr int IM2COL_MAXK = 1024;
 __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ frames, op_t* __restrict__ out,
                                                        Conv3dGeom g, long ldo) {
+  __shared__ unsigned lut[IM2COL_MAXK];          // column k -> c << 24 | a << 16 | y << 8 | x   (0xffffffff: k >= K)
   const int chunks = (int)(ldo >> 3);
   const long rows = (long)g.B * g.To * g.Ho * g.Wo;
   const long total = rows * chunks;
   const int khw = g.kh * g.kw, kvol = g.kt * khw;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int ch = (int)(idx % chunks);
-    long r = idx / chunks;
-    const int wo = (int)(r % g.Wo); r /= g.Wo;
-    const int ho = (int)(r % g.Ho); r /= g.Ho;
-    const int to = (int)(r % g.To);
-    const int b = (int)(r / g.To);
-    opx8 o;
+  for (int k = threadIdx.x; k < (int)ldo; k += 256) {
+    unsigned e = 0xffffffffu;
+    if (k < g.K) {
+      const int c = k / kvol;
+      int rem = k - c * kvol;
+      const int a = rem / khw;
+      rem -= a * khw;
+      const int y = rem / g.kw, x = rem - y * g.kw;
+      e = ((unsigned)c << 24) | ((unsigned)a << 16) | ((unsigned)y << 8) | (unsigned)x;
+    }
+    lut[k] = e;
+  }
+  __syncthreads();
+  const long plane = (long)g.H * g.W;
+  // (32-bit index arithmetic: the host checks rows * chunks < 2^31 -- 64-bit divisions cost ~100 VALU instructions each)
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / (unsigned)chunks;
+    const int ch = (int)(idx - row * (unsigned)chunks);
+    unsigned r = row;
+    const unsigned r1 = r / (unsigned)g.Wo; const int wo = (int)(r - r1 * (unsigned)g.Wo); r = r1;
+    const unsigned r2 = r / (unsigned)g.Ho; const int ho = (int)(r - r2 * (unsigned)g.Ho); r = r2;
+    const unsigned r3 = r / (unsigned)g.To; const int to = (int)(r - r3 * (unsigned)g.To);
+    const int b = (int)r3;
+    const int t0 = to * g.st - g.pt, y0 = ho * g.sh - g.ph, x0 = wo * g.sw - g.pw;
+    const float* fb = frames + (long)b * g.Cin * g.T * plane;
+    const u32x4 l0 = *reinterpret_cast<const u32x4*>(&lut[ch * 8]);
+    const u32x4 l1 = *reinterpret_cast<const u32x4*>(&lut[ch * 8 + 4]);
+    float v[8];
+    bool ok[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k = ch * 8 + e;
-      float v = 0.f;
-      if (k < g.K) {
-        const int c = k / kvol;
-        int rem = k - c * kvol;
-        const int a = rem / khw;
-        rem -= a * khw;
-        const int y = rem / g.kw, x = rem - y * g.kw;
-        const int ti = to * g.st - g.pt + a, yi = ho * g.sh - g.ph + y, xi = wo * g.sw - g.pw + x;
-        if (ti >= 0 && ti < g.T && yi >= 0 && yi < g.H && xi >= 0 && xi < g.W)
-          v = frames[((((long)b * g.Cin + c) * g.T + ti) * g.H + yi) * g.W + xi];
-      }
-      o[e] = (op_t)v;
+      const unsigned q = e < 4 ? l0[e] : l1[e - 4];
+      const int c = (int)(q >> 24) & 0x7f, ti = t0 + (int)((q >> 16) & 0xff), yi = y0 + (int)((q >> 8) & 0xff), xi = x0 + (int)(q & 0xff);
+      ok[e] = q != 0xffffffffu && ti >= 0 && ti < g.T && yi >= 0 && yi < g.H && xi >= 0 && xi < g.W;
+      const int tc = min(max(ti, 0), g.T - 1), yc = min(max(yi, 0), g.H - 1), xc = min(max(xi, 0), g.W - 1);
+      v[e] = fb[((long)min(c, g.Cin - 1) * g.T + tc) * plane + (long)yc * g.W + xc];       // unconditional: in flight together
     }
-    *reinterpret_cast<opx8*>(out + (idx / chunks) * ldo + ch * 8) = o;
+    opx8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (op_t)(ok[e] ? v[e] : 0.f);
+    *reinterpret_cast<opx8*>(out + (long)row * ldo + ch * 8) = o;
+  }
+}
+
+// The stem's geometry (W % 4 == 0, W <= 240, Cin*kt*kh <= 64 input lines per output row, pw <= 4, kw <= 8): one workgroup per
+// (b, to, ho) = one ROW of Wo output positions.  Phase 1 brings the Cin*kt*kh input rows that row of outputs touches into LDS as
+// 16-bit values -- whole rows, float4 loads, fully coalesced, zero rows / zero borders for the padding -- phase 2 assembles the Wo
+// output rows from LDS (a column's LDS offset from a table, no bounds checks left) and writes them as full 16-byte chunks.
+constexpr int IMR_LINES = 64, IMR_PITCH = 256, IMR_LPAD = 4;
+__global__ __launch_bounds__(256) void im2col3d_rows_kernel(const float* __restrict__ frames, op_t* __restrict__ out,
+                                                            Conv3dGeom g, long ldo) {
+  __shared__ __attribute__((aligned(16))) op_t lines[IMR_LINES][IMR_PITCH];
+  __shared__ unsigned koff[IM2COL_MAXK];          // column k -> byte offset of (line, x) inside `lines`; 0xffffffff: k >= K
+  __shared__ unsigned lca[IMR_LINES];             // line -> c << 16 | a << 8 | y
+  const int tid = threadIdx.x;
+  const int nline = g.Cin * g.kt * g.kh;
+  const int khw = g.kh * g.kw;
+  for (int k = tid; k < (int)ldo; k += 256) {
+    unsigned e = 0xffffffffu;
+    if (k < g.K) {
+      const int l = k / g.kw, x = k - l * g.kw;
+      e = (unsigned)(l * IMR_PITCH + x) * 2u;
+    }
+    koff[k] = e;
+  }
+  if (tid < nline) {
+    const int y = tid % g.kh, ca = tid / g.kh, a = ca % g.kt, c = ca / g.kt;
+    lca[tid] = ((unsigned)c << 16) | ((unsigned)a << 8) | (unsigned)y;
+  }
+  for (int i = tid; i < IMR_LINES * IMR_PITCH / 2; i += 256) reinterpret_cast<unsigned*>(&lines[0][0])[i] = 0u;   // borders stay zero
+  __syncthreads();
+  (void)khw;
+  const long plane = (long)g.H * g.W;
+  const int w4 = g.W >> 2, chunks = (int)(ldo >> 3);
+  const int lrow = tid >> 6, j = tid & 63;
+  const int groups = g.B * g.To * g.Ho;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ho = grp % g.Ho, bt = grp / g.Ho, to = bt % g.To, b = bt / g.To;
+    // ---- phase 1: input rows -> LDS (lane j = one float4 of a row, four rows per pass) ----
+    for (int l = lrow; l < nline; l += 4) {
+      const unsigned q = lca[l];
+      const int c = (int)(q >> 16), ti = to * g.st - g.pt + (int)((q >> 8) & 0xff), yi = ho * g.sh - g.ph + (int)(q & 0xff);
+      const bool ok = ti >= 0 && ti < g.T && yi >= 0 && yi < g.H && j < w4;
+      const float* src = frames + (((long)b * g.Cin + c) * g.T + min(max(ti, 0), g.T - 1)) * plane +
+                         (long)min(max(yi, 0), g.H - 1) * g.W + 4 * min(j, w4 - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);                     // unconditional
+      opx4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (op_t)(ok ? v[e] : 0.f);
+      if (j < w4) *reinterpret_cast<opx4*>(&lines[l][IMR_LPAD + 4 * j]) = o;
+    }
+    __syncthreads();
+    // ---- phase 2: Wo output rows x chunks of 8 columns ----
+    for (int task = tid; task < g.Wo * chunks; task += 256) {
+      const int wo = task / chunks, ch = task - wo * chunks;
+      const unsigned base = (unsigned)(wo * g.sw - g.pw + IMR_LPAD) * 2u;
+      const u32x4 k0 = *reinterpret_cast<const u32x4*>(&koff[ch * 8]);
+      const u32x4 k1 = *reinterpret_cast<const u32x4*>(&koff[ch * 8 + 4]);
+      opx8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned off = e < 4 ? k0[e] : k1[e - 4];
+        const op_t v = *reinterpret_cast<const op_t*>(reinterpret_cast<const char*>(&lines[0][0]) + (off == 0xffffffffu ? 0u : off + base));
+        o[e] = off == 0xffffffffu ? (op_t)0.f : v;
+      }
+      *reinterpret_cast<opx8*>(out + ((long)grp * g.Wo + wo) * ldo + ch * 8) = o;
+    }
+    __syncthreads();
   }
 }
 
@@ -968,10 +1058,20 @@ extern "C" int pvrl_im2col3d_bf16(const float* frames, int64_t B, int64_t Cin, i
   g.pt = (int)pt; g.ph = (int)ph; g.pw = (int)pw;
   g.To = (int)((T + 2 * pt - kt) / st + 1); g.Ho = (int)((H + 2 * ph - kh) / sh + 1); g.Wo = (int)((W + 2 * pw - kw) / sw + 1);
   g.K = (int)(Cin * kt * kh * kw);
-  if (ldo < g.K) return PVRL_EINVAL;
-  const long total = (long)B * g.To * g.Ho * g.Wo * (ldo >> 3);
-  hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (op_t*)out, g,
-                     (long)ldo);
+  const long nrows = (long)B * g.To * g.Ho * g.Wo;
+  const long total = nrows * (ldo >> 3);
+  if (ldo < g.K || ldo > IM2COL_MAXK || (ldo % 8) || g.kt > 255 || g.kh > 255 || g.kw > 255 || Cin > 127 || total >= (1L << 31))
+    return PVRL_EINVAL;
+  const int nline = (int)(Cin * g.kt * g.kh);
+  const bool rows_form = (W % 4 == 0) && W + IMR_LPAD + g.kw <= IMR_PITCH && nline <= IMR_LINES && g.pw <= IMR_LPAD && g.kw <= 8 &&
+                         (g.Wo - 1) * g.sw - g.pw + g.kw - 1 + IMR_LPAD < IMR_PITCH;
+  if (rows_form) {
+    long wgs = (long)B * g.To * g.Ho;
+    if (wgs > 8192) wgs = 8192;
+    hipLaunchKernelGGL(im2col3d_rows_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, frames, (op_t*)out, g, (long)ldo);
+  } else {
+    hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, (op_t*)out, g, (long)ldo);
+  }
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
