@@ -137,6 +137,15 @@ int nt_tails_enabled() {
   return on;
 }
 
+int nt_wide_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_NT_WIDE");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
+  }
+  return on;
+}
+
 #if PVRL_NT_PERSIST_BUILD
 // probe builds only (gemm_nt_core.h, "MEASURED AND NOT SHIPPED"): PVRL_NT_PERSIST = bit mask over the epilogue codes whose 256x256
 // shapes take the persistent kernel; read once
@@ -161,6 +170,12 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
     if ((nt_persist_mask() >> EPI) & 1) return launch_pers<EPI>(p, s);
 #endif
     return launch_tile<EPI, 4, 4>(p, s);
+  }
+  // N = 384 / 1152 and 640 (MViTv2-S stages 1-3): one 128 x 384 / 128 x 320 tile row instead of three / five 128 x 128 column tiles
+  // -- the A panel is fetched once and a workgroup's fixed costs cover 3x / 2.5x the output (PVRL_NT_WIDE=0: A/B runs)
+  if (nt_wide_enabled() && p.M >= 4096 && p.N % 256 != 0) {
+    if (p.N == 384 || (p.N % 384 == 0 && p.M >= 100000)) return launch_tile<EPI, 2, 6>(p, s);   // (N = 1152 at M = 50,208: 128 x 128 tiles are 7 % faster)
+    if (p.N % 320 == 0) return launch_tile<EPI, 2, 5>(p, s);
   }
   if (p.M >= 2048 && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);

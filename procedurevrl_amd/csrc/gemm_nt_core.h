@@ -290,8 +290,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   constexpr bool TAILS = WM == 4 && WN == 4;      // sub-tiles of the last round: 256x256 tiles only
   constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
   constexpr int NINST = (BM + BN) / 8;          // 1 KiB LDS-DMA instructions per stage
-  constexpr int PER = NINST / NW;               // per wave
-  static_assert(NINST % NW == 0, "stage instructions must divide evenly over the waves");
+  constexpr bool EVEN = NINST % NW == 0;        // wide tiles (WN = 5 / 6: 10 / 12 waves) deal the instructions round-robin, the last ones guarded
+  constexpr int PER = (NINST + NW - 1) / NW;    // per wave
   constexpr int SUB_STAGE = 48 * 1024;          // sub-tiles of the last round: (128 + 256) x 128 B per stage, THREE slots
   __shared__ __attribute__((aligned(16))) char smem[TAILS ? 3 * SUB_STAGE : 2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   bool gval[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int it = f == 1 ? wave * PER + j : j * NW + wave;
+    const int it = (f == 1 && EVEN) ? wave * PER + j : j * NW + wave;
     gval[j] = it < (bm + BN) / 8;
     const int pc = lane & 7;
     if (it < bm / 8) {
@@ -355,7 +355,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   auto stage = [&](int buf, int k0) {            // full tiles: two slots, the compiler orders the LDS-DMA (vmcnt(0) at the barrier)
     char* b = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);
+    for (int j = 0; j < PER; ++j) {
+      if constexpr (EVEN) glds16(gsrc[j] + k0, b + (wave * PER + j) * 1024);
+      else if (gval[j]) glds16(gsrc[j] + k0, b + (j * NW + wave) * 1024);     // (wave-uniform guard)
+    }
   };
 
   // ---- fragment read offsets (bytes inside an operand tile), ks = 0; ks = 1 is ^64 ----

@@ -231,15 +231,24 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   constexpr int TS = RT8_TS, OPB = RT8_OPB, STAGE = RT8_STAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wk = wave >> 1;                 // 2 x 4 waves: 128 n x 64 k each
   const int s = pair / p.tiles_nk;
   const int rem = pair - s * p.tiles_nk;
   const int tn = rem / p.tiles_k, tk = rem - tn * p.tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   // N and K are multiples of 128, not necessarily of 256: the last tile along either may be half a tile.  Its missing columns
-  // are staged as zeros and the two (n) or four (k) waves that own them skip their stores.
+  // are staged as zeros; the waves whose 128 x 64 block lies in the missing half only help with the staging -- no fragment
+  // reads, no MFMAs, no stores (MViTv2-S: 96 / 384-wide layers, 11 of every 38 tiles of a stage-3 block are padding).  The wave
+  // -> block map is chosen so that those waves are 4..7, ONE PER SIMD (waves w and w + 4 share a SIMD): the other wave of each
+  // SIMD then has the matrix pipe to itself.
   const bool nfull = n0 + 256 <= p.N, kfull = k0 + 256 <= p.K;
+#ifndef PVRL_TN_SKIP_PAD
+#define PVRL_TN_SKIP_PAD 1                                 // 0: A/B builds (tools/build_variant.py) -- MFMAs over the zero half as before
+#endif
+  const bool remap = PVRL_TN_SKIP_PAD && !nfull;
+  const int wn = remap ? (wave >> 2) : (wave & 1);         // 2 x 4 waves: 128 n x 64 k each
+  const int wk = remap ? (wave & 3) : (wave >> 1);
   const bool n_ok = nfull || wn == 0, k_ok = kfull || wk < 2;
+  const bool compute = !PVRL_TN_SKIP_PAD || (n_ok && k_ok);   // wave-uniform
   const int mbeg = s * p.Ms;
   const int mend = min(p.M, mbeg + p.Ms);
   const int rows = mend - mbeg;
@@ -263,12 +272,16 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   const int l256 = (wave & 3) * 64 + lane;
   const int g = l256 >> 5, cg = l256 & 31;                 // 8-row block of the stage, 8-column group
   const char* ubase = reinterpret_cast<const char*>(isq ? p.Q + k0 : p.P + n0) + (long)mbeg * ld2;
-  const unsigned loff = (unsigned)(8 * g * ld2 + cg * 16);
-  const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
   const bool colok = (isq ? kfull : nfull) || cg < 16;        // this lane's 8 columns exist
+  const unsigned loff = (unsigned)(8 * g * ld2 + (colok ? cg : 0) * 16);   // (a lane of the missing half re-reads column group 0; masked in wait_set)
+  const int wr = (isq ? OPB : 0) + g * 4096 + (cg >> 1) * 256 + (cg & 1) * 128 + ((cg & 7) << 4);
   const bool tile_full = isq ? kfull : nfull;                 // wave-uniform (waves 0-3 stage P, 4-7 stage Q)
+  const unsigned colkeep = colok ? 0xffffffffu : 0u;
+  // Round 3: a half tile's stages used to take the masked path below for EVERY stage -- plain loads whose values the mask consumes
+  // at once, i.e. an s_waitcnt vmcnt(0) inside gload and the load latency exposed once per stage (2.45 us per stage at N = 128
+  // against 1.9 for full tiles).  They now take the asm loads like everyone else; the mask is applied when the set is waited for.
   auto gload = [&](u32x4* r, int st) {
-    if ((st + 1) * TS <= rows && tile_full) {
+    if ((st + 1) * TS <= rows) {
       const char* b = ubase + (long)st * TS * ld2;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -286,6 +299,10 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   auto wait_set = [&](u32x4* r) {        // ONE register set, one stage (2,048 MFMA cycles per SIMD) ahead: it has landed
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+    if (!tile_full) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] &= (u32x4){colkeep, colkeep, colkeep, colkeep};
+    }
   };
   auto twrite = [&](const u32x4* r, int j, char* slot) {   // column j of the lane's 8: gather its 8 m, store 16 B
     u32x4 o;
@@ -322,6 +339,11 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   u32x4 ra[8];
   // one stage: two K = 32 MFMA steps from slot `rs`; the 8 transposed columns of register set r go to slot `ws`
   auto step = [&](const char* rs, const u32x4* r, char* ws) {
+    if (!compute) {                                        // a wave of the missing half: staging only
+#pragma unroll
+      for (int j = 0; j < 8; ++j) twrite(r, j, ws);
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       opx8 qf[4];
