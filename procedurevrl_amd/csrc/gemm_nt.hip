@@ -162,19 +162,39 @@ int nt_persist_mask() {
 }
 #endif
 
+// PVRL_NT_TILE=22|42|44|26|25 forces a tile shape where it is legal for the problem (shape sweeps: tools/probe/mvit_gemm_times.py); read once
+int nt_forced_tile() {
+  static int t = -1;
+  if (t < 0) {
+    const char* e = getenv("PVRL_NT_TILE");
+    t = e ? atoi(e) : 0;
+  }
+  return t;
+}
+
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   constexpr bool two_out = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
+  switch (nt_forced_tile()) {
+    case 22: return launch_tile<EPI, 2, 2>(p, s);
+    case 42: return launch_tile<EPI, 4, 2>(p, s);
+    case 44: if (p.N % 256 == 0) return launch_tile<EPI, 4, 4>(p, s); break;
+    case 26: if (p.N % 384 == 0) return launch_tile<EPI, 2, 6>(p, s); break;
+    case 25: if (p.N % 320 == 0) return launch_tile<EPI, 2, 5>(p, s); break;
+    default: break;
+  }
+  if (nt_wide_enabled() && p.N == 768 && p.M >= 4096 && p.M < 20000) return launch_tile<EPI, 2, 6>(p, s);   // MViT stage 4 (M = 12,576): 99 tiles of 128 x 384 x 2 fill 198 CUs; 256 x 256 tiles 150 (-10 %)
   if (p.M >= 4096 && p.N % 256 == 0) {
 #if PVRL_NT_PERSIST_BUILD
     if ((nt_persist_mask() >> EPI) & 1) return launch_pers<EPI>(p, s);
 #endif
     return launch_tile<EPI, 4, 4>(p, s);
   }
-  // N = 384 / 1152 and 640 (MViTv2-S stages 1-3): one 128 x 384 / 128 x 320 tile row instead of three / five 128 x 128 column tiles
-  // -- the A panel is fetched once and a workgroup's fixed costs cover 3x / 2.5x the output (PVRL_NT_WIDE=0: A/B runs)
+  // N = 384 / 1152 and 640 at M >= 100k rows (MViTv2-S stages 1-2): one 128 x 384 / 128 x 320 tile row instead of three / five 128 x 128
+  // column tiles -- the A panel is fetched once and a workgroup's fixed costs cover 3x / 2.5x the output (8-23 % per shape; at
+  // M = 50,208 the 128 x 128 tiles' two workgroups per CU win by 5-9 %: gpurun_out/r3_w_shapes_*.txt).  PVRL_NT_WIDE=0: A/B runs
   if (nt_wide_enabled() && p.M >= 4096 && p.N % 256 != 0) {
-    if (p.N == 384 || (p.N % 384 == 0 && p.M >= 100000)) return launch_tile<EPI, 2, 6>(p, s);   // (N = 1152 at M = 50,208: 128 x 128 tiles are 7 % faster)
+    if (p.N % 384 == 0 && p.M >= 100000) return launch_tile<EPI, 2, 6>(p, s);
     if (p.N % 320 == 0) return launch_tile<EPI, 2, 5>(p, s);
   }
   if (p.M >= 2048 && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
