@@ -40,7 +40,39 @@ struct PA {
   float* kv_part;                                // [nsplit][2][BH][Lk+1][96] fp32 partial dK / dV
   int B, H, Lq, Lk, kt, kh, kw, J, JP;
   float scale;
+  int gx, gy, gz;                                // logical grid: tiles x (b, h) x slices, see pattn_block
 };
+
+// XCD-aware launch order (round 3).  The workgroups of one (b, h) share an operand -- K / V for the query-tile kernels, Q / dO for the
+// dK / dV kernel -- and the hardware deals consecutive workgroup ids round-robin over the 8 XCDs: with the natural (tile fastest) order
+// every XCD's L2 fetched every (b, h)'s shared operand (forward: 280 MB read per launch against 58 MB of operands; dK / dV: 995 MB at
+// 5.7 TB/s -- fabric-bound on re-reads).  1-D grid, id = 8 j + xcd: XCD x runs the (b, h) with bh % 8 == x, their tiles back to back.
+#ifndef PVRL_PATTN_XCD
+#define PVRL_PATTN_XCD 1
+#endif
+struct PBlk { int x, y, z; };
+__device__ __forceinline__ bool pattn_block(const PA& p, PBlk& o) {
+  const int inner = p.gx * p.gz;
+#if PVRL_PATTN_XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int i = j % inner;
+  o.y = (j / inner) * 8 + xcd;
+#else
+  const int i = blockIdx.x % inner;
+  o.y = blockIdx.x / inner;
+#endif
+  o.x = i % p.gx;
+  o.z = i / p.gx;
+  return o.y < p.gy;
+}
+static unsigned pattn_grid(PA& p, long gx, long gy, long gz) {
+  p.gx = (int)gx; p.gy = (int)gy; p.gz = (int)gz;
+#if PVRL_PATTN_XCD
+  return (unsigned)(8 * ((gy + 7) / 8) * gx * gz);
+#else
+  return (unsigned)(gx * gy * gz);
+#endif
+}
 
 // Staging of a PAIR of 32 x 96 tiles (K | V, or Q | dO): 768 chunks of 16 B, exactly three per thread, no branches.  Chunk
 // c = tid + 256 e belongs to the first tile for c < 384.  The (row, column, LDS offset) split is a loop invariant kept
@@ -165,9 +197,11 @@ __global__ __launch_bounds__(256, 4) void pattn_fwd_kernel(PA p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const FragLanes fl = frag_lanes(lane);
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  PBlk blk;
+  if (!pattn_block(p, blk)) return;                        // (block-uniform; before any barrier)
+  const int bh = blk.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
-  const int query = blockIdx.x * 64 + wave * 16 + i;
+  const int query = blk.x * 64 + wave * 16 + i;
   const int qc = query < Lq1 ? query : Lq1 - 1;
   const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
   opx8 qf[3], rh[NJS], rl[NJS];
@@ -281,9 +315,11 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const FragLanes fl = frag_lanes(lane);
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  PBlk blk;
+  if (!pattn_block(p, blk)) return;                        // (block-uniform; before any barrier)
+  const int bh = blk.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
-  const int query = blockIdx.x * 64 + wave * 16 + i;
+  const int query = blk.x * 64 + wave * 16 + i;
   const int qc = query < Lq1 ? query : Lq1 - 1;
   const bool qpatch = query < p.Lq;
   const op_t* qrow = p.q + ((long)bh * Lq1 + qc) * D;
@@ -314,7 +350,7 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_q_kernel(PA p
   pair_lstore(rkv, pm, smem);
   *reinterpret_cast<u32x4*>(smem + 2 * TILE_BYTES + tid * 16) = re;
   __syncthreads();
-  const bool qpatch_any = blockIdx.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
+  const bool qpatch_any = blk.x * 64 < p.Lq;          // uniform: does this workgroup hold any patch query
 
   const float c = p.scale * LOG2E;
   f32x4 dq[6];
@@ -416,9 +452,11 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q4 = lane >> 4;
   const FragLanes fl = frag_lanes(lane);
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  PBlk blk;
+  if (!pattn_block(p, blk)) return;                        // (block-uniform; before any barrier)
+  const int bh = blk.y, b = bh / p.H, h = bh - b * p.H;
   const int Lq1 = p.Lq + 1, Lk1 = p.Lk + 1;
-  const int key = blockIdx.x * 64 + wave * 16 + i;
+  const int key = blk.x * 64 + wave * 16 + i;
   const int kc = key < Lk1 ? key : Lk1 - 1;
   opx8 kf[3], vf[3], ef[NJS];
 #pragma unroll
@@ -430,8 +468,8 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
   for (int js = 0; js < NJS; ++js)
     ef[js] = *reinterpret_cast<const opx8*>(p.keymap + (long)(kc / KT) * ET_BYTES + bl_off(kc % KT, (js * 4 + q4) * 8));
   const int ntiles_all = (Lq1 + KT - 1) / KT;
-  const int per = (ntiles_all + gridDim.z - 1) / gridDim.z;          // query tiles of this z-slice
-  const int tbeg = blockIdx.z * per, ntiles = min(ntiles_all, tbeg + per);
+  const int per = (ntiles_all + p.gz - 1) / p.gz;                    // query tiles of this z-slice
+  const int tbeg = blk.z * per, ntiles = min(ntiles_all, tbeg + per);
   const op_t* qb = p.q + (long)bh * Lq1 * D;
 
   // Q | dO pair: the dO rows are gathered from the token-major activation (rows (b, query), the cls row last; columns
@@ -548,8 +586,8 @@ __global__ __launch_bounds__(256, NJS == 1 ? 3 : 2) void pattn_bwd_kv_kernel(PA 
     __syncthreads();
   }
   if (key < Lk1) {
-    const long nkv = (long)gridDim.y * Lk1 * D;
-    float* kp = p.kv_part + ((long)blockIdx.z * 2) * nkv + ((long)bh * Lk1 + key) * D + 4 * q4;
+    const long nkv = (long)p.gy * Lk1 * D;
+    float* kp = p.kv_part + ((long)blk.z * 2) * nkv + ((long)bh * Lk1 + key) * D + 4 * q4;
     float* vp = kp + nkv;
 #pragma unroll
     for (int dt = 0; dt < 6; ++dt) {
@@ -617,7 +655,7 @@ extern "C" int pvrl_mvit_attn_fwd(const void* q, const void* k, const void* v, c
   PA p = {};
   if (!o || !lse || fill(p, q, k, v, relp, keymap, B, H, Lq, kt, kh, kw, scale, ldo)) return PVRL_EINVAL;
   p.o = (op_t*)o; p.lse = lse;
-  const dim3 grid((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H));
+  const dim3 grid(pattn_grid(p, cdiv(Lq + 1, 64), B * H, 1));
   if (p.JP == 32) hipLaunchKernelGGL(pattn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(pattn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
   PVRL_LAUNCH_CHECK();
@@ -650,12 +688,12 @@ extern "C" int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, c
   p.o = (op_t*)o; p.d_o = (const op_t*)d_o; p.lse = (float*)lse; p.delta = delta;
   p.dq = (op_t*)dq; p.dk = (op_t*)dk; p.dv = (op_t*)dv; p.drel = drel;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 gq((unsigned)cdiv(Lq + 1, 64), (unsigned)(B * H));
+  const dim3 gq(pattn_grid(p, cdiv(Lq + 1, 64), B * H, 1));
   if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_q_kernel<1>, gq, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(pattn_bwd_q_kernel<2>, gq, dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
   const int ns = kv_splits(B * H, Lq, p.Lk);
-  const dim3 gk((unsigned)cdiv(p.Lk + 1, 64), (unsigned)(B * H), (unsigned)ns);
+  const dim3 gk(pattn_grid(p, cdiv(p.Lk + 1, 64), B * H, ns));
   if (p.JP == 32) hipLaunchKernelGGL(pattn_bwd_kv_kernel<1>, gk, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(pattn_bwd_kv_kernel<2>, gk, dim3(256), 0, s, p);
   PVRL_LAUNCH_CHECK();
