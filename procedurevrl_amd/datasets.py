@@ -98,7 +98,11 @@ class SyntheticValClips(torch.utils.data.Dataset):
         if self.clips:
             return (torch.randn(self.clips, 3, T, S, S, generator=g), torch.randint(0, K, (self.clips,), generator=g),
                     torch.tensor(index), {})
-        return torch.randn(3, T, S, S, generator=g), torch.randint(0, K, (1,), generator=g)[0], torch.tensor(index), {}
+        x = torch.randn(3, T, S, S, generator=g)
+        if self.cfg.TRAIN.DATASET == "Epickitchens":            # lib/datasets/epickitchens.py: label = {'verb', 'noun'} (97 / 300 classes)
+            return x, {"verb": torch.randint(0, 97, (1,), generator=g)[0], "noun": torch.randint(0, 300, (1,), generator=g)[0]}, \
+                torch.tensor(index), {}
+        return x, torch.randint(0, K, (1,), generator=g)[0], torch.tensor(index), {}
 
 
 def create_sampler(dataset, shuffle, cfg):
@@ -122,7 +126,10 @@ def construct_loader(cfg, split="train", num_videos=None, batch_size=None):
         bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
         shuffle, drop_last = False, False
     else:
-        ds = SyntheticHowTo100M(cfg, n)
+        # the pre-training tuple (clips + narration tokens) or, for the fine-tuning configs (TRAIN.LABEL_EMB / TRAIN.TEXT empty),
+        # labelled clips
+        pretrain = cfg.TRAIN.LABEL_EMB != "" and cfg.TRAIN.TEXT != ""
+        ds = SyntheticHowTo100M(cfg, n) if pretrain else SyntheticValClips(cfg, n, seed=2)
         bs = batch_size or max(1, int(cfg.TRAIN.BATCH_SIZE / max(1, cfg.NUM_GPUS)))
         shuffle, drop_last = True, True
     sampler = create_sampler(ds, shuffle, cfg)

@@ -2,7 +2,9 @@
 
 Kept from the reference: per-iteration LR set (:123-124), `meta` reshape (:146), the model call and KL + MSE loss
 (:147-162), NaN check (:174), the accumulation branch to GLOBAL_BATCH_SIZE (:176-192, folded into the optimiser's
-grad_scale), top-k error on the logits vs a dummy label (:226-231), json_stats logging, checkpoint / auto-resume.
+grad_scale), top-k error on the logits vs a dummy label (:226-231), the fine-tuning branch (:149-150, 163-169: cross entropy /
+`smooth` on model(inputs); EPIC-Kitchens verb + noun heads with their accuracies :195-222), json_stats logging, checkpoint /
+auto-resume.  Not built: MIXUP (no shipped ProcedureVRL config enables it).
 Changed by design: gradients are reduced by `GradReducer` (flat buffer, overlapped with backward) instead of DDP,
 the three metric scalars are one all-reduce, and the host reads them only every LOG_PERIOD iterations instead of
 `.item()`-syncing every iteration (:234-236)."""
@@ -29,6 +31,56 @@ def topks_correct(preds, labels, ks):
     return [correct[:k, :].float().sum() for k in ks]
 
 
+def topk_accuracies(preds, labels, ks):
+    """lib/utils/metrics.py:60-70: top-k accuracy in percent"""
+    return [x / preds.size(0) * 100.0 for x in topks_correct(preds, labels, ks)]
+
+
+def multitask_topk_accuracies(preds, labels, ks):
+    """lib/utils/metrics.py:73-96 (EPIC action = verb AND noun): a sample counts for k when EVERY task's label is among
+    that task's top-k predictions."""
+    max_k = int(max(ks))
+    all_correct = torch.ones(max_k, labels[0].size(0), dtype=torch.bool, device=labels[0].device)
+    for output, label in zip(preds, labels):
+        _, top = output.topk(min(max_k, output.shape[1]), 1, True, True)
+        hit = top.t().eq(label.view(1, -1).expand_as(top.t()))
+        if hit.shape[0] < max_k:                                     # fewer classes than k: the task is always "in the top k" past its width
+            hit = torch.cat([hit, hit.any(0, keepdim=True).expand(max_k - hit.shape[0], -1)], 0)
+        all_correct = all_correct & hit.cumsum(0).bool()
+    return [all_correct[k - 1].float().sum() / labels[0].size(0) * 100.0 for k in ks]
+
+
+class LabelSmoothingCrossEntropy(torch.nn.Module):
+    """timm.loss.LabelSmoothingCrossEntropy as tools/train_net.py:127-128 uses it (`MODEL.LOSS_FUNC: smooth`, smoothing 0.2)"""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        self.smoothing = smoothing
+
+    def forward(self, x, target):
+        logp = torch.nn.functional.log_softmax(x, dim=-1)
+        nll = -logp.gather(dim=-1, index=target.unsqueeze(1)).squeeze(1)
+        return ((1.0 - self.smoothing) * nll + self.smoothing * (-logp.mean(dim=-1))).mean()
+
+
+def is_pretraining(cfg):
+    """tools/train_net.py:146: the pre-training tuple (inputs, narration tokens) vs the fine-tuning call model(inputs)"""
+    return cfg.TRAIN.LABEL_EMB != "" and cfg.TRAIN.TEXT != ""
+
+
+def finetune_loss(preds, labels, cfg):
+    """tools/train_net.py:126-136,163-169: cross entropy (or `smooth`) on the logits; EPIC-Kitchens: the mean of the verb and
+    the noun loss.  Returns (loss, per-task losses or None)."""
+    from .losses import get_loss_func
+    if cfg.MIXUP.ENABLED:
+        raise NotImplementedError("MIXUP.ENABLED (timm Mixup, tools/train_net.py:137-143) is not built; no shipped ProcedureVRL config enables it")
+    loss_fun = LabelSmoothingCrossEntropy(0.2) if cfg.MODEL.LOSS_FUNC == "smooth" else get_loss_func(cfg.MODEL.LOSS_FUNC)(reduction="mean")
+    if isinstance(labels, dict) and cfg.TRAIN.DATASET == "Epickitchens":
+        lv, ln = loss_fun(preds[0], labels["verb"]), loss_fun(preds[1], labels["noun"])
+        return 0.5 * (lv + ln), (lv, ln)
+    return loss_fun(preds, labels), None
+
+
 def log_json_stats(stats):
     """lib/utils/logging.py:83-95: floats rounded to 5 decimals, one `json_stats:` line."""
     stats = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in stats.items()}
@@ -49,18 +101,25 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
     optimizer.grad_scale = 1.0 / (world * (num_iters if accumulate else 1))
     dev = next(model.parameters()).device
     window = []
+    last_line = None
+    pretrain = is_pretraining(cfg)
     t_last = time.perf_counter()
     for cur_iter, (inputs, labels, _index, meta) in enumerate(train_loader):
         if max_iters is not None and cur_iter >= max_iters:
             break
         inputs = inputs.to(dev, non_blocking=True)
-        labels = labels.to(dev).view(-1)
+        labels = {k: v.to(dev).view(-1) for k, v in labels.items()} if isinstance(labels, dict) else labels.to(dev).view(-1)
         meta = {k: v.to(dev, non_blocking=True) for k, v in meta.items()}
         lr = optim.get_epoch_lr(cur_epoch + float(cur_iter) / data_size, cfg)
         optim.set_lr(optimizer, lr)
-        meta = {k: meta[k].view(-1, meta[k].shape[-1]) for k in meta}
-        pred, teacher_pred, mse = model([inputs, meta])
-        loss, loss1, loss2 = pretrain_loss(pred, teacher_pred, mse, cfg)
+        task_losses = None
+        if pretrain:
+            meta = {k: meta[k].view(-1, meta[k].shape[-1]) for k in meta}
+            pred, teacher_pred, mse = model([inputs, meta])
+            loss, loss1, loss2 = pretrain_loss(pred, teacher_pred, mse, cfg)
+        else:                                                  # fine-tuning (train_net.py:149-150,163-169): logits -> cross entropy
+            pred = model(inputs)
+            loss, task_losses = finetune_loss(pred, labels, cfg)
         if not accumulate or cur_iter % num_iters == 0:
             optimizer.zero_grad(set_to_none=True)
         last_micro = not accumulate or (cur_iter + 1) % num_iters == 0
@@ -70,10 +129,18 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
             reducer.finish()
             optimizer.step()
         with torch.no_grad():
-            lab = labels[0].expand(pred.size(0))
-            k5 = min(5, pred.shape[1])
-            c1, c5 = topks_correct(pred, lab, (1, k5))
-            stats = du.all_reduce_scalars([loss.detach(), (1.0 - c1 / pred.size(0)) * 100.0, (1.0 - c5 / pred.size(0)) * 100.0])
+            if task_losses is not None:                        # EPIC-Kitchens (train_net.py:195-222): verb / noun / action accuracies
+                v1, v5 = topk_accuracies(pred[0], labels["verb"], (1, 5))
+                n1, n5 = topk_accuracies(pred[1], labels["noun"], (1, 5))
+                a1, a5 = multitask_topk_accuracies((pred[0], pred[1]), (labels["verb"], labels["noun"]), (1, 5))
+                stats = du.all_reduce_scalars([loss.detach(), 100.0 - a1, 100.0 - a5, task_losses[0].detach(), task_losses[1].detach(),
+                                               v1, v5, n1, n5, a1, a5])
+            else:
+                # pre-training ignores the labels: the first one is copied to the prediction's length (train_net.py:226-227)
+                lab = labels[0].expand(pred.size(0)) if cfg.DEV.ORDER_PRETRAIN_ENABLED and pretrain else labels
+                k5 = min(5, pred.shape[1])
+                c1, c5 = topks_correct(pred, lab, (1, k5))
+                stats = du.all_reduce_scalars([loss.detach(), (1.0 - c1 / pred.size(0)) * 100.0, (1.0 - c5 / pred.size(0)) * 100.0])
         window.append(stats)
         if (cur_iter + 1) % cfg.LOG_PERIOD == 0 or cur_iter + 1 == data_size:
             w = torch.stack(window)
@@ -83,12 +150,18 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
             now = time.perf_counter()
             dt = (now - t_last) / len(window)
             t_last = now
-            log_json_stats({"_type": "train_iter", "epoch": "{}/{}".format(cur_epoch + 1, cfg.SOLVER.MAX_EPOCH),
-                            "iter": "{}/{}".format(cur_iter + 1, data_size), "dt": dt, "loss": vals[0],
-                            "top1_err": vals[1], "top5_err": vals[2], "lr": lr,
-                            "clips_per_s": inputs.size(0) * inputs.size(1) * world / dt})
+            nclip = inputs.size(0) * (inputs.size(1) if inputs.dim() == 6 else 1)
+            line = {"_type": "train_iter", "epoch": "{}/{}".format(cur_epoch + 1, cfg.SOLVER.MAX_EPOCH),
+                    "iter": "{}/{}".format(cur_iter + 1, data_size), "dt": dt, "loss": vals[0],
+                    "top1_err": vals[1], "top5_err": vals[2], "lr": lr, "clips_per_s": nclip * world / dt}
+            if task_losses is not None:                        # EPICTrainMeter's extra columns (lib/utils/meters.py)
+                m = w.median(0).values.tolist()
+                line.update({"verb_loss": m[3], "noun_loss": m[4], "verb_top1_acc": m[5], "verb_top5_acc": m[6],
+                             "noun_top1_acc": m[7], "noun_top5_acc": m[8], "top1_acc": m[9], "top5_acc": m[10]})
+            log_json_stats(line)
+            last_line = line
             window = []
-    return None
+    return last_line
 
 
 class ValMeter:

@@ -337,3 +337,38 @@ def test_val_meter_epoch_stats_and_eval_schedule():
     s2 = m.log_epoch_stats(1)
     assert s2["min_top1_err"] == s["top1_err"] and s2["min_top5_err"] == 5.0      # minima persist across reset()
     assert [e for e in range(7) if is_eval_epoch(cfg, e)] == [2, 5, 6]
+
+
+def test_finetune_metrics_and_losses_match_their_definitions():
+    """The fine-tuning branch of the train loop (tools/train_net.py:126-136,163-169,195-222): multi-task (EPIC action) top-k
+    accuracy = both labels within their task's top k, by brute force; `smooth` = timm's label-smoothing cross entropy;
+    the EPIC loss is the mean of the verb and the noun cross entropy."""
+    import torch.nn.functional as F
+    from procedurevrl_amd import train_net as tn
+    g = torch.Generator().manual_seed(3)
+    pv, pn = torch.randn(33, 97, generator=g), torch.randn(33, 300, generator=g)
+    lv, ln = torch.randint(0, 97, (33,), generator=g), torch.randint(0, 300, (33,), generator=g)
+    pv[torch.arange(0, 33, 3), lv[::3]] += 6.0                       # make a share of the samples right
+    pn[torch.arange(0, 33, 2), ln[::2]] += 6.0
+    a1, a5 = tn.multitask_topk_accuracies((pv, pn), (lv, ln), (1, 5))
+    for k, got in ((1, a1), (5, a5)):
+        hit = 0
+        for b in range(33):
+            hit += int(lv[b] in pv[b].topk(k).indices and ln[b] in pn[b].topk(k).indices)
+        assert abs(float(got) - 100.0 * hit / 33) < 1e-4
+    v1, = tn.topk_accuracies(pv, lv, (1,))
+    assert abs(float(v1) - 100.0 * float((pv.argmax(1) == lv).float().mean())) < 1e-4
+    x, t = torch.randn(9, 11, generator=g), torch.randint(0, 11, (9,), generator=g)
+    ref = F.cross_entropy(x, t, label_smoothing=0.0) * 0.8 + 0.2 * (-F.log_softmax(x, -1).mean(-1)).mean()
+    assert torch.allclose(tn.LabelSmoothingCrossEntropy(0.2)(x, t), ref, atol=1e-6)
+    cfg = get_cfg()
+    cfg.TRAIN.DATASET = "Epickitchens"
+    loss, (l_v, l_n) = tn.finetune_loss((pv, pn), {"verb": lv, "noun": ln}, cfg)
+    assert torch.allclose(loss, 0.5 * (F.cross_entropy(pv, lv) + F.cross_entropy(pn, ln)), atol=1e-6)
+    cfg.TRAIN.DATASET = "kinetics"
+    loss, none = tn.finetune_loss(pv, lv, cfg)
+    assert none is None and torch.allclose(loss, F.cross_entropy(pv, lv), atol=1e-6)
+    assert not tn.is_pretraining(cfg)
+    cfg.MIXUP.ENABLED = True
+    with pytest.raises(NotImplementedError):
+        tn.finetune_loss(pv, lv, cfg)
