@@ -126,17 +126,36 @@ __global__ __launch_bounds__(256) void rel_fwd_kernel(const op_t* __restrict__ Q
 // ------------------------------------------------------------------------------------------------- dQ
 // dQ[bh][q][c] += sum_j drel[bh][q][j] * R_j(q)[c]     (dQ is the 16-bit gradient written by the attention backward)
 // one thread per (q, CPT channels): the d rel value and the table index of a j are loaded once per CPT / 4 row chunks
-template <int CPT>
-__global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
+// TAB_LDS (round 3): the three tables (<= 240 rows of 96 floats) and their index maps are copied into LDS once per workgroup of 16 waves
+// and every gather reads LDS -- the kernel was bound by its vector-memory instruction count (J x 3 sixteen-byte gathers per lane from
+// L1 / L2); what is left in the vector-memory path is the d rel row and the read-modify-write of dQ.
+constexpr int RELQ_MAXROWS = 240, RELQ_MAXIDX = 1024;
+template <int CPT, bool TAB_LDS>
+__global__ __launch_bounds__(TAB_LDS ? 1024 : 256) void rel_bwd_q_kernel(const float* __restrict__ drel, RelGeom g,
                                                         const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                         const float* __restrict__ Rt, const int* __restrict__ ih,
                                                         const int* __restrict__ iw, const int* __restrict__ it,
-                                                        op_t* __restrict__ dQ) {
+                                                        int nrh, int nrw, int nrt, op_t* __restrict__ dQ) {
   constexpr int NV = CPT / 4, TPQ = HD / CPT;
+  constexpr int NT = TAB_LDS ? 1024 : 256;
+  __shared__ __attribute__((aligned(16))) float tab[TAB_LDS ? RELQ_MAXROWS * HD : 4];
+  __shared__ int tix[TAB_LDS ? 3 * RELQ_MAXIDX : 4];
+  if constexpr (TAB_LDS) {
+    const int n4h = nrh * (HD / 4), n4w = nrw * (HD / 4), n4t = nrt * (HD / 4);
+    for (int i = threadIdx.x; i < n4h + n4w + n4t; i += NT) {
+      const f32x4 v = i < n4h ? reinterpret_cast<const f32x4*>(Rh)[i]
+                              : (i < n4h + n4w ? reinterpret_cast<const f32x4*>(Rw)[i - n4h] : reinterpret_cast<const f32x4*>(Rt)[i - n4h - n4w]);
+      reinterpret_cast<f32x4*>(tab)[i] = v;
+    }
+    for (int i = threadIdx.x; i < g.qh * g.kh; i += NT) tix[i] = ih[i];
+    for (int i = threadIdx.x; i < g.qw * g.kw; i += NT) tix[RELQ_MAXIDX + i] = iw[i];
+    for (int i = threadIdx.x; i < g.qt * g.kt; i += NT) tix[2 * RELQ_MAXIDX + i] = it[i];
+    __syncthreads();
+  }
   const int J = g.kh + g.kw + g.kt;
   const int Lq = g.qt * g.qh * g.qw;
   const long total = (long)g.BH * Lq * TPQ;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
     const int c = (int)(idx % TPQ) * CPT;
     const long bq = idx / TPQ;
     const int q = (int)(bq % Lq);
@@ -156,24 +175,34 @@ __global__ __launch_bounds__(256) void rel_bwd_q_kernel(const float* __restrict_
         const int jk = min(j0 + k8, kn - 1);
         const float wk = j0 + k8 < kn ? dj[jk] : 0.f;
         const int rk = ix[jk];
-        f32x4 rows[8][NV];
-        float w[8];
+        constexpr int GB = TAB_LDS ? 4 : 8;          // rows gathered per batch (LDS latency needs less in flight; 128-VGPR budget at 16 waves)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          w[e] = __shfl(wk, e, 8);
-          const f32x4* row = reinterpret_cast<const f32x4*>(R + (long)__shfl(rk, e, 8) * HD + c);
+        for (int e0 = 0; e0 < 8; e0 += GB) {
+          f32x4 rows[GB][NV];
+          float w[GB];
 #pragma unroll
-          for (int v = 0; v < NV; ++v) rows[e][v] = row[v];
+          for (int e = 0; e < GB; ++e) {
+            w[e] = __shfl(wk, e0 + e, 8);
+            const f32x4* row = reinterpret_cast<const f32x4*>(R + (long)__shfl(rk, e0 + e, 8) * HD + c);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) rows[e][v] = row[v];
+          }
+#pragma unroll
+          for (int e = 0; e < GB; ++e)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) a[v] += w[e] * rows[e][v];
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int v = 0; v < NV; ++v) a[v] += w[e] * rows[e][v];
       }
     };
-    axis(Rh, ih + y * g.kh, g.kh, d);
-    axis(Rw, iw + x * g.kw, g.kw, d + g.kh);
-    axis(Rt, it + t * g.kt, g.kt, d + g.kh + g.kw);
+    if constexpr (TAB_LDS) {
+      axis(tab, tix + y * g.kh, g.kh, d);
+      axis(tab + nrh * HD, tix + RELQ_MAXIDX + x * g.kw, g.kw, d + g.kh);
+      axis(tab + (nrh + nrw) * HD, tix + 2 * RELQ_MAXIDX + t * g.kt, g.kt, d + g.kh + g.kw);
+    } else {
+      axis(Rh, ih + y * g.kh, g.kh, d);
+      axis(Rw, iw + x * g.kw, g.kw, d + g.kh);
+      axis(Rt, it + t * g.kt, g.kt, d + g.kh + g.kw);
+    }
     op_t* p = dQ + (bh * (Lq + 1) + q) * HD + c;
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -363,8 +392,18 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
   hipStream_t s = (hipStream_t)stream;
   // 12 channels per thread = 8 lanes per query (with per-thread d rel / index loads: 4 / 8 / 16 / 32 channels measured
   // 2.4 / 1.9 / 2.8 / 4.2 ms per MViTv2-S step)
-  hipLaunchKernelGGL(rel_bwd_q_kernel<12>, dim3(grid_for((long)BH * qt * qh * qw * (HD / 12))), dim3(256), 0, s, drel, g, Rh, Rw,
-                     Rt, idx_h, idx_w, idx_t, (op_t*)dQ);
+  const long nthr = (long)BH * qt * qh * qw * (HD / 12);
+  static const int relq_lds = [] { const char* e = getenv("PVRL_RELQ_LDS"); return e ? (e[0] != '0') : 1; }();   // 0: A/B runs
+  if (relq_lds && nrows_h + nrows_w + nrows_t <= RELQ_MAXROWS && qh * kh <= RELQ_MAXIDX && qw * kw <= RELQ_MAXIDX && qt * kt <= RELQ_MAXIDX &&
+      ((uintptr_t)Rh % 16) == 0 && ((uintptr_t)Rw % 16) == 0 && ((uintptr_t)Rt % 16) == 0) {
+    // one 16-wave workgroup per CU (104 KB of tables), walking the queries grid-stride
+    const unsigned grid = (unsigned)std::min<long>((nthr + 1023) / 1024, 256);
+    hipLaunchKernelGGL((rel_bwd_q_kernel<12, true>), dim3(grid), dim3(1024), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
+                       (int)nrows_h, (int)nrows_w, (int)nrows_t, (op_t*)dQ);
+  } else {
+    hipLaunchKernelGGL((rel_bwd_q_kernel<12, false>), dim3(grid_for(nthr)), dim3(256), 0, s, drel, g, Rh, Rw, Rt, idx_h, idx_w, idx_t,
+                       (int)nrows_h, (int)nrows_w, (int)nrows_t, (op_t*)dQ);
+  }
   PVRL_LAUNCH_CHECK();
   RelAxes ax = {};
   rel_axes(ax, g);
