@@ -671,7 +671,9 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const op_t* __restrict_
 
 // The same for temporal stride 1, sliding along t (see pool_fwd_t_kernel): 16 lanes own one INPUT column (b, h, yi, xi); the
 // (at most 9) outputs of a frame that touch it are loaded once and feed the running sums of dX at t - 1, t and t + 1.
-template <bool DENSE>
+// S = the spatial stride as a compile-time constant (1 / 2 / 4 / 8; 0: any): the nine `% stride`, `/ stride` pairs of a column's
+// set-up become masks and shifts -- with run-time strides they were ~540 of the ~2,800 VALU instructions per column (issue-bound kernel).
+template <bool DENSE, int S>
 __global__ __launch_bounds__(256) void pool_dgrad_t_kernel(const op_t* __restrict__ dc, PoolGeom g,
                                                            const float* __restrict__ w, op_t* __restrict__ dqkv) {
   __shared__ float ws[27 * HD];
@@ -692,8 +694,9 @@ __global__ __launch_bounds__(256) void pool_dgrad_t_kernel(const op_t* __restric
 #pragma unroll
       for (int xx = 0; xx < 3; ++xx) {
         const int yn = yi + 1 - yy, xn = xi + 1 - xx;
-        const bool ok = yn >= 0 && xn >= 0 && (yn % g.sh) == 0 && (xn % g.sw) == 0 && yn / g.sh < g.Ho && xn / g.sw < g.Wo;
-        noff[yy * 3 + xx] = ok ? (yn / g.sh) * g.Wo + xn / g.sw : -1;
+        const int sh = S ? S : g.sh, sw = S ? S : g.sw;
+        const bool ok = yn >= 0 && xn >= 0 && (yn % sh) == 0 && (xn % sw) == 0 && yn / sh < g.Ho && xn / sw < g.Wo;
+        noff[yy * 3 + xx] = ok ? (yn / sh) * g.Wo + xn / sw : -1;
       }
     const op_t* base = dc + (long)bh * (Lo + 1) * HD + c0;
     op_t* dst = dqkv + ((long)b * L + pos) * g.ld + g.col0 + h * HD + c0;
@@ -1211,12 +1214,19 @@ extern "C" int pvrl_mvit_pool_bwd(const void* dy, const void* conv_out, const vo
     const dim3 dg(grid_for(nin * 16)), db(256);
     const int S = (st == 1 && sh == sw && (sh == 1 || sh == 2 || sh == 4 || sh == 8)) ? (int)sh : 0;
 #define DGRAD(SS) hipLaunchKernelGGL(pool_dgrad_kernel<SS>, dg, db, 0, s, (const op_t*)dc_scratch, g, w, (op_t*)dqkv)
-    if (st == 1 && sh == 1 && sw == 1)         // temporal stride 1: one 16-lane group per input column, sliding along t
-      hipLaunchKernelGGL(pool_dgrad_t_kernel<true>, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch,
-                         g, w, (op_t*)dqkv);
-    else if (st == 1)
-      hipLaunchKernelGGL(pool_dgrad_t_kernel<false>, dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, (const op_t*)dc_scratch,
-                         g, w, (op_t*)dqkv);
+#define DGRAD_T(DD, SS) hipLaunchKernelGGL((pool_dgrad_t_kernel<DD, SS>), dim3(grid_for((long)B * H * Hh * Ww * 16)), db, 0, s, \
+                                           (const op_t*)dc_scratch, g, w, (op_t*)dqkv)
+#ifndef PVRL_POOL_DGRAD_S
+#define PVRL_POOL_DGRAD_S 1                                     // 0: run-time strides everywhere (A/B builds)
+#endif
+    if (!PVRL_POOL_DGRAD_S && st == 1 && sh == 1 && sw == 1) DGRAD_T(true, 0);
+    else if (!PVRL_POOL_DGRAD_S && st == 1) DGRAD_T(false, 0);
+    else if (st == 1 && sh == 1 && sw == 1) DGRAD_T(true, 1);   // temporal stride 1: one 16-lane group per input column, sliding along t
+    else if (st == 1 && S == 2) DGRAD_T(false, 2);
+    else if (st == 1 && S == 4) DGRAD_T(false, 4);
+    else if (st == 1 && S == 8) DGRAD_T(false, 8);
+    else if (st == 1) DGRAD_T(false, 0);
+#undef DGRAD_T
     else if (S == 2) DGRAD(2); else if (S == 4) DGRAD(4); else if (S == 8) DGRAD(8); else DGRAD(0);
 #undef DGRAD
   }
