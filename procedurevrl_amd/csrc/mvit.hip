@@ -818,18 +818,18 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_t_kernel(const op
   __shared__ float red[27][HD];
   const int cq = threadIdx.x % PW_CQ, tl = threadIdx.x / PW_CQ, c0 = cq * 4;
   const int HoWo = g.Ho * g.Wo, Lo = g.T * HoWo, plane = g.Hh * g.Ww, L = g.T * plane;
-  const long ncol = (long)g.B * g.H * HoWo;
-  f32x4 acc[27];
+  const unsigned ncol = (unsigned)((long)g.B * g.H * HoWo);       // < 2^27 (checked by the launcher): 32-bit column arithmetic --
+  f32x4 acc[27];                                                  // four 64-bit divisions per column were ~half of a column's instructions
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < 27 * HD; i += PW_CQ * PW_LANES) red[i / HD][i % HD] = 0.f;
-  const long wgl = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const long chunk = (ncol + gridDim.x - 1) / gridDim.x;
-  const long cend = min(ncol, (wgl + 1) * chunk);
-  for (long colid = wgl * chunk + tl; colid < cend; colid += PW_LANES) {
-    const int pos = (int)(colid % HoWo);
-    const long bh = colid / HoWo;
-    const int h = (int)(bh % g.H), b = (int)(bh / g.H);
+  const unsigned wgl = (unsigned)xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const unsigned chunk = (ncol + gridDim.x - 1) / gridDim.x;
+  const unsigned cend = min(ncol, (wgl + 1) * chunk);
+  for (unsigned colid = wgl * chunk + tl; colid < cend; colid += PW_LANES) {
+    const int pos = (int)(colid % (unsigned)HoWo);
+    const unsigned bh = colid / (unsigned)HoWo;
+    const int h = (int)(bh % (unsigned)g.H), b = (int)(bh / (unsigned)g.H);
     const int xo = pos % g.Wo, yo = pos / g.Wo;
     int noff[9];
 #pragma unroll
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(PW_CQ * PW_LANES) void pool_wgrad_t_kernel(const op
         noff[yy * 3 + xx] = (yi >= 0 && yi < g.Hh && xi >= 0 && xi < g.Ww) ? yi * g.Ww + xi : -1;
       }
     const op_t* xb = qkv + (long)b * L * g.ld + g.col0 + h * HD + c0;
-    const op_t* db = dc + (bh * (Lo + 1) + pos) * HD + c0;
+    const op_t* db = dc + ((long)bh * (Lo + 1) + pos) * HD + c0;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 dP = zero, dC = ld4bf(db), dN = g.T > 1 ? ld4bf(db + (long)HoWo * HD) : zero;   // dc of output frames ti-1, ti, ti+1
     // two frames per iteration: 18 neighbour loads (+ the two dc rows that come into reach) in flight instead of 9 -- at 2 waves
@@ -933,17 +933,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   const int c4n = g.C >> 2;
   const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
   const long rows = g.B * Lo + g.B;
-  const long total = rows * c4n;
+  const unsigned total = (unsigned)(rows * c4n);               // < 2^31 (checked by the launcher): 32-bit index arithmetic
   const int pad = g.k / 2;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c4 = (int)(idx % c4n);
-    const long row = idx / c4n;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const int c4 = (int)(idx % (unsigned)c4n);
+    const long row = idx / (unsigned)c4n;
     f32x4 m;
     if (row >= g.B * Lo) {
       m = *reinterpret_cast<const f32x4*>(x + (g.B * L + (row - g.B * Lo)) * g.ldi + c4 * 4);
     } else {
-      const int wo = (int)(row % g.Wo), ho = (int)((row / g.Wo) % g.Ho);
-      const long bt = row / ((long)g.Wo * g.Ho);       // b*T + t
+      const unsigned r32 = (unsigned)row;
+      const int wo = (int)(r32 % (unsigned)g.Wo), ho = (int)((r32 / (unsigned)g.Wo) % (unsigned)g.Ho);
+      const long bt = r32 / (unsigned)(g.Wo * g.Ho);   // b*T + t
       m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       int arg[4] = {-1, -1, -1, -1};
       for (int yy = 0; yy < g.k; ++yy) {
@@ -977,18 +978,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   const int c4n = g.C >> 2;
   const long Lo = (long)g.T * g.Ho * g.Wo, L = (long)g.T * g.H * g.W;
   const long rows = g.B * L + g.B;
-  const long total = rows * c4n;
+  const unsigned total = (unsigned)(rows * c4n);               // < 2^31 (checked by the launcher): 32-bit index arithmetic
   const int pad = g.k / 2;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % c4n) * 4;
-    const long row = idx / c4n;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const int c = (int)(idx % (unsigned)c4n) * 4;
+    const long row = idx / (unsigned)c4n;
     if (row >= g.B * L) {
       *reinterpret_cast<f32x4*>(dx + row * g.ldi + c) =
           *reinterpret_cast<const f32x4*>(dy + (g.B * Lo + (row - g.B * L)) * g.ldo + c);
       continue;
     }
-    const int xi = (int)(row % g.W), yi = (int)((row / g.W) % g.H);
-    const long bt = row / ((long)g.W * g.H);
+    const unsigned r32 = (unsigned)row;
+    const int xi = (int)(r32 % (unsigned)g.W), yi = (int)((r32 / (unsigned)g.W) % (unsigned)g.H);
+    const long bt = r32 / (unsigned)(g.W * g.H);
     const int me = yi * g.W + xi;
     int ho0 = (yi + pad - g.k + 1 + g.s - 1) / g.s, ho1 = (yi + pad) / g.s;     // windows with yi in [ho*s-pad, ho*s-pad+k-1]
     int wo0 = (xi + pad - g.k + 1 + g.s - 1) / g.s, wo1 = (xi + pad) / g.s;
@@ -1266,6 +1268,7 @@ extern "C" int pvrl_mvit_maxpool_fwd(const float* x, int64_t ldi, int64_t B, int
   MaxPoolGeom g;
   if (!x || !y || maxpool_geom(g, B, T, H, W, s, C, ldi, ldo)) return PVRL_EINVAL;
   const long total = ((long)B * T * g.Ho * g.Wo + B) * (C >> 2);
+  if (total >= (1L << 31) - (1L << 24)) return PVRL_EINVAL;          // 32-bit index arithmetic in the kernel
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, g, y,
                      (unsigned char*)argmax);
   PVRL_LAUNCH_CHECK();
@@ -1280,6 +1283,7 @@ extern "C" int pvrl_mvit_maxpool_bwd(const float* x, int64_t ldi, const float* d
   //  memset node in a captured HIP graph did not re-zero the buffer on replay -- ROCm 7.2 -- so gradients accumulated
   //  across replays; nothing on a captured path uses hipMemset* any more.)
   const long total = ((long)B * T * H * W + B) * (C >> 2);
+  if (total >= (1L << 31) - (1L << 24)) return PVRL_EINVAL;          // 32-bit index arithmetic in the kernel
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, g, dx,
                      (const unsigned char*)argmax);
   PVRL_LAUNCH_CHECK();

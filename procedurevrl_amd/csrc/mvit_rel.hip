@@ -154,12 +154,12 @@ __global__ __launch_bounds__(TAB_LDS ? 1024 : 256) void rel_bwd_q_kernel(const f
   }
   const int J = g.kh + g.kw + g.kt;
   const int Lq = g.qt * g.qh * g.qw;
-  const long total = (long)g.BH * Lq * TPQ;
-  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
+  const unsigned total = (unsigned)((long)g.BH * Lq * TPQ);          // < 2^31 (checked by the launcher): 32-bit index arithmetic
+  for (unsigned idx = blockIdx.x * NT + threadIdx.x; idx < total; idx += gridDim.x * NT) {
     const int c = (int)(idx % TPQ) * CPT;
     const long bq = idx / TPQ;
-    const int q = (int)(bq % Lq);
-    const long bh = bq / Lq;
+    const int q = (int)((unsigned)bq % (unsigned)Lq);
+    const long bh = (unsigned)bq / (unsigned)Lq;
     const int x = q % g.qw, y = (q / g.qw) % g.qh, t = q / (g.qw * g.qh);
     const float* d = drel + bq * J;
     f32x4 a[NV];
@@ -393,6 +393,7 @@ extern "C" int pvrl_mvit_rel_bwd(const float* drel, const void* Q, void* dQ, int
   // 12 channels per thread = 8 lanes per query (with per-thread d rel / index loads: 4 / 8 / 16 / 32 channels measured
   // 2.4 / 1.9 / 2.8 / 4.2 ms per MViTv2-S step)
   const long nthr = (long)BH * qt * qh * qw * (HD / 12);
+  if (nthr >= (1L << 31) - (1L << 20)) return PVRL_EINVAL;          // 32-bit index arithmetic in rel_bwd_q_kernel
   static const int relq_lds = [] { const char* e = getenv("PVRL_RELQ_LDS"); return e ? (e[0] != '0') : 1; }();   // 0: A/B runs
   if (relq_lds && nrows_h + nrows_w + nrows_t <= RELQ_MAXROWS && qh * kh <= RELQ_MAXIDX && qw * kw <= RELQ_MAXIDX && qt * kt <= RELQ_MAXIDX &&
       ((uintptr_t)Rh % 16) == 0 && ((uintptr_t)Rw % 16) == 0 && ((uintptr_t)Rt % 16) == 0) {
