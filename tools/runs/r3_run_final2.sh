@@ -8,4 +8,4 @@ cd $R
 python tools/timeline.py $(find gpurun_out/prof_r3_mvit_trace -name "*kernel_trace.csv" | head -1) > gpurun_out/r3_timeline_mvit.txt 2>&1
 find gpurun_out/prof_r3_mvit_trace -name "*.csv" -size +20M -delete
 python tools/probe/mvit_gemm_times.py 2>&1 | grep -v amdgpu > gpurun_out/r3_final_mvit_shapes.txt
-tools/r3_run_full.sh
+tools/runs/r3_run_full.sh
