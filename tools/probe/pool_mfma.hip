@@ -13,8 +13,12 @@
 // diagonal operands) leaves neither deeper prefetch nor more than 12 waves per CU to cover it; the VALU kernel is issue-bound
 // (tools/pmc_pool.sh: every wave waits 60 % of its cycles while its SIMD's issue slots are ~95 % used by the 4-5 resident waves)
 // but keeps 16-20 waves per CU.  Halving the MFMA time (v1 -> v2) and halving the load segment size changed nothing: neither pipe
-// nor the texture path is the limit.  The form that would win stages the input rows of a tile in LDS with LDS-DMA several frames
-// ahead (no VGPRs for data in flight) and reads the B operands with ds_read_b128; not built.
+// nor the texture path is the limit.  Per frame a wave runs one dependent chain -- loads -> 15 MFMAs (five deep per accumulator) ->
+// accumulator read -> two cross-lane reductions -> LDS exchange + barrier -> rsqrt -> convert -> stores -- of ~2,000 cycles with ~500 cycles
+// of issue in it; it takes 8+ waves per SIMD (or several tiles per wave) to fill that, and the diagonal operands alone cap the kernel at 3.
+// Building the operands on the fly from 8 VGPRs of packed weights (5 VALU per MFMA) frees the registers but costs 75 VALU per frame:
+// ~2.1 issue cycles per output against the VALU kernel's 2.75 -- not worth a second kernel family.  Staging the input rows in LDS with
+// LDS-DMA several frames ahead would fix the memory side only.
 
 // ---- Round 3: the depthwise convolution on the matrix pipe ------------------------------------------------------------------------
 // PMC (tools/pmc_pool.sh, block 4): the VALU forms above are instruction-issue-bound -- 2,590 VALU instructions per wave for 3,072
