@@ -322,6 +322,11 @@ int pvrl_comm_unique_id(void* id128);
 int pvrl_comm_init(void** comm, int world, int rank, const void* id128);
 int pvrl_comm_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int pvrl_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+/* rank r receives sum over ranks of send[r * n_per_rank, (r + 1) * n_per_rank) in recv (recv may be the caller's own shard of
+ * send).  reducescatter + allgather of the reduced shards = the gradient all-reduce as two direct exchanges over all 7 xGMI
+ * links of a fully-connected 8-GPU node (procedurevrl_amd/distributed.py GradReducer, PVRL_GRAD_COLL=rsag) in place of the
+ * bucketed ring all-reduce of lib/models/build.py:49-53. */
+int pvrl_comm_reducescatter_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
 int pvrl_comm_destroy(void* comm);
 
 #ifdef __cplusplus

@@ -20,6 +20,7 @@ struct Rccl {
   int (*CommDestroy)(rcclComm_t);
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
   int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
   bool ok;
 };
 Rccl* rccl() {
@@ -38,7 +39,8 @@ Rccl* rccl() {
     x.CommDestroy = (int (*)(rcclComm_t))dlsym(h, "ncclCommDestroy");
     x.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(h, "ncclAllReduce");
     x.AllGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))dlsym(h, "ncclAllGather");
-    x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather;
+    x.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(h, "ncclReduceScatter");
+    x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather && x.ReduceScatter;
     return x;
   }();
   return r.ok ? &r : nullptr;
@@ -82,6 +84,18 @@ extern "C" int pvrl_comm_allgather(void* comm, const void* send, void* recv, int
   if (!comm || !send || !recv || bytes_per_rank < 0) return PVRL_EINVAL;
   if (bytes_per_rank == 0) return PVRL_OK;
   return r->AllGather(send, recv, (size_t)bytes_per_rank, kNcclInt8, comm, (hipStream_t)stream) == 0 ? PVRL_OK : PVRL_ECOMM;
+}
+
+// Sum-reduce `world` equal shards: rank r receives the sum over ranks of send[r * n_per_rank, (r + 1) * n_per_rank) in recv.
+// With pvrl_comm_allgather of the reduced shards this is the two-step gradient all-reduce of SURVEY section 5 / 8e for a
+// fully-connected xGMI node: every rank talks to its 7 peers directly (payload (W - 1) / W of the buffer per step over 7
+// links) instead of pushing the whole buffer around a ring; recv may alias the caller's own shard of send (in place).
+extern "C" int pvrl_comm_reducescatter_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream) {
+  Rccl* r = rccl();
+  if (!r) return PVRL_ECOMM;
+  if (!comm || ((!send || !recv) && n_per_rank > 0) || n_per_rank < 0) return PVRL_EINVAL;
+  if (n_per_rank == 0) return PVRL_OK;
+  return r->ReduceScatter(send, recv, (size_t)n_per_rank, kNcclFloat32, kNcclSum, comm, (hipStream_t)stream) == 0 ? PVRL_OK : PVRL_ECOMM;
 }
 
 extern "C" int pvrl_comm_destroy(void* comm) {

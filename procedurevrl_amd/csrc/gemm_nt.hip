@@ -2,6 +2,7 @@
 // gemm_nt_core.h (shared with the measured-and-rejected variants kept under tools/probe/, which are NOT part of this library).
 #include <cstdlib>
 #include "gemm_nt_core.h"
+#include "gemm_nt8_core.h"
 
 namespace {
 
@@ -146,21 +147,15 @@ int nt_wide_enabled() {
   return on;
 }
 
-#if PVRL_NT_PERSIST_BUILD
-// probe builds only (gemm_nt_core.h, "MEASURED AND NOT SHIPPED"): PVRL_NT_PERSIST = bit mask over the epilogue codes whose 256x256
-// shapes take the persistent kernel; read once
-#ifndef PVRL_NT_PERSIST_DEFAULT
-#define PVRL_NT_PERSIST_DEFAULT 0
-#endif
-int nt_persist_mask() {
-  static int mask = -1;
-  if (mask < 0) {
-    const char* e = getenv("PVRL_NT_PERSIST");
-    mask = e ? (int)strtol(e, nullptr, 0) : PVRL_NT_PERSIST_DEFAULT;
+// PVRL_NT8=0 sends the 256x256 shapes back to the 16-wave one-tile kernel (A/B runs, tools/bench_kernels.py); read once
+int nt8_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_NT8");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
   }
-  return mask;
+  return on;
 }
-#endif
 
 // PVRL_NT_TILE=22|42|44|26|25 forces a tile shape where it is legal for the problem (shape sweeps: tools/probe/mvit_gemm_times.py); read once
 int nt_forced_tile() {
@@ -185,9 +180,8 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
   }
   if (nt_wide_enabled() && p.N == 768 && p.M >= 4096 && p.M < 20000) return launch_tile<EPI, 2, 6>(p, s);   // MViT stage 4 (M = 12,576): 99 tiles of 128 x 384 x 2 fill 198 CUs; 256 x 256 tiles 150 (-10 %)
   if (p.M >= 4096 && p.N % 256 == 0) {
-#if PVRL_NT_PERSIST_BUILD
-    if ((nt_persist_mask() >> EPI) & 1) return launch_pers<EPI>(p, s);
-#endif
+    // persistent 8-wave ping-pong kernel (gemm_nt8_core.h); its load stream runs two K-tiles ahead, so K >= 128
+    if (nt8_enabled() && p.K >= 2 * BK) return launch_nt8<EPI>(p, s);
     return launch_tile<EPI, 4, 4>(p, s);
   }
   // N = 384 / 1152 and 640 at M >= 100k rows (MViTv2-S stages 1-2): one 128 x 384 / 128 x 320 tile row instead of three / five 128 x 128

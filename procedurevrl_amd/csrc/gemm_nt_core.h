@@ -96,36 +96,37 @@ template <int AUX, typename T> __device__ __forceinline__ T bld16(rsrc_t r, unsi
   return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
 }
 
-template <int EPI>
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane,
-                                            const float* bias_lds = nullptr) {
-  // bias_lds (persistent kernel): the tile's 256 bias values staged in LDS by the LDS-DMA that brought the tile's first stage --
-  // no global load, hence no wait on the vector-memory queue, stands between the last MFMA and the first store
+// The epilogue of ONE 64-row x 64-column accumulator block acc[mt][nt] (4 x 4 MFMA tiles of 16 x 16, operands swapped: a lane owns
+// row `rb + 16 mt + (lane & 15)` of the tile and, per column group c = nt >> 1, the 8 consecutive columns `cb[c] + 8 (lane >> 4) + ...`).
+//   rb      first row of the block inside the tile
+//   c0, c1  first column (inside the tile) of the block's two 32-column groups: wn * 64, wn * 64 + 32 for the 16-wave kernel;
+//           32 wn and 128 + 32 wn for the 8-wave kernel, whose wave columns are split over the two W half-tiles
+//   BATCH   row tiles whose residual / stored pre-activation loads go out together (one memory round trip per batch)
+template <int EPI, int BATCH = 2>
+__device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int rb, int c0, int c1, int lane) {
   constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
   constexpr int ST = PVRL_NT_ST_AUX, LD = PVRL_NT_LD_AUX;
-  // ---- epilogue ----
+  static_assert(BATCH == 1 || BATCH == 2 || BATCH == 4, "row tiles per load batch");
   const int q = lane >> 4, i = lane & 15;
-  const int nw0 = n0 + wn * 64;
-  const int rows = max(0, min(1024, p.M - m0));    // rows of the matrices from the tile's first row on (any bound >= the tile height that keeps the byte count in 31 bits)
+  const int ncol[2] = {n0 + c0 + 8 * q, n0 + c1 + 8 * q};   // this lane's first column of each 32-column group
+  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(1024, p.M - m0)));    // rows of the matrices from the tile's first row on (any bound >= the tile height that keeps the byte count in 31 bits)
   if constexpr (F32OUT) {
-    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
+    // lane holds, for c = 0,1: columns ncol[c] + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
     f32x4 bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      bv[nt] = !p.bias ? (f32x4){0.f, 0.f, 0.f, 0.f}
-               : bias_lds ? *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1))
-                          : *reinterpret_cast<const f32x4*>(p.bias + nw0 + 32 * (nt >> 1) + 8 * q + 4 * (nt & 1));
+      bv[nt] = !p.bias ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.bias + ncol[nt >> 1] + 4 * (nt & 1));
     // Per-row factors (DropPath) and the second bias are fetched HERE, before the first store: a load issued between the
     // stores is followed by s_waitcnt vmcnt(0), and on gfx9 that also waits for every earlier store to be acknowledged by
     // L2 -- four (rowscale) to sixteen (bias2) serial store round trips per thread.  bias2 has no 16 spare registers in the
-    // 128-VGPR budget of the 16-wave tile: each lane keeps ONE column of the wave's 64 and the others come by ds_bpermute.
+    // 128-VGPR budget of the 16-wave tile: each lane keeps ONE column of the block's 64 and the others come by ds_bpermute.
     float rs4[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + wm * 64 + mt * 16 + i, p.M - 1)] : 1.f;
+    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + rb + mt * 16 + i, p.M - 1)] : 1.f;
     float b2lane = 0.f;
     if constexpr (EPI == PVRL_EPI_RESID_F32) {
       if (p.bias2) {
-        b2lane = p.bias2[nw0 + lane];
+        b2lane = p.bias2[n0 + (lane < 32 ? c0 + lane : c1 + lane - 32)];
         if (!p.rowscale) {                 // no row factor: rs * (acc + bias) + bias2 = acc + (bias + bias2)
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
@@ -136,40 +137,38 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     }
     const bool b2_late = EPI == PVRL_EPI_RESID_F32 && p.bias2 && p.rowscale;
     const rsrc_t ro = tile_rsrc(p.out0, m0, p.ld0, 4, rows);
-    const unsigned ocol = (unsigned)(nw0 + 8 * q) * 4u;
     // the residual: rows of the tile (streamed once: LD policy), or rows modulo aux_rowmod of a small table every clip
     // re-reads (pos / time embedding prologue: default policy)
     const bool tab = EPI == PVRL_EPI_RESID_F32 && p.aux_rowmod != 0;
     const rsrc_t ra = EPI == PVRL_EPI_RESID_F32 ? (tab ? tile_rsrc(p.aux, 0, p.aux_ld, 4, p.aux_rowmod) : tile_rsrc(p.aux, m0, p.aux_ld, 4, rows)) : ro;
     // (Measured and rejected: finishing all 16 tiles in place and storing last, so that the second half's residual loads are
     //  not queued behind the first half's stores: -0.4 % on the step -- the early stores start the write traffic sooner.)
-    // The residual loads of TWO row tiles (32 registers, freed by the MFMA fragments) go out together, twice: two memory
-    // round trips per wave instead of four dependent ones (all 16 at once would spill).  With every CU in its epilogue at
-    // the same time the loaded latency of a round trip is microseconds.
+    // The residual loads of BATCH row tiles (16 registers each, freed by the MFMA fragments) go out together: 4 / BATCH memory
+    // round trips per wave instead of four dependent ones.  With every CU in its epilogue at the same time the loaded latency of
+    // a round trip is microseconds.
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x4 rv[2][4];
+    for (int bt = 0; bt < 4 / BATCH; ++bt) {
+      f32x4 rv[BATCH][4];
       if constexpr (EPI == PVRL_EPI_RESID_F32) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ml = wm * 64 + (2 * half + h) * 16 + i;                     // row inside the tile
+        for (int h = 0; h < BATCH; ++h) {
+          const int ml = rb + (BATCH * bt + h) * 16 + i;                        // row inside the tile
           const int mr = tab ? ((min(m0 + ml, p.M - 1) + p.m_off) % p.aux_rowmod) : ml;
-          const unsigned ab = (unsigned)mr * (unsigned)p.aux_ld * 4u + ocol;
+          const unsigned ab = (unsigned)mr * (unsigned)p.aux_ld * 4u;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const unsigned off = ab + (unsigned)(32 * (nt >> 1) + 4 * (nt & 1)) * 4u;
+            const unsigned off = ab + (unsigned)(ncol[nt >> 1] + 4 * (nt & 1)) * 4u;
             rv[h][nt] = tab ? bld16<0, f32x4>(ra, off) : bld16<LD, f32x4>(ra, off);
           }
         }
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int mt = 2 * half + h;
+      for (int h = 0; h < BATCH; ++h) {
+        const int mt = BATCH * bt + h;
         const float rs = rs4[mt];
-        const unsigned ob = (unsigned)(wm * 64 + mt * 16 + i) * (unsigned)p.ld0 * 4u + ocol;
+        const unsigned ob = (unsigned)(rb + mt * 16 + i) * (unsigned)p.ld0 * 4u;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const int off = 32 * (nt >> 1) + 4 * (nt & 1);
           f32x4 ov;
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov[e] = rs * (acc[mt][nt][e] + bv[nt][e]);
@@ -177,45 +176,43 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
             ov += rv[h][nt];
             if (b2_late) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ov[e] += __shfl(b2lane, 8 * q + off + e, 64);
+              for (int e = 0; e < 4; ++e) ov[e] += __shfl(b2lane, 32 * (nt >> 1) + 8 * q + 4 * (nt & 1) + e, 64);
             }
           }
-          bst16<ST>(ro, ob + (unsigned)off * 4u, ov);                          // rows past M: dropped by the bounds check
+          bst16<ST>(ro, ob + (unsigned)(ncol[nt >> 1] + 4 * (nt & 1)) * 4u, ov);   // rows past M: dropped by the bounds check
         }
       }
     }
   } else {
-    // lane holds, for c = 0,1: columns nw0 + 32c + 8q + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
+    // lane holds, for c = 0,1: columns ncol[c] + (0..7)  (tile 2c -> +0..3, tile 2c+1 -> +4..7)
     float bv[2][8];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        bv[c][e] = !p.bias ? 0.f : bias_lds ? bias_lds[wn * 64 + 32 * c + 8 * q + e] : p.bias[nw0 + 32 * c + 8 * q + e];
+      for (int e = 0; e < 8; ++e) bv[c][e] = !p.bias ? 0.f : p.bias[ncol[c] + e];
     float rs4[4];                      // before the first store (see above)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + wm * 64 + mt * 16 + i, p.M - 1)] : 1.f;
+    for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + rb + mt * 16 + i, p.M - 1)] : 1.f;
     constexpr bool TWO = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
     constexpr bool DACT = EPI == PVRL_EPI_DGELU || EPI == PVRL_EPI_DQGELU;
     const rsrc_t r0 = tile_rsrc(p.out0, m0, p.ld0, 2, rows);
     const rsrc_t r1 = TWO ? tile_rsrc(p.out1, m0, p.ld1, 2, rows) : r0;
     const rsrc_t ra = DACT ? tile_rsrc(p.aux, m0, p.aux_ld, 2, rows) : r0;
-    const unsigned ccol = (unsigned)(nw0 + 8 * q) * 2u;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      opx8 uv[2][2];
-      if constexpr (DACT) {   // the stored pre-activations of two row tiles: one round trip
+    for (int bt = 0; bt < 4 / BATCH; ++bt) {
+      opx8 uv[BATCH][2];
+      if constexpr (DACT) {   // the stored pre-activations of BATCH row tiles: one round trip
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned ab = (unsigned)(wm * 64 + (2 * half + h) * 16 + i) * (unsigned)p.aux_ld * 2u + ccol;
+        for (int h = 0; h < BATCH; ++h) {
+          const unsigned ab = (unsigned)(rb + (BATCH * bt + h) * 16 + i) * (unsigned)p.aux_ld * 2u;
 #pragma unroll
-          for (int c = 0; c < 2; ++c) uv[h][c] = bld16<LD, opx8>(ra, ab + 64u * c);
+          for (int c = 0; c < 2; ++c) uv[h][c] = bld16<LD, opx8>(ra, ab + (unsigned)ncol[c] * 2u);
         }
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int mt = 2 * half + h;
-        const unsigned ml = (unsigned)(wm * 64 + mt * 16 + i);
+      for (int h = 0; h < BATCH; ++h) {
+        const int mt = BATCH * bt + h;
+        const unsigned ml = (unsigned)(rb + mt * 16 + i);
         const float rs = rs4[mt];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -225,7 +222,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
             v[e] = acc[mt][2 * c][e] + bv[c][e];
             v[4 + e] = acc[mt][2 * c + 1][e] + bv[c][4 + e];
           }
-          const unsigned o0off = ml * (unsigned)p.ld0 * 2u + ccol + 64u * c;
+          const unsigned o0off = ml * (unsigned)p.ld0 * 2u + (unsigned)ncol[c] * 2u;
           if constexpr (EPI == PVRL_EPI_BF16) {
             opx8 o0;
 #pragma unroll
@@ -239,7 +236,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
               g0[e] = (op_t)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
             }
             bst16<ST>(r0, o0off, u0);
-            bst16<ST>(r1, ml * (unsigned)p.ld1 * 2u + ccol + 64u * c, g0);
+            bst16<ST>(r1, ml * (unsigned)p.ld1 * 2u + (unsigned)ncol[c] * 2u, g0);
           } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
             const opx8 ua = uv[h][c];
             opx8 o0;
@@ -254,6 +251,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
       }
     }
   }
+}
+
+// the 16-wave kernels' form: wave (wm, wn) owns rows [64 wm, +64) x columns [64 wn, +64) of its tile
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+  nt_epilogue_at<EPI, 2>(p, acc, m0, n0, wm * 64, wn * 64, wn * 64 + 32, lane);
 }
 
 // ---- the ragged last round (256x256 tiles only) --------------------------------------------------------------------
@@ -464,309 +467,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   if (!TAILS || active) nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
-#ifndef PVRL_NT_PERSIST_BUILD
-#define PVRL_NT_PERSIST_BUILD 0
-#endif
-#if PVRL_NT_PERSIST_BUILD
-// ---------------------------------------------------------------------------------------------------------------------
-// MEASURED AND NOT SHIPPED (round 3; compiled only with -DPVRL_NT_PERSIST_BUILD=1, tools/probe/nt_cache_policy.py): the persistent
-// form below is correct (kernel + end-to-end parity suites, 12-launch bit-compare stress per shape) and SLOWER than the one-tile
-// kernel: per launch at M = 50,208 (interleaved, us) fc1 GELU 340.7 -> 393.3, dGELU 334.2 -> 472.5, qkv bf16 186.4 -> 209.1, dfc1 bf16
-// 207.7 -> 224.6, proj residual 114.7 -> 156.2, fc2 residual 247.6 -> 306.7; training step 587-590 -> 548-551 clips/s with every
-// epilogue persistent, 587.7 with the bf16 epilogue only (profiles/r3_nt_persistent.txt).  Cause: at 16 waves the kernel has 128
-// VGPRs; the loop-carried state (however small: lane index, two staging offsets, two fragment offsets) tips the allocator into
-// scratch (44-224 bytes per lane), and EVERY scratch reload is followed by s_waitcnt vmcnt(0), which drains the prefetch LDS-DMA
-// and the epilogue's stores -- exactly the two overlaps the design exists for.  With the K loop spill-free (bf16 epilogue) the
-// kernel is on par (K = 3072: 260 vs 259 us per 3 rounds), with spills in the epilogue it loses 10-40 %.  The register budget, not the
-// idea, is the obstacle: an 8-wave form (128x64 wave blocks, 256 VGPRs) is the variant that could carry the state; not built.
-// PERSISTENT 256x256 kernel (round 3).  One workgroup per CU walks its XCD's list of tiles (then sub-tiles) with the stride of
-// the CUs per XCD -- the same order the hardware dispatches one-tile workgroups in -- so that the SEAM between two tiles costs
-// nothing but the epilogue's own instructions:
-//   * the next tile's first stage (and its 256 bias values) go out as LDS-DMA at the top of the current tile's LAST K step:
-//     in flight under that step's MFMAs and the whole epilogue (a one-tile workgroup pays the fill, 64 KiB per CU with every
-//     CU asking at once, ~2-3 us, in front of every tile);
-//   * the epilogue's stores drain under the next tile's first K steps: every LDS-DMA is raw ISA with COUNTED waits, so the
-//     first barrier of a prefetched tile waits with vmcnt(<stores of the epilogue>) -- the DMA is older than the stores -- instead
-//     of the vmcnt(0) a compiler-managed __syncthreads() needs (a one-tile workgroup holds its CU until every store is acknowledged);
-//   * no workgroup launch / LDS hand-over between tiles.
-// Measured per-tile overhead of the one-tile kernel: 28.7 us per round at K = 768 against 20.6 us of MFMA time at the sustained
-// rate (time vs M, profiles/r3_nt_tail_subtiles.txt).  Round 2's persistent probe (tools/probe, tile 14) kept the staging
-// pointers and fragment offsets alive across the epilogue and spilled 116-196 bytes per lane; here they are recomputed per tile
-// from an opaque copy of the lane index, and the bias tile lives in LDS, so nothing but the lane index crosses the seam.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int EPI> constexpr int nt_epi_stores() {      // store instructions per wave in nt_epilogue (every row tile issues them:
-  return (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32 || EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) ? 16 : 8;   // bounds-checked, no branches)
-}
-
-template <int EPI>
-__global__ __launch_bounds__(1024) void gemm_nt_pers_kernel(GemmNT p) {
-  constexpr int WN = 4, BM = 256, BN = 256, NW = 16, PER = 4;
-  constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
-  constexpr int XBYTES = BM * BK * 2, STAGE = 2 * XBYTES;          // 64 KiB per stage
-  constexpr int SUB_STAGE = 48 * 1024;
-  constexpr int BIAS_OFF = 2 * STAGE;                              // two 1 KiB bias tiles behind the two full-tile slots
-  constexpr int NST = nt_epi_stores<EPI>();
-  __shared__ __attribute__((aligned(16))) char smem[3 * SUB_STAGE];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-  const int GM = p.gm;
-  const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-  const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
-  const int cm = qm + (xcd < rm ? 1 : 0);                   // panels owned by this XCD
-  const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
-  const NtTail plan = nt_tail_plan(cm, p.tiles_n, p.cus, p.tails);
-  const int gsz = GM * p.tiles_n;
-  const int nk = p.K / BK;
-  // list entry j -> tile (tm, tn), split factor f, sub-tile index
-  auto decode = [&](int j, int& tm, int& tn, int& f, int& sub) {
-    f = 1; sub = 0;
-    if (j >= plan.full) {
-      const int s = j - plan.full;
-      f = plan.f;
-      j = plan.full + s / f;
-      sub = s - (s / f) * f;
-    }
-    const int g = j / gsz, r = j - g * gsz;
-    const int gm = min(GM, cm - g * GM);
-    tn = r / gm;
-    tm = mbase + g * GM + (r - tn * gm);
-  };
-  // The epilogue's arguments (output / residual pointers, leading dimensions ...: ~24 scalar registers) are RE-READ from the
-  // kernel-argument segment at every epilogue through an opaque pointer, so they are not live across the K loops -- kept
-  // resident they push the loop-carried scalars into v_writelane spills and, through those, vector registers into scratch.
-  auto epi_args = [&]() {
-    GemmNT t;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) unsigned* kernarg_t;
-    kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    unsigned* d = reinterpret_cast<unsigned*>(&t);
-#pragma unroll
-    for (int w = 0; w < (int)(sizeof(GemmNT) / 4); ++w) d[w] = ka[w];
-#else
-    t = p;
-#endif
-    return t;
-  };
-  int j = blockIdx.x >> 3;
-  if (j >= plan.nblk) return;
-  int tm, tn, f, sub;
-  decode(j, tm, tn, f, sub);
-  bool pre = false;          // the current entry's first stage (+ bias tile) is already in flight (issued at the previous seam)
-  int slot = 0, bpar = 0;    // ring slot / bias buffer of the current full tile
-
-  while (true) {
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));                          // opaque per tile: nothing derived from it is kept across the seam
-    const int bm = BM / f;
-    const int m0 = tm * BM + sub * bm, n0 = tn * BN;
-    const bool active = wm < 4 / f;
-    const int jn = j + stride;
-    const bool more = jn < plan.nblk;
-    int tmn = 0, tnn = 0, fn = 1, subn = 0;
-    if (more) decode(jn, tmn, tnn, fn, subn);
-    bool pre_next = false;
-    if (m0 < p.M) {                                         // (a sub-tile past the ragged end of the last panel: nothing to do)
-      // ---- staging: instruction `it` of a stage copies 8 tile rows (X rows first, then W rows) as
-      //      global_load_lds_dwordx4 <32-bit lane offset>, <uniform 64-bit base>: ONE offset register per instruction parity
-      //      (the chunk swizzle of row 8 it + lane / 8 depends on it & 1 only) instead of a 64-bit pointer per instruction.
-      //      Full tile: wave w issues it = 4 w .. 4 w + 3 (waves 0-7 bring X rows, 8-15 W rows); sub-tile: it = 16 e + w.
-      // lane byte offsets of this wave's LDS-DMA instructions.  Full tile, wave w: instructions 4 w .. 4 w + 3 = tile rows
-      // [32 (w & 7), + 32) of X (w < 8) or W.  The chunk swizzle of X has period 16 rows and W's differs by ^4 (= byte offset ^ 64)
-      // between rows r and r + 16, so TWO registers (instruction parity) serve the four instructions; +16 rows go to the uniform base.
-      unsigned loff[4];          // [0], [1]: full tiles (interior panels) and sub-tile e = 0, 1;  [2]: sub-tile e = 2
-      auto set_off = [&]() {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int row = 32 * (wave & 7) + 8 * e + (lane >> 3);      // row inside the operand tile
-          const int pc = lane & 7;
-          loff[e] = wave < 8 ? (unsigned)((8 * e + (lane >> 3)) * (int)p.lda + ((pc ^ swz_x(row)) << 3)) * 2u
-                             : (unsigned)((8 * e + (lane >> 3)) * (int)p.ldw + ((pc ^ swz_w<F32OUT>(row)) << 3)) * 2u;
-        }
-      };
-      auto stage_full = [&](int sl, int m0_, int n0_, int k0) {
-        const unsigned b = sbase + sl * STAGE + wave * (PER * 1024);
-        if (wave < 8 && m0_ + BM > p.M) {
-          // ragged last panel: rows past M re-read row M - 1 (never stored); lane offsets are unsigned, so they are taken
-          // relative to the (clamped) first row of the wave and computed here, per instruction
-          const int rb = min(m0_ + 32 * wave, p.M - 1);
-          const op_t* base = p.A + (long)rb * p.lda + k0;
-#pragma unroll
-          for (int e = 0; e < PER; ++e) {
-            const int row = 32 * wave + 8 * e + (lane >> 3);
-            const int d = min(m0_ + row, p.M - 1) - rb;
-            glds16_raw(base, (unsigned)(d * (int)p.lda + (((lane & 7) ^ swz_x(row)) << 3)) * 2u, b + e * 1024);
-          }
-          return;
-        }
-        const op_t* base = wave < 8 ? p.A + ((long)m0_ + 32 * wave) * p.lda + k0 : p.W + ((long)n0_ + 32 * (wave - 8)) * p.ldw + k0;
-        const long step = 16 * (wave < 8 ? p.lda : p.ldw);
-        const unsigned flip = wave < 8 ? 0u : 64u;             // W rows r + 16: chunk ^ 4 (16 ldw elements = a multiple of 128 bytes)
-#pragma unroll
-        for (int e = 0; e < PER; ++e) glds16_raw(base + (e >> 1) * step, (e >> 1) ? (loff[e & 1] ^ flip) : loff[e & 1], b + e * 1024);
-      };
-      auto bias_dma = [&](int bp, int n0_) {                // 256 floats = ONE 1 KiB LDS-DMA instruction (wave 0)
-        if (p.bias && wave == 0) glds16_raw(p.bias + n0_, (unsigned)lane * 16u, sbase + BIAS_OFF + bp * 1024);
-      };
-      // fragment offsets: row r of a tile sits at 128 r + 16 (chunk ^ swizzle(r)); both swizzles are periodic over the rows a
-      // lane reads (x: row + 16 t; w: rows of tile nt), so ONE register per operand and K half serves all four fragments
-      const int q = lane >> 4, i = lane & 15;
-      const int rx0 = wm * 64 + i, rw0 = wn * 64 + w_row<F32OUT>(0, i);
-      const int x0 = rx0 * 128 + ((q ^ swz_x(rx0)) << 4), w0 = rw0 * 128 + ((q ^ swz_w<F32OUT>(rw0)) << 4);
-      auto wofs = [](int t) { return (32 * (t >> 1) + 4 * (t & 1)) * 128; };     // w_row(t, i) - w_row(0, i) rows
-      f32x4 acc[4][4];
-      {
-        float z = 0.f;
-        asm volatile("" : "+v"(z));     // opaque zero: the compiler must not peel the first K step to fold C = 0 into its MFMAs
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){z, z, z, z};
-      }
-      auto kstep = [&](const char* bx, const char* bw) {
-        opx8 xf0[4], wf0[4], xf1[4], wf1[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          wf0[t] = *reinterpret_cast<const opx8*>(bw + w0 + wofs(t));
-          xf0[t] = *reinterpret_cast<const opx8*>(bx + x0 + t * 2048);
-        }
-        const int x1 = x0 ^ 64, w1 = w0 ^ 64;               // (two VALU per K step instead of two registers across the loops)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          wf1[t] = *reinterpret_cast<const opx8*>(bw + w1 + wofs(t));
-          xf1[t] = *reinterpret_cast<const opx8*>(bx + x1 + t * 2048);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[mt][nt] = MFMA_16x16x32(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[mt][nt] = MFMA_16x16x32(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      };
-
-      if (f == 1) {
-        set_off();
-        if (!pre) {
-          stage_full(slot, m0, n0, 0);
-          bias_dma(bpar, n0);
-        }
-        // stage 0 has landed: the only younger vector-memory operations of this wave are the previous epilogue's stores (a
-        // prefetched tile), which may keep draining
-        if (pre) {
-          if (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int kt = 0; kt < nk; ++kt) {
-          if (kt + 1 < nk) {
-            stage_full(slot ^ 1, m0, n0, (kt + 1) * BK);
-          } else if (more && fn == 1) {                     // the seam: the next full tile's first stage + bias tile
-            stage_full(slot ^ 1, tmn * BM, tnn * BN, 0);
-            bias_dma(bpar ^ 1, tnn * BN);
-            pre_next = true;
-          }
-          const char* bx = smem + slot * STAGE;
-          kstep(bx, bx + XBYTES);
-          slot ^= 1;
-          if (kt + 1 < nk) {                                // stage kt + 1 (issued a whole K step ago) has landed for every wave
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-          }
-        }
-        nt_epilogue<EPI>(epi_args(), acc, m0, n0, wm, wn, lane, reinterpret_cast<const float*>(smem + BIAS_OFF + bpar * 1024));
-        bpar ^= 1;
-      } else {
-        // sub-tile of the ragged last round (see gemm_nt_kernel): three 48 KiB slots over the whole LDS image -- every wave must
-        // be past its reads of the previous entry's ring and bias tile first
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // instruction it = 16 e + w copies tile rows 8 it .. 8 it + 7: X rows while it < bm / 8, W rows after; it & 1 = w & 1
-        const int xbytes = bm * BK * 2;
-        const int nx = bm / 8, ninst = nx + BN / 8;
-        int nv = 0;
-#pragma unroll
-        for (int e = 0; e < PER; ++e) nv += (e * NW + wave) < ninst ? 1 : 0;
-        // lane offsets of this wave's (up to) three instructions, fixed for the whole K loop; the chunk swizzles depend on it & 1 (X
-        // rows) / (it - nx) & 3 (W rows) only, i.e. on the wave
-#pragma unroll
-        for (int e = 0; e < PER - 1; ++e) {
-          const int it = e * NW + wave, pc = lane & 7;
-          if (it < nx) {
-            const int d = min(m0 + it * 8 + (lane >> 3), p.M - 1) - m0;
-            loff[e] = (unsigned)(d * (int)p.lda) * 2u + ((unsigned)(pc ^ swz_x((wave & 1) * 8 + (lane >> 3))) << 4);
-          } else {
-            loff[e] = (unsigned)((lane >> 3) * (int)p.ldw) * 2u + ((unsigned)(pc ^ swz_w<F32OUT>((wave & 3) * 8 + (lane >> 3))) << 4);
-          }
-        }
-        auto stage3 = [&](int kt) {
-          const unsigned b = sbase + (kt % 3) * SUB_STAGE;
-#pragma unroll
-          for (int e = 0; e < PER - 1; ++e) {               // 40 or 48 instructions per stage: e = 0 .. 2
-            const int it = e * NW + wave;
-            if (it < nx) glds16_raw(p.A + (long)m0 * p.lda + kt * BK, loff[e], b + it * 1024);
-            else if (it < ninst) glds16_raw(p.W + ((long)n0 + (it - nx) * 8) * p.ldw + kt * BK, loff[e], b + it * 1024);
-          }
-        };
-        stage3(0);
-        if (nk > 1) stage3(1);
-        for (int kt = 0; kt < nk; ++kt) {
-          if (kt + 1 < nk) {
-            if (nv >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (nv == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (kt + 2 < nk) stage3(kt + 2);
-          if (active) {
-            const char* bx = smem + (kt % 3) * SUB_STAGE;
-            kstep(bx, bx + xbytes);
-          }
-        }
-        if (active) nt_epilogue<EPI>(epi_args(), acc, m0, n0, wm, wn, lane);
-        slot = 0;                                           // (a full tile never follows a sub-tile; keep the state defined)
-      }
-    }
-    if (!more) break;
-    j = jn; tm = tmn; tn = tnn; f = fn; sub = subn;
-    pre = pre_next;
-  }
-}
-
-template <int EPI>
-int launch_pers(GemmNT p, hipStream_t s) {
-  p.tiles_n = p.N / 256;
-  p.tiles_m = cdiv(p.M, 256);
-  if (p.gm <= 0) p.gm = nt_gm_for(p.tiles_n);
-  const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
-  int nb = nt_tail_plan(qm + (rm ? 1 : 0), p.tiles_n, p.cus, p.tails).nblk;      // the longest per-XCD list
-  p.nwg = 8 * std::min(nb, p.cus);                                                  // one workgroup per CU
-  hipLaunchKernelGGL((gemm_nt_pers_kernel<EPI>), dim3(p.nwg), dim3(1024), 0, s, p);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
-}
-
-#endif  // PVRL_NT_PERSIST_BUILD
 
 template <int EPI, int WM, int WN>
 int launch_tile(GemmNT p, hipStream_t s) {

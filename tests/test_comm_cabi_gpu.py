@@ -28,8 +28,11 @@ def test_comm_world1_roundtrip():
         y = torch.empty(4096, device="cuda", dtype=torch.uint8)
         src = torch.randint(0, 255, (4096,), device="cuda", dtype=torch.uint8)
         L.call("pvrl_comm_allgather", comm, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(y.data_ptr()), 4096, stream)
+        z = torch.randn(1 << 16, device="cuda")
+        zr = torch.zeros_like(z)
+        L.call("pvrl_comm_reducescatter_f32", comm, ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(zr.data_ptr()), z.numel(), stream)
     st.synchronize()
-    assert torch.equal(x, want) and torch.equal(y, src)
+    assert torch.equal(x, want) and torch.equal(y, src) and torch.equal(z, zr)
     L.call("pvrl_comm_destroy", comm)
     # argument errors are status codes, not crashes
     with pytest.raises(Exception):
