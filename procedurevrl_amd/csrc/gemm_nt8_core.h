@@ -53,6 +53,18 @@ __host__ __device__ inline Nt8Plan nt8_plan(int cm, int tiles_n, int cus, int en
   return t;
 }
 
+// Probe builds only (-DPVRL_NT8_TRACE=1, tools/probe/nt8_ab.py trace): waves 0 and 4 of workgroup 8 stamp s_memtime at the four
+// seams of every phase of their first tile's first NT8_TRACE_KT K-tiles into spare LDS and dump it through GemmNT::bias2.
+#ifndef PVRL_NT8_TRACE
+#define PVRL_NT8_TRACE 0
+#endif
+// Probe builds only (tools/probe/nt8_ab.py ablate; results are garbage, only the time means something): bit 0 = no LDS-DMA,
+// bit 1 = no fragment reads, bit 2 = no MFMAs, bit 3 = no barrier behind the compute segments, bit 4 = no s_setprio, bit 5 = every K-tile
+// loads K offset 0 (the same 64 KB per tile: L2-hot), bit 6 = every tile loads tile (0, 0) as well (one 64 KB image for the whole chip)
+#ifndef PVRL_NT8_ABLATE
+#define PVRL_NT8_ABLATE 0
+#endif
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 // One 1 KiB LDS-DMA copy through a buffer descriptor: lane l's 16 bytes at r.base + soff + voff land at LDS byte lds + 16 l.
@@ -60,6 +72,8 @@ __host__ __device__ inline Nt8Plan nt8_plan(int cm, int tiles_n, int cus, int en
 // counts it nor waits for it.  (s_nop 4: a descriptor / offset register produced by v_readfirstlane needs five wait states before
 // a vector-memory instruction reads it; s_nop 0: M0 write -> LDS-DMA.  Nothing inside an asm string is padded by hipcc.)
 __device__ __forceinline__ void bdma16(rsrc_t r, unsigned voff, unsigned soff, unsigned lds) {
+  if (PVRL_NT8_ABLATE & 1) return;
+  if (PVRL_NT8_ABLATE & 32) soff = 0;
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :: "v"(voff), "s"(r), "s"(soff), "s"(lds) : "memory", "m0");
 }
@@ -72,6 +86,18 @@ __device__ __forceinline__ void bdma16(rsrc_t r, unsigned voff, unsigned soff, u
 #define PVRL_NT8_EB(EPI) ((EPI) == PVRL_EPI_RESID_F32 ? 2 : 4)
 #endif
 
+constexpr int NT8_TRACE_KT = 10;
+#if PVRL_NT8_TRACE
+#define NT8_STAMP(ph, k)                                                                                         \
+  do {                                                                                                           \
+    if (tracing && kt < NT8_TRACE_KT)                                                                            \
+      reinterpret_cast<unsigned long long*>(smem + 2 * NT8_BUF)[(wm * NT8_TRACE_KT + kt) * 16 + (ph) * 4 + (k)] = \
+          __builtin_readcyclecounter();                                                                          \
+  } while (0)
+#else
+#define NT8_STAMP(ph, k) do { } while (0)
+#endif
+
 #define NT8_BARRIER()                       \
   do {                                      \
     __builtin_amdgcn_sched_barrier(0);      \
@@ -79,16 +105,31 @@ __device__ __forceinline__ void bdma16(rsrc_t r, unsigned voff, unsigned soff, u
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
 // end of a memory segment: this wave's fragment reads have completed BEFORE the barrier (WAR rule above)
-#define NT8_MEM_END()                                     \
+#define NT8_MEM_END(ph)                                   \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    NT8_STAMP(ph, 1);                                     \
+    NT8_BARRIER();                                        \
+    NT8_STAMP(ph, 2);                                     \
+    if (!(PVRL_NT8_ABLATE & 16)) __builtin_amdgcn_s_setprio(1); \
+  } while (0)
+#define NT8_MEM_END_Q()                                   \
   do {                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     NT8_BARRIER();                                        \
     __builtin_amdgcn_s_setprio(1);                        \
   } while (0)
-#define NT8_CMP_END()                 \
+#define NT8_CMP_END_Q()               \
   do {                                \
     __builtin_amdgcn_s_setprio(0);    \
     NT8_BARRIER();                    \
+  } while (0)
+#define NT8_CMP_END(ph)                                          \
+  do {                                                           \
+    if (!(PVRL_NT8_ABLATE & 16)) __builtin_amdgcn_s_setprio(0);  \
+    NT8_STAMP(ph, 3);                                            \
+    if (!(PVRL_NT8_ABLATE & 8)) NT8_BARRIER();                   \
+    else __builtin_amdgcn_sched_barrier(0);                      \
   } while (0)
 
 template <int EPI>
@@ -98,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
   // store instructions per wave of one whole tile's epilogue (bounds-checked buffer stores, no branches: every lane of every wave
   // issues all of them; tests/test_nt8_isa.py counts them in the built library)
   constexpr int NST = (F32OUT || EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU) ? 32 : 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * NT8_BUF];
+  __shared__ __attribute__((aligned(16))) char smem[2 * NT8_BUF + (PVRL_NT8_TRACE ? 2 * NT8_TRACE_KT * 16 * 8 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -148,6 +189,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
   auto srdW = [&](int n0_) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)n0_ * p.ldw), 0, 256 * (int)p.ldw * 2, 0x00020000);
   };
+  auto issueA1 = [&](int h, int e, unsigned lb, rsrc_t r, unsigned soff) {      // instruction e of this wave's two of A half-tile h
+    bdma16(r, voffA[h][e], soff, lb + h * NT8_HALF + wave * 2048 + e * 1024);
+  };
+  auto issueW1 = [&](int c, int e, unsigned lb, rsrc_t r, unsigned soff) {
+    bdma16(r, voffW[e], soff + c * wstep, lb + (2 + c) * NT8_HALF + wave * 2048 + e * 1024);
+  };
   auto issueA = [&](int h, unsigned lb, rsrc_t r, unsigned soff) {
     bdma16(r, voffA[h][0], soff, lb + h * NT8_HALF + wave * 2048);
     bdma16(r, voffA[h][1], soff, lb + h * NT8_HALF + wave * 2048 + 1024);
@@ -157,8 +204,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
     bdma16(r, voffW[1], soff + c * wstep, lb + (2 + c) * NT8_HALF + wave * 2048 + 1024);
   };
 
-  opx8 ra[4][2], rb0[2][2], rb1[2][2];                      // fragments: [row tile][k half], [h][k half]
+  opx8 ra[4][2], rb0[2][2], rb1[2][2];                      // fragments: [row tile][k half], [h][k half] (rb0 / rb1: column group 0 / 1)
   f32x4 acc[2][4][4];                                       // [row half][row tile][nt = 2 c + h]
+  // ---- whole tiles: a phase is (row half mh, k half ks) = 4 x 4 accumulators x K = 32 ----
+  auto rdAk = [&](const char* buf, int mh, int ks) {        // 4 reads: the row half's 4 row tiles, k half ks
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (PVRL_NT8_ABLATE & 2) asm volatile("" : "+v"(ra[t][ks]));
+      else ra[t][ks] = *reinterpret_cast<const opx8*>(buf + mh * NT8_HALF + t * 2048 + (xb ^ (ks * 64)));
+    }
+  };
+  auto rdBk = [&](const char* buf, int ks) {                // 4 reads: both column groups, k half ks (kept for both row halves)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (PVRL_NT8_ABLATE & 2) {
+        asm volatile("" : "+v"(rb0[h][ks]), "+v"(rb1[h][ks]));
+      } else {
+        rb0[h][ks] = *reinterpret_cast<const opx8*>(buf + 2 * NT8_HALF + h * 512 + (wb ^ (ks * 64)));
+        rb1[h][ks] = *reinterpret_cast<const opx8*>(buf + 3 * NT8_HALF + h * 512 + (wb ^ (ks * 64)));
+      }
+    }
+  };
+  auto mmk = [&](f32x4 (&a)[4][4], int ks) {                // 16 MFMAs on 16 different accumulators
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (PVRL_NT8_ABLATE & 4) {
+          asm volatile("" :: "v"(rb0[h][ks]), "v"(rb1[h][ks]), "v"(ra[t][ks]));
+        } else {
+          a[t][h] = MFMA_16x16x32(rb0[h][ks], ra[t][ks], a[t][h], 0, 0, 0);
+          a[t][2 + h] = MFMA_16x16x32(rb1[h][ks], ra[t][ks], a[t][2 + h], 0, 0, 0);
+        }
+      }
+  };
+  // ---- half items: a phase is (column group c) x K = 64 of the upper row half ----
   auto rdA = [&](const char* buf, int mh) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -180,6 +260,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) a[t][2 * c + h] = MFMA_16x16x32(rb[h][ks], ra[t][ks], a[t][2 * c + h], 0, 0, 0);
   };
+  if (PVRL_NT8_ABLATE & 2) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ra[t][ks] = (opx8)(op_t)0.5f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { rb0[h][ks] = (opx8)(op_t)0.25f; rb1[h][ks] = (opx8)(op_t)0.125f; }
+  }
   auto zero_acc = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -189,6 +279,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
         for (int c = 0; c < 4; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
+#if PVRL_NT8_TRACE
+  bool tracing = blockIdx.x == 8 && (wave & 3) == 0;
+#endif
   int par = 0;            // ring slot of the current item's K-tile 0
   bool primed = false;    // K-tiles 0 and 1 of the current item are already in the ring (issued under the previous tile; 0 has landed)
 
@@ -201,64 +294,93 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
     const bool nxt = jn < plan.full;                        // the load stream continues into another whole tile
     int tmn = 0, tnn = 0;
     if (nxt) decode(jn, tmn, tnn);
-    rsrc_t lsA = srdA(m0, 256), lsW = srdW(n0);
-    if (!primed) {                                          // cold start: K-tiles 0 and 1, wait for 0
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const unsigned lb = sbase + ((par + kt) & 1) * NT8_BUF;
-        issueW(0, lb, lsW, kt * 128); issueA(0, lb, lsA, kt * 128);
-        issueW(1, lb, lsW, kt * 128); issueA(1, lb, lsA, kt * 128);
-      }
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    const rsrc_t cA = srdA((PVRL_NT8_ABLATE & 64) ? 0 : m0, 256), cW = srdW((PVRL_NT8_ABLATE & 64) ? 0 : n0);
+    const rsrc_t nA = nxt ? srdA(tmn * 256, 256) : cA, nW = nxt ? srdW(tnn * 256) : cW;
+    if (!primed) {                                          // cold start: K-tile 0, K-tile 1 without its A1; wait for K-tile 0
+      const unsigned l0 = sbase + par * NT8_BUF, l1 = sbase + (par ^ 1) * NT8_BUF;
+      issueW(0, l0, cW, 0); issueA(0, l0, cA, 0); issueW(1, l0, cW, 0); issueA(1, l0, cA, 0);
+      issueW(0, l1, cW, 128); issueA(0, l1, cA, 128); issueW(1, l1, cW, 128);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       NT8_BARRIER();
     }
     zero_acc();
     if (wm == 1) NT8_BARRIER();                             // G1 runs one barrier interval behind G0
+#if PVRL_NT8_TRACE
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (tracing) { tr_c0 = __builtin_readcyclecounter(); tr_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (int kt = 0; kt < nk; ++kt) {
-      bool ld_on = true;                                    // the load stream: K-tile kt + 2 of this tile, or kt + 2 - nk of the next
-      int lkt = kt + 2;
-      if (lkt >= nk) {
-        lkt -= nk;
-        if (!nxt) ld_on = false;
-        else if (lkt == 0) { lsA = srdA(tmn * 256, 256); lsW = srdW(tnn * 256); }
-      }
+      // The load stream, two cursors: the lower-row half-tile A1 of K-tile kt + 1 (its slot is free behind phase 3 of K-tile kt - 1)
+      // and A0 / B0 / B1 of K-tile kt + 2 (this K-tile's slot, free behind phase 1) -- of this tile or, past its end, of the next.
+      const int k1 = kt + 1, k2 = kt + 2;
+      const bool in1 = k1 < nk, in2 = k2 < nk;
+      const bool on1 = in1 || nxt, on2 = in2 || nxt;
+      const rsrc_t a1 = in1 ? cA : nA, a2 = in2 ? cA : nA, w2 = in2 ? cW : nW;
+      const unsigned so1 = (unsigned)(in1 ? k1 : k1 - nk) * 128u, so2 = (unsigned)(in2 ? k2 : k2 - nk) * 128u;
       const int cur = (par + kt) & 1;
       const char* rbuf = smem + cur * NT8_BUF;
-      const unsigned lb = sbase + cur * NT8_BUF;
-      const unsigned lso = (unsigned)lkt * 128u;
-      // ---- phase 0: quadrant (rows 0, cols 0) ----
-      rdA(rbuf, 0);
-      rdB(rbuf, 0, rb0);
-      NT8_MEM_END();
-      quad(acc[0], 0, rb0);
-      NT8_CMP_END();
-      // ---- phase 1: (rows 0, cols 1); A0 and B0 of this slot were last read in phase 0 -> re-stage ----
-      if (ld_on) { issueW(0, lb, lsW, lso); issueA(0, lb, lsA, lso); }
-      rdB(rbuf, 1, rb1);
-      NT8_MEM_END();
-      quad(acc[0], 1, rb1);
-      NT8_CMP_END();
-      // ---- phase 2: (rows 1, cols 1); B1 last read in phase 1 ----
-      if (ld_on) issueW(1, lb, lsW, lso);
-      rdA(rbuf, 1);
-      NT8_MEM_END();
-      quad(acc[1], 1, rb1);
-      NT8_CMP_END();
-      // ---- phase 3: (rows 1, cols 0); A1 last read in phase 2; the next K-tile must have landed behind this phase ----
-      if (ld_on) {
-        issueA(1, lb, lsA, lso);
-        // all but the 8 instructions of K-tile + 2: K-tile + 1 is in LDS.  In the first K-tile behind a seam the previous epilogue's
-        // NST stores sit between K-tile 1 (issued before them) and K-tile 2: they may keep draining (vmcnt retires in issue order)
-        if (primed && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NST) : "memory");
+      const unsigned lb = sbase + cur * NT8_BUF, lo = sbase + (cur ^ 1) * NT8_BUF;
+      const bool seam = primed && kt == 0;                  // the previous epilogue's NST stores sit in the queue behind the prefetch
+      // Every memory segment issues its fragment reads FIRST and the LDS-DMA behind them: a DMA instruction blocks its wave while the
+      // CU's address path takes the 1 KiB (16 cycles each, the group's four waves queue up), and the reads complete underneath.
+      // ---- phase 0: rows 0, k half 0 ----
+      NT8_STAMP(0, 0);
+      rdAk(rbuf, 0, 0);
+      rdBk(rbuf, 0);
+      if (on1) issueA1(1, 0, lo, a1, so1);
+      NT8_MEM_END(0);
+      mmk(acc[0], 0);
+      NT8_CMP_END(0);
+      // ---- phase 1: rows 0, k half 1; behind it this slot's A0 / B0 / B1 are free.  Waits for this K-tile's A1 (read in phase 2) ----
+      NT8_STAMP(1, 0);
+      rdAk(rbuf, 0, 1);
+      rdBk(rbuf, 1);
+      if (on1) {
+        issueA1(1, 1, lo, a1, so1);
+        // younger than this K-tile's A1: 3 + 3 instructions of phases 2 / 3 of the previous K-tile, 1 + 1 of this one
+        if (seam) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      NT8_MEM_END();
-      quad(acc[1], 0, rb0);
-      NT8_CMP_END();
+      NT8_MEM_END(1);
+      mmk(acc[0], 1);
+      NT8_CMP_END(1);
+      // ---- phase 2: rows 1, k half 0 ----
+      NT8_STAMP(2, 0);
+      rdAk(rbuf, 1, 0);
+      if (on2) { issueW1(0, 0, lb, w2, so2); issueW1(0, 1, lb, w2, so2); issueA1(0, 0, lb, a2, so2); }
+      NT8_MEM_END(2);
+      mmk(acc[1], 0);
+      NT8_CMP_END(2);
+      // ---- phase 3: rows 1, k half 1; behind it this slot's A1 is free.  Waits for the next K-tile's A0 / B0 / B1 ----
+      NT8_STAMP(3, 0);
+      rdAk(rbuf, 1, 1);
+      if (on2) {
+        issueA1(0, 1, lb, a2, so2); issueW1(1, 0, lb, w2, so2); issueW1(1, 1, lb, w2, so2);
+        // younger than the next K-tile's A0 / B0 / B1: 1 + 1 + 3 + 3 instructions of this K-tile
+        if (seam) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      NT8_MEM_END(3);
+      mmk(acc[1], 1);
+      NT8_CMP_END(3);
     }
     if (wm == 0) NT8_BARRIER();                             // G0 waits for G1's last compute segment: both groups run the epilogue together
+#if PVRL_NT8_TRACE
+    if (tracing) {
+      unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias2));
+      if (lane == 0) {       // shader cycles and 100 MHz ticks across the K loop: the clock the kernel ran at
+        out[2 * NT8_TRACE_KT * 16 + 2 * wm] = __builtin_readcyclecounter() - tr_c0;
+        out[2 * NT8_TRACE_KT * 16 + 2 * wm + 1] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+      }
+      for (int e = lane; e < NT8_TRACE_KT * 16; e += 64)
+        out[wm * NT8_TRACE_KT * 16 + e] = reinterpret_cast<unsigned long long*>(smem + 2 * NT8_BUF)[wm * NT8_TRACE_KT * 16 + e];
+      tracing = false;
+    }
+#endif
     nt_epilogue_at<EPI, EB>(p, acc[0], m0, n0, 64 * wm, 32 * wn, 128 + 32 * wn, lane);
     nt_epilogue_at<EPI, EB>(p, acc[1], m0, n0, 128 + 64 * wm, 32 * wn, 128 + 32 * wn, lane);
     par = (par + nk) & 1;
@@ -294,9 +416,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
       if (kt + 1 < nk) issueW(1, lo, lsW, (unsigned)(kt + 1) * 128u);        // B1 of the other slot: last read in phase 1 of K-tile - 1
       rdA(rbuf, 0);
       rdB(rbuf, 0, rb0);
-      NT8_MEM_END();
+      NT8_MEM_END_Q();
       quad(acc[0], 0, rb0);
-      NT8_CMP_END();
+      NT8_CMP_END_Q();
       // ---- phase 1 ----
       if (kt + 2 < nk) {
         issueW(0, lb, lsW, (unsigned)(kt + 2) * 128u);
@@ -306,9 +428,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       rdB(rbuf, 1, rb1);
-      NT8_MEM_END();
+      NT8_MEM_END_Q();
       quad(acc[0], 1, rb1);
-      NT8_CMP_END();
+      NT8_CMP_END_Q();
     }
     if (wm == 0) NT8_BARRIER();
     nt_epilogue_at<EPI, EB>(p, acc[0], m0, n0, 64 * wm, 32 * wn, 128 + 32 * wn, lane);

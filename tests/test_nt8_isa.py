@@ -45,11 +45,11 @@ def test_nt8_kernel_code(asm, epi):
     # whole-tile epilogue = two 64-row blocks, the half item's epilogue = one more: 3 blocks of NST / 2 stores
     assert body.count("buffer_store_dwordx4") == 3 * NST[epi] // 2
     assert body.count("buffer_store_") == body.count("buffer_store_dwordx4")
-    assert f"s_waitcnt vmcnt({8 + NST[epi]})" in body
+    assert body.count(f"s_waitcnt vmcnt({8 + NST[epi]})") == 2        # phases 1 and 3 of the first K-tile behind a seam
     assert "scratch_" not in body and "buffer_load_dword v" not in body          # no spill traffic
     assert "s_and_saveexec" not in body                                           # no waterfall loops
-    # LDS-DMA: 16 (cold start) + 8 (K-tile body) + 10 + 6 (half item); the compiler may peel the K loop's first iteration (+ 8)
-    assert len(re.findall(r"buffer_load_dwordx4 .* lds", body)) in (40, 48)
+    # LDS-DMA: 14 (cold start) + 8 (K-tile body) + 10 + 6 (half item); the compiler may peel the K loop's first iteration (+ 8)
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", body)) in (38, 46)
     # every MFMA sits in a 16-instruction cluster between s_setprio 1 / 0 (a phase's compute segment)
     assert body.count("s_setprio 1") == body.count("s_setprio 0")
     assert body.count("v_mfma_f32_16x16x32") == 16 * body.count("s_setprio 1")

@@ -26,10 +26,10 @@ EPI = {k[len("PVRL_EPI_"):]: v for k, v in C.items() if k.startswith("PVRL_EPI_"
 _tmp = tempfile.mkdtemp(prefix="nt8ab_")
 
 
-def load(tag, env):
-    """a private copy of the library, its once-read switches fixed to `env`"""
+def load(tag, env, src=None):
+    """a private copy of the library (or of the variant build `src`), its once-read switches fixed to `env`"""
     path = os.path.join(_tmp, f"libpvrl_{tag}.so")
-    shutil.copy(_lib.LIB_PATH, path)
+    shutil.copy(src or _lib.LIB_PATH, path)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     dll = ctypes.CDLL(path)
@@ -192,11 +192,78 @@ def time_all(libs, rounds=7, reps=10):
         print(line, flush=True)
 
 
+def trace(shapes=((65536, 768, 3072), (65536, 768, 768), (8192, 8192, 8192))):
+    """per-phase timeline of waves 0 and 4 of workgroup 8 (variant build -DPVRL_NT8_TRACE=1: tools/build_variant.py nt8trace ...)"""
+    src = os.path.join(HERE, "..", "..", "procedurevrl_amd", "csrc", "variants", "libpvrl_hip_nt8trace.so")
+    dll = load("trace", {"PVRL_NT8": "1"}, src)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    KT = 10
+    for (M, N, K) in shapes:
+        A, W, kw = operands(M, N, K, EPI["RESID_F32"], g)
+        tb = torch.zeros(16384, device=DEV, dtype=torch.float32)
+        kw["bias2"] = tb
+        for _ in range(3):
+            run(dll, A, W, EPI["RESID_F32"], **kw)
+        torch.cuda.synchronize()
+        t = tb.view(torch.int64)[:2 * KT * 16].cpu().view(2, KT, 4, 4)        # [group][kt][phase][stamp]
+        t0 = int(t[0, 0, 0, 0])
+        print(f"--- trace M {M} N {N} K {K}: cycles since G0's first stamp; per phase: mem = work of the memory segment, wait1 = at its barrier, "
+              f"cmp = 16 MFMAs issued, wait2 = at the compute barrier", flush=True)
+        for gi in range(2):
+            for kt in range(min(KT, K // 64)):
+                row = []
+                for ph in range(4):
+                    s0, s1, s2, s3 = (int(x) for x in t[gi, kt, ph])
+                    nxt = int(t[gi, kt, ph + 1, 0]) if ph < 3 else (int(t[gi, kt + 1, 0, 0]) if kt + 1 < min(KT, K // 64) else s3)
+                    row.append(f"[{s0 - t0:6d} mem {s1 - s0:4d} wait1 {s2 - s1:4d} cmp {s3 - s2:4d} wait2 {nxt - s3:4d}]")
+                print(f"G{gi} kt {kt}: " + " ".join(row), flush=True)
+        per = (int(t[0, min(KT, K // 64) - 1, 0, 0]) - int(t[0, 1, 0, 0])) / (min(KT, K // 64) - 2)
+        print(f"cycles per K-tile (G0, kt 1..): {per:.0f}  (16 MFMA clusters x 8 = 2048 at the issue rate)", flush=True)
+        clk = tb.view(torch.int64)[2 * KT * 16:2 * KT * 16 + 4].cpu().tolist()
+        for gi in range(2):
+            cyc, ticks = clk[2 * gi], clk[2 * gi + 1]
+            print(f"G{gi}: K loop of the traced tile = {cyc} shader cycles in {ticks} ticks of 100 MHz -> {cyc / max(ticks, 1) * 0.1:.3f} GHz, "
+                  f"{cyc / (K // 64):.0f} cycles per K-tile incl. {min(KT, K // 64)} traced ones", flush=True)
+
+
+def ablate(rounds=5, reps=10):
+    """time of the main loop with one ingredient removed (variant builds -DPVRL_NT8_ABLATE=<bits>; outputs are garbage)"""
+    vdir = os.path.join(HERE, "..", "..", "procedurevrl_amd", "csrc", "variants")
+    names = {0: "full", 1: "no DMA", 2: "no frag reads", 4: "no MFMA", 8: "no barrier behind compute", 16: "no setprio", 3: "no DMA, no reads (MFMA + barriers)",
+             6: "no reads, no MFMA (DMA + barriers)", 5: "no DMA, no MFMA (reads + barriers)", 7: "barriers only",
+             38: "DMA + barriers, every K-tile the same 64 KB per tile", 102: "DMA + barriers, ONE 64 KB image for the chip",
+             32: "full, every K-tile the same 64 KB per tile"}
+    libs = {}
+    for bits, nm in names.items():
+        src = os.path.join(vdir, f"libpvrl_hip_nt8abl{bits}.so") if bits else None
+        if src is None or os.path.exists(src):
+            libs[nm] = load(f"abl{bits}", {"PVRL_NT8": "1"}, src)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for (M, N, K) in [(65536, 768, 3072), (8192, 8192, 8192), (65536, 768, 768)]:
+        A, W, kw = operands(M, N, K, EPI["BF16"], g)
+        outs = run(libs["full"], A, W, EPI["BF16"], **kw)
+        res = {t: [] for t in libs}
+        for t in libs:
+            timeit(lambda: run(libs[t], A, W, EPI["BF16"], outs=outs, **kw), 3)
+        for _ in range(rounds):
+            for t in libs:
+                res[t].append(timeit(lambda: run(libs[t], A, W, EPI["BF16"], outs=outs, **kw), reps))
+        fl = 2.0 * M * N * K / 1e6
+        print(f"--- ablation M {M} N {N} K {K}", flush=True)
+        for t in libs:
+            med = statistics.median(res[t])
+            print(f"  {t:40s} {med:8.1f} us  ({fl / med:6.0f} TF-equivalent)", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     libs = {"old": load("old", {"PVRL_NT8": "0"}), "new": load("new", {"PVRL_NT8": "1"}),
             "new_nt": load("new_nt", {"PVRL_NT8": "1", "PVRL_NT_TAILS": "0"})}
     rc = 0
+    if "trace" in what:
+        trace()
+    if "ablate" in what:
+        ablate()
     if "check" in what:
         rc |= check(libs)
     if "race" in what:
