@@ -183,11 +183,16 @@ int pvrl_milnce(const float* x, int64_t n, int64_t C, float grad_scale, float* n
  * lib/models/optimizer.py:93-118; gscale = 1/num_iters of the accumulation branch, train_net.py:187-189).
  * decoupled = 1: AdamW, 0: Adam with L2 weight decay.  `step` counts from 1 and is the count of THIS range's parameters
  * (torch.optim keeps it per parameter).  Hyper-parameters are doubles, as torch.optim holds them: the fp32 constants of
- * the update (1 - lr*wd, 1 - beta, lr / bias_correction1 ...) are formed in double and rounded once, like torch's. */
+ * the update (1 - lr*wd, 1 - beta, lr / bias_correction1 ...) are formed in double and rounded once, like torch's.
+ * `skip` (device pointer or null): when *skip != 0 the call leaves p and the state untouched -- the device-side form of
+ * `misc.check_nan_losses(loss)` raising in front of optimizer.step() (tools/train_net.py:174): the flag is the non-finiteness of
+ * the loss (and, for the fp16 flavour, of the gradients: pvrl_nonfinite_flag_f32), no host sync per iteration. */
 int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                   double eps, double weight_decay, int64_t step, double gscale, int decoupled, void* stream);
+                   double eps, double weight_decay, int64_t step, double gscale, int decoupled, const float* skip, void* stream);
 int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum, double dampening,
-                  double weight_decay, int nesterov, int first_step, double gscale, void* stream);
+                  double weight_decay, int nesterov, int first_step, double gscale, const float* skip, void* stream);
+/* *flag = 1 when any of x[0, n) is inf / nan; never cleared here (zero it, then chain the buffers to check).  x 16-byte aligned. */
+int pvrl_nonfinite_flag_f32(const float* x, int64_t n, float* flag, void* stream);
 
 /* softmax over the rows of an fp32 logit matrix: the eval-mode output `self.softmax(x)` (vit.py:355-356, mvit.py:203-204) */
 int pvrl_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, void* stream);

@@ -438,6 +438,114 @@ def seeded_state(shapes, seed):
     return sd
 
 
+def stack_shapes(pre, layers, w):
+    """parameter shapes of a CLIP-style residual attention stack (tfm_model.py:32-67 names)"""
+    sh = {}
+    for i in range(layers):
+        q = f"{pre}resblocks.{i}."
+        sh.update({q + "attn.in_proj_weight": (3 * w, w), q + "attn.in_proj_bias": (3 * w,),
+                   q + "attn.out_proj.weight": (w, w), q + "attn.out_proj.bias": (w,),
+                   q + "ln_1.weight": (w,), q + "ln_1.bias": (w,), q + "ln_2.weight": (w,), q + "ln_2.bias": (w,),
+                   q + "mlp.c_fc.weight": (4 * w, w), q + "mlp.c_fc.bias": (4 * w,),
+                   q + "mlp.c_proj.weight": (w, 4 * w), q + "mlp.c_proj.bias": (w,)})
+    return sh
+
+
+def order_shapes(layers=4, w=512, L=9):
+    """DiffusionTransformer parameters (tfm_model.py:70-104)"""
+    sh = {"order_tfm.pad_embedding.weight": (1, w), "order_tfm.type_embedding.weight": (2, w),
+          "order_tfm.temporalEmbedding.weight": (L, w), "order_tfm.time_mlp.1.weight": (w, w // 4),
+          "order_tfm.time_mlp.1.bias": (w,), "order_tfm.time_mlp.3.weight": (w, w), "order_tfm.time_mlp.3.bias": (w,)}
+    sh.update(stack_shapes("order_tfm.temporalModelling.", layers, w))
+    return sh
+
+
+def text_shapes(layers, w=512):
+    """CLIP ViT-B/16 text tower parameters under CLIP's key names (vit.py:258-261)"""
+    sh = {"text_model.token_embedding.weight": (49408, w), "text_model.positional_embedding": (77, w),
+          "text_model.ln_final.weight": (w,), "text_model.ln_final.bias": (w,), "text_model.text_projection": (w, w),
+          "text_model.logit_scale": ()}
+    sh.update(stack_shapes("text_model.transformer.", layers, w))
+    return sh
+
+
+def host_cpu():
+    """(model string, physical cores, logical cores visible to this process) of the host"""
+    import os
+    model, phys = "unknown CPU", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown CPU":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except Exception:
+        logical = os.cpu_count() or 1
+    return model, (len(phys) or logical), logical
+
+
+def timed_full_step(videos=2, frames=8, classes=9871, budget_s=60.0, threads=None):
+    """SURVEY 8(d)'s CPU baseline: BASELINE configs[0] -- `videos` videos x 9 clips of 8 x 224^2, the reference's FULL pre-training
+    step (vit.py:283-352 encoder + head + frozen 12-layer CLIP-text teacher + order / diffusion transformer, train_net.py:152-192
+    top-5 KL + MSE, backward, AdamW over the trainable parameters) in eager fp32 on ALL cores visible to the process.  Bounded:
+    the first (warm-up) step is timed too, and when it alone exhausts `budget_s` it IS the sample."""
+    model, phys, logical = host_cpu()
+    threads = int(threads or min(phys, logical))              # one thread per physical core (SMT siblings add nothing to fp32 GEMMs)
+    torch.set_num_threads(max(1, threads))
+    sh = encoder_shapes(12, frames)
+    sh.update(order_shapes())
+    sh.update(text_shapes(12))
+    sd = seeded_state(sh, 0)
+    params = {k: (v.clone().requires_grad_(True) if not k.startswith("text_model.") else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=5e-5, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1)
+    b, m = videos, 9
+    inputs = torch.randn(b, m, 3, frames, 224, 224, generator=g)
+    label = l2n(torch.randn(classes, 512, generator=g) * 0.38)
+    L = torch.randint(8, 41, (b * m,), generator=g)
+    ids = torch.zeros(b * m, 77, dtype=torch.long)
+    for r in range(b * m):
+        n = int(L[r])
+        ids[r, 0] = 49406
+        ids[r, 1:1 + n] = torch.randint(1, 49406, (n,), generator=g)
+        ids[r, 1 + n] = 49407
+    meta = {"clip_text_ids": ids, "clip_vis_feat": torch.randn(b * m, 512, generator=g) * 0.4}
+    rng = {"mask_inds": torch.randint(0, m, (b,), generator=g), "pad_start": torch.randint(1, m + 1, (b,), generator=g).tolist(),
+           "noises": [torch.randn(b, 512, generator=g) for _ in range(4)], "rand_inds": torch.randperm(b * m, generator=g)}
+    times = []
+    t_all = time.perf_counter()
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred, teacher, mse = vit_forward_train(params, inputs, meta, label, 0.02, 12, m, 4, 12, rng)
+        loss, _, _ = pretrain_loss(pred, teacher, mse, 5)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all + times[-1] > budget_s:     # another step would not fit the budget
+            break
+    timed = times[1:] if len(times) > 1 else times
+    dt = sorted(timed)[len(timed) // 2]
+    clips = b * m
+    return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"BASELINE configs[0]: {videos} videos x 9 = {clips} clips x {frames}f x 224^2, the reference's FULL pre-training step "
+                      f"(encoder + head + frozen CLIP-text teacher + order transformer + top-5 KL + MSE, backward, AdamW), eager fp32 PyTorch "
+                      f"oracle on {threads} threads (host: {phys} physical / {logical} logical cores visible to the process, {model}); "
+                      f"{'median of %d steps after 1 warm-up' % len(timed) if len(times) > 1 else 'ONE step, no warm-up (budget)'}, "
+                      f"{dt:.2f} s per step ({time.perf_counter() - t_all:.0f} s of wall time in all)"}
+
+
 def timed_train_step(clips=2, frames=8, classes=9871, threads=8, repeats=3):
     """One full training step of BASELINE config 2's workload (encoder fwd, head + step logits + top-5 KL,
     backward, AdamW) on the host CPU in eager fp32, on a bounded sample of `clips` clips."""

@@ -35,7 +35,7 @@ struct Conv3dGeom {
 constexpr int IM2COL_MAXK = 1024;
 __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ frames, op_t* __restrict__ out,
                                                        Conv3dGeom g, long ldo) {
-  __shared__ unsigned lut[IM2COL_MAXK];          // column k -> c << 24 | a << 16 | y << 8 | x   (0xffffffff: k >= K)
+  __shared__ __attribute__((aligned(16))) unsigned lut[IM2COL_MAXK];          // column k -> c << 24 | a << 16 | y << 8 | x   (0xffffffff: k >= K)
   const int chunks = (int)(ldo >> 3);
   const long rows = (long)g.B * g.To * g.Ho * g.Wo;
   const long total = rows * chunks;
@@ -92,7 +92,7 @@ constexpr int IMR_LINES = 64, IMR_PITCH = 256, IMR_LPAD = 4;
 __global__ __launch_bounds__(256) void im2col3d_rows_kernel(const float* __restrict__ frames, op_t* __restrict__ out,
                                                             Conv3dGeom g, long ldo) {
   __shared__ __attribute__((aligned(16))) op_t lines[IMR_LINES][IMR_PITCH];
-  __shared__ unsigned koff[IM2COL_MAXK];          // column k -> byte offset of (line, x) inside `lines`; 0xffffffff: k >= K
+  __shared__ __attribute__((aligned(16))) unsigned koff[IM2COL_MAXK];          // column k -> byte offset of (line, x) inside `lines`; 0xffffffff: k >= K
   __shared__ unsigned lca[IMR_LINES];             // line -> c << 16 | a << 8 | y
   const int tid = threadIdx.x;
   const int nline = g.Cin * g.kt * g.kh;

@@ -27,8 +27,13 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p -= c.step_size * (m / denom);
 }
 
+// `skip` (device flag, may be null): non-zero = this step must not be applied (a non-finite loss or gradient was seen on the
+// device -- tools/train_net.py:174 `misc.check_nan_losses` raises BEFORE optimizer.step(); the host here reads its metrics only every
+// LOG_PERIOD iterations, so the bad step is dropped on the device and reported at the next log point).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamConst c) {
+                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamConst c,
+                                                   const float* __restrict__ skip) {
+  if (skip && *skip != 0.f) return;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
     if (i + 4 <= n) {
       f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
@@ -52,7 +57,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float momentum,
-                                                  float one_minus_damp, float wd, int nesterov, int first, float gscale) {
+                                                  float one_minus_damp, float wd, int nesterov, int first, float gscale,
+                                                  const float* __restrict__ skip) {
+  if (skip && *skip != 0.f) return;
   // torch.optim.SGD: g += wd * p;  buf = g (first update) | momentum * buf + (1 - dampening) * g;
   //                  g = g + momentum * buf (nesterov) | buf;  p -= lr * g
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -66,11 +73,37 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// flag = 1 when any element of x is inf / nan (exponent all ones); the flag is only ever raised, never cleared
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ x, long n, float* __restrict__ flag) {
+  bool bad = false;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(x + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bad |= (w[e] & 0x7f800000u) == 0x7f800000u;
+    } else {
+      for (long j = i; j < n; ++j) bad |= (__float_as_uint(x[j]) & 0x7f800000u) == 0x7f800000u;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
+}
+
 }  // namespace
+
+extern "C" int pvrl_nonfinite_flag_f32(const float* x, int64_t n, float* flag, void* stream) {
+  if (n <= 0) return PVRL_OK;
+  if (!x || !flag || ((uintptr_t)x & 15)) return PVRL_EINVAL;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, flag);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
 
 extern "C" int pvrl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                               double beta2, double eps, double weight_decay, int64_t step, double gscale, int decoupled,
-                              void* stream) {
+                              const float* skip, void* stream) {
   if (n <= 0) return PVRL_OK;
   if (!p || !g || !m || !v || step < 1) return PVRL_EINVAL;
   const double bc1 = 1.0 - pow(beta1, (double)step);
@@ -83,20 +116,20 @@ extern "C" int pvrl_adam_step(float* p, const float* g, float* m, float* v, int6
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, c);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, c, skip);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
 
 extern "C" int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum,
                              double dampening, double weight_decay, int nesterov, int first_step, double gscale,
-                             void* stream) {
+                             const float* skip, void* stream) {
   if (n <= 0) return PVRL_OK;
   if (!p || !g || (momentum != 0.0 && !buf)) return PVRL_EINVAL;
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, (float)lr,
-                     (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step, (float)gscale);
+                     (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step, (float)gscale, skip);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

@@ -128,7 +128,7 @@ class GradReducer:
     """Sum the flat gradient buffer over ranks, overlapped with the encoder backward.
 
     Installs `engine.grad_hook`; during loss.backward() the hook fires after each block (last block first) and
-    launches an async all-reduce of that block's contiguous slice on a dedicated communication stream (ordered behind
+    launches an async collective on that block's contiguous slice on a dedicated communication stream (ordered behind
     the main stream and the weight-gradient side stream, and behind nothing later).  `finish()` reduces whatever is
     left (embeddings, head, order transformer: they sit outside the block ranges) and makes the main stream wait.
     Averaging (1/world) is folded into the optimiser's `grad_scale`.
@@ -137,23 +137,34 @@ class GradReducer:
     `no_sync()` -- keeps the hook silent so gradients accumulate locally, and the accumulated buffer is reduced ONCE
     during the final micro-iteration's backward.
 
+    `grad_coll` (env PVRL_GRAD_COLL = "allreduce" | "rsag"): the collective per chunk.  "rsag" = reduce-scatter + all-gather of
+    the reduced shards, both in place: on a fully-connected xGMI node every rank exchanges 1/W of the chunk with each of its
+    W - 1 peers directly (all 7 links busy in both phases) instead of walking a ring (~0.9 vs ~6 ms for the 538 MB
+    of ViT-B at W = 8); chunks whose length W does not divide fall back to the all-reduce.
+
     `find_unused` (the reference builds DDP with find_unused_parameters=True, lib/models/build.py:51): a parameter
     that received no gradient on ANY rank keeps `.grad is None`, so the optimiser skips it exactly as torch.optim
     does; one that was used on some rank gets the summed gradient on every rank.  The per-parameter "used" flags ride
     in the tail of the flat buffer (no extra collective).  Modes:
       True / "sync"   read the reduced flags back every step (one host sync per step: the host cannot run ahead);
       "cached"        (train() default, env PVRL_FIND_UNUSED) the reduced flags are read back on the FIRST step with a
-                      given local used-pattern; later steps with that pattern reuse the decision without a sync, and
-                      every step's flags are checked one step late from a pinned host copy (a changed pattern on some
-                      other rank is then seen: warning + the mode drops to "sync" for the rest of the run);
+                      given local used-pattern; later steps with that pattern reuse the decision without a sync.  EVERY step's
+                      reduced flags are copied to pinned memory and compared with what the step assumed exactly LAG steps later
+                      (by then the copy is long complete: the host blocks on nothing it would not soon need) -- on every rank at
+                      the same step.  A rank that finds a mismatch (another rank started / stopped using a parameter: one or
+                      more optimiser steps ran with the stale set, so the replicas have diverged) raises a request slot that rides
+                      in the same tail; LAG steps later every rank sees it, re-synchronises through `on_resync` (train() installs
+                      a broadcast of parameters and optimiser state from rank 0) and continues in "sync" mode.  Without an
+                      `on_resync` the mismatch raises: diverged replicas are never trained on silently.
       False / "off"   every parameter is known to be used every step: no flags, no sync (bench.py).
 
-    `grad_comm` (env PVRL_GRAD_COMM = "f32" | "bf16"): payload type of the all-reduce.  "bf16" casts each chunk on the
-    communication stream, reduces the 16-bit copy (269 instead of 538 MB per step for ViT-B) and writes the sum back
-    into the fp32 buffer -- SURVEY 8e's half-payload option as a switch.
+    `grad_comm` (env PVRL_GRAD_COMM = "f32" | "bf16"): payload type of the collective.  "bf16" casts each chunk into a persistent
+    16-bit staging buffer on the communication stream, reduces that (269 instead of 538 MB per step for ViT-B) and writes the sum
+    back into the fp32 buffer -- SURVEY 8e's half-payload option as a switch.
     """
+    LAG = 2          # "cached": a step's flags are checked this many steps later
 
-    def __init__(self, vt, enabled=None, find_unused=True, grad_comm=None):
+    def __init__(self, vt, enabled=None, find_unused=True, grad_comm=None, grad_coll=None):
         self.vt = vt
         self.enabled = (get_world_size() > 1) if enabled is None else enabled
         fu = {True: "sync", False: "off", None: "sync"}.get(find_unused, find_unused)
@@ -161,42 +172,79 @@ class GradReducer:
         self.find_unused = fu
         self.grad_comm = (grad_comm or os.environ.get("PVRL_GRAD_COMM", "f32")).lower()
         assert self.grad_comm in ("f32", "bf16"), self.grad_comm
+        self.grad_coll = (grad_coll or os.environ.get("PVRL_GRAD_COLL", "allreduce")).lower()
+        assert self.grad_coll in ("allreduce", "rsag"), self.grad_coll
         self.sync = True
         self.handles = []
-        self.done = []
+        self.done = []           # block indices whose slice the hook has already sent this step
+        self.on_resync = None    # "cached": called on EVERY rank at the same step when a rank saw a changed used-pattern
         self._comm = None
         self._masks = {}
+        self._layout_of = None   # (grad store, per-block parameter indices, per-block span, parameters outside the blocks, spans outside)
+        self._stage = None       # "bf16": persistent 16-bit image of the flat buffer (chunks are cast into their own slice)
         self._decided = {}       # "cached": local used-pattern -> the reduced (global) pattern seen with it
-        self._pending = None     # "cached": (event, pinned flags, assumed pattern) of the last unchecked step
+        self._queue = []         # "cached": [(event | None, host copy of the reduced tail, assumed pattern)] of the last LAG steps
+        self._want_resync = False
         self.host_syncs = 0      # flag read-backs that blocked the host (tests / diagnostics)
+        self.resyncs = 0
         vt.engine.grad_hook = self._hook if self.enabled else None
 
-    def _block_params(self, i):
+    # ---- layout of the flat buffer: computed once per gradient store ----------------------------------------------------
+    def _layout(self):
         gs = self.vt.grad_store()
-        pre = f"{getattr(self.vt, 'block_prefix', 'blocks.')}{i}."
-        return [k for k, n in enumerate(gs.names) if n.startswith(pre)]
+        if self._layout_of is None or self._layout_of[0] is not gs:
+            pre = getattr(self.vt, "block_prefix", "blocks.")
+            blocks = {}
+            for k, n in enumerate(gs.names):
+                if n.startswith(pre):
+                    blocks.setdefault(int(n[len(pre):].split(".", 1)[0]), []).append(k)
+            spans = {i: (gs.span(idx[0])[0], gs.span(idx[-1])[1]) for i, idx in blocks.items()}
+            inblock = set(k for idx in blocks.values() for k in idx)
+            rest = [k for k in range(len(gs.params)) if k not in inblock]
+            self._layout_of = (gs, blocks, spans, rest)
+        return self._layout_of
+
+    def _block_params(self, i):
+        return self._layout()[1][i]
 
     def _block_range(self, i):
-        gs = self.vt.grad_store()
-        idx = self._block_params(i)
-        return gs.span(idx[0])[0], gs.span(idx[-1])[1]
+        return self._layout()[2][i]
 
     def _comm_stream(self, device):
         if self._comm is None or self._comm.device != device:
             self._comm = torch.cuda.Stream(device=device)
         return self._comm
 
-    def _reduce(self, t):
-        """async all-reduce of a slice of the flat buffer, ordered after everything enqueued so far on the main stream
-        and on the engine's weight-gradient side stream"""
+    def _staging(self, gs, a, b):
+        if self._stage is None or self._stage.numel() != gs.flat.numel() or self._stage.device != gs.flat.device:
+            self._stage = torch.empty(gs.flat.numel(), device=gs.flat.device, dtype=torch.bfloat16)
+        return self._stage[a:b]
+
+    def _collective(self, c):
+        """sum `c` over the ranks in place; returns the async handles in issue order"""
+        world = dist.get_world_size()
+        n = c.numel()
+        if self.grad_coll == "rsag" and world > 1 and n % world == 0:
+            rank = dist.get_rank()
+            own = c.view(world, n // world)[rank]
+            if c.is_cuda:      # RCCL: in place (recv = send + rank * count for the reduce-scatter, send = recv + rank * count for the gather)
+                return [dist.reduce_scatter_tensor(own, c, async_op=True), dist.all_gather_into_tensor(c, own, async_op=True)]
+            shard = torch.empty_like(own)                       # CPU / gloo: through a private shard
+            dist.reduce_scatter_tensor(shard, c)
+            return [dist.all_gather_into_tensor(c, shard, async_op=True)]
+        return [dist.all_reduce(c, async_op=True)]
+
+    def _reduce(self, a, b):
+        """async sum over ranks of flat[a:b], ordered after everything enqueued so far on the main stream and on the
+        engine's weight-gradient side stream"""
+        gs = self.vt.grad_store()
+        t = gs.flat[a:b]
         half = self.grad_comm == "bf16"
         if not t.is_cuda:
+            c = self._staging(gs, a, b) if half else t
             if half:
-                c = t.to(torch.bfloat16)
-                dist.all_reduce(c)
-                t.copy_(c)
-            else:
-                self.handles.append((dist.all_reduce(t, async_op=True), None, None))
+                c.copy_(t)
+            self.handles.append((self._collective(c), t if half else None, c if half else None))
             return
         comm = self._comm_stream(t.device)
         comm.wait_event(torch.cuda.current_stream().record_event())
@@ -204,28 +252,31 @@ class GradReducer:
         if side is not None:
             comm.wait_event(side.record_event())
         with torch.cuda.stream(comm):
+            c = self._staging(gs, a, b) if half else t
             if half:
-                c = t.to(torch.bfloat16)         # allocated, reduced and consumed on the communication stream
-                self.handles.append((dist.all_reduce(c, async_op=True), t, c))
-            else:
-                self.handles.append((dist.all_reduce(t, async_op=True), None, None))
+                c.copy_(t)                       # cast, reduced and consumed on the communication stream; the slice is this chunk's own
+            self.handles.append((self._collective(c), t if half else None, c if half else None))
 
     def _wait_all(self, device):
         if device.type != "cuda":
-            for h, _, _ in self.handles:
-                h.wait()
+            for hs, t, c in self.handles:
+                for h in hs:
+                    h.wait()
+                if c is not None:
+                    t.copy_(c)
         else:
             comm = self._comm_stream(device)
             with torch.cuda.stream(comm):
-                for h, t, c in self.handles:
-                    h.wait()                    # the communication stream waits for the collective ...
+                for hs, t, c in self.handles:
+                    for h in hs:
+                        h.wait()                # the communication stream waits for the collective ...
                     if c is not None:
                         t.copy_(c)              # ... and widens the 16-bit sum back into the fp32 buffer
             torch.cuda.current_stream().wait_stream(comm)
         self.handles = []
 
     def _settle(self, gs, k):
-        """parameter k is about to be all-reduced: its slot of the flat buffer must hold THIS step's gradient of this rank
+        """parameter k is about to be reduced: its slot of the flat buffer must hold THIS step's gradient of this rank
         -- zeros when the rank produced none (zero_grad(set_to_none=True) does not clear the buffer), the values of a
         gradient tensor somebody else allocated otherwise"""
         p, v = gs.params[k], gs.views[k]
@@ -238,41 +289,56 @@ class GradReducer:
     def _hook(self, i):
         if not self.sync:
             return
-        gs = self.vt.grad_store()
-        idx = self._block_params(i)
-        for k in idx:           # (on the main stream, i.e. before the event the all-reduce is ordered behind)
+        gs, blocks, spans, _ = self._layout()
+        for k in blocks[i]:     # (on the main stream, i.e. before the event the collective is ordered behind)
             self._settle(gs, k)
-        a, b = gs.span(idx[0])[0], gs.span(idx[-1])[1]
-        self._reduce(gs.flat[a:b])
-        self.done.append((a, b))
+        self._reduce(*spans[i])
+        self.done.append(i)
 
-    def _check_pending(self, block=False):
-        """"cached" mode: compare the flags of an earlier step (pinned host copy) with the pattern that step assumed"""
-        if self._pending is None:
-            return
-        ev, host, assumed = self._pending
-        if not block and not ev.query():
-            return
-        ev.synchronize()
-        self._pending = None
-        if tuple(bool(x) for x in (host > 0).tolist()) != assumed:
+    # ---- "cached": late check of every step's reduced flags -------------------------------------------------------------
+    def _resync(self):
+        self.resyncs += 1
+        self._queue = []
+        self._decided = {}
+        self._want_resync = False
+        self.find_unused = "sync"
+        if self.on_resync is None:
+            raise RuntimeError("GradReducer(find_unused='cached'): the set of parameters used on SOME rank changed between steps and "
+                               "optimiser steps ran with the stale set -- the replicas have diverged, and no `on_resync` is installed "
+                               "to restore them (train() broadcasts parameters and optimiser state from rank 0).")
+        self.on_resync()
+
+    def _check_one(self, block):
+        """the oldest queued step: -> False when it is not complete yet (block = False)"""
+        ev, host, assumed = self._queue[0]
+        if ev is not None:
+            if not block and not ev.query():
+                return False
+            ev.synchronize()
+        self._queue.pop(0)
+        vals = host.tolist()
+        if vals[-1] > 0:                  # some rank asked for a re-synchronisation at that step: every rank acts now, at the same step
             import warnings
-            warnings.warn("GradReducer(find_unused='cached'): the set of parameters used on SOME rank changed between steps; "
-                          "one optimiser step ran with the previous set.  Falling back to find_unused='sync' (one host sync "
-                          "per step).")
-            self.find_unused = "sync"
-            self._decided = {}
+            warnings.warn("GradReducer(find_unused='cached'): a rank saw the set of used parameters change; re-synchronising parameters "
+                          "and optimiser state from rank 0 and falling back to find_unused='sync' (one host sync per step).")
+            self._resync()
+            return True
+        if assumed is not None and tuple(v > 0 for v in vals[:-1]) != assumed:
+            self._want_resync = True       # rides in the next step's tail: all ranks re-synchronise together LAG steps after it
+        return True
 
     def finish(self):
         if not self.enabled:
             return
-        gs = self.vt.grad_store()
+        gs, blocks, spans, rest = self._layout()
         had = [p.grad is not None for p in gs.params]           # host-side knowledge, before the buffer is adopted
-        reduced = sorted(self.done)
-        in_done = lambda a: any(x <= a < y for x, y in reduced)
-        for k in range(len(gs.params)):                         # block parameters were settled (and sent) by the hook
-            if not in_done(gs.offsets[k]):
-                self._settle(gs, k)
+        sent = set(self.done)
+        for i, idx in blocks.items():                           # block parameters the hook has not settled (and sent) this step
+            if i not in sent:
+                for k in idx:
+                    self._settle(gs, k)
+        for k in rest:
+            self._settle(gs, k)
         if self.find_unused != "off":
             key = tuple(had)                 # a pageable host->device copy would block the host until the backward has
             m = self._masks.get(key)         # drained: the handful of distinct patterns are cached on the device
@@ -280,28 +346,40 @@ class GradReducer:
                 m = torch.tensor([1.0 if h else 0.0 for h in had], device=gs.used.device)
                 self._masks[key] = m
             gs.used.copy_(m)
+            gs.ctl.fill_(1.0 if self._want_resync else 0.0)
+            self._want_resync = False
         cur = 0
-        for a, b in reduced + [(gs.flat.numel(), gs.flat.numel())]:
+        for a, b in sorted(spans[i] for i in sent) + [(gs.flat.numel(), gs.flat.numel())]:
             if a > cur:
-                self._reduce(gs.flat[cur:a])
+                self._reduce(cur, a)
             cur = max(cur, b)
         self._wait_all(gs.flat.device)                          # the current (main) stream waits for the collectives
         self.done = []
         if self.find_unused == "off":
             used = [True] * len(had)
+        elif self.find_unused == "sync":
+            used = tuple(bool(x) for x in (gs.used > 0).tolist())              # host sync
+            self.host_syncs += 1
         else:
-            if self.find_unused == "cached":
-                self._check_pending()
-            used = self._decided.get(tuple(had)) if self.find_unused == "cached" else None
-            if used is None:
-                self._check_pending(block=True)
-                used = tuple(bool(x) for x in (gs.used > 0).tolist())          # host sync
+            n = len(had)
+            tail = gs.flat[gs.end:gs.end + n + 1]                              # the reduced flags + the request slot
+            used = self._decided.get(tuple(had))
+            if used is None:                                                   # first step with this local pattern: read it now
+                host = tail.to("cpu")                                          # host sync
                 self.host_syncs += 1
-                if self.find_unused == "cached":
-                    self._decided[tuple(had)] = used
-            elif gs.used.is_cuda:
-                host = torch.empty(gs.used.shape, dtype=gs.used.dtype, pin_memory=True)
-                host.copy_(gs.used, non_blocking=True)
-                self._pending = (torch.cuda.current_stream().record_event(), host, used)
+                used = tuple(v > 0 for v in host[:n].tolist())
+                self._decided[tuple(had)] = used
+                self._queue.append((None, host, None))
+            elif tail.is_cuda:
+                host = torch.empty(n + 1, dtype=tail.dtype, pin_memory=True)
+                host.copy_(tail, non_blocking=True)
+                self._queue.append((torch.cuda.current_stream().record_event(), host, used))
+            else:
+                self._queue.append((None, tail.clone(), used))
+            while len(self._queue) > self.LAG and self.find_unused == "cached":   # the step LAG steps back, on every rank alike
+                self._check_one(block=True)
+            if self.find_unused == "sync":                                     # a re-synchronisation just happened: this step's flags, read now
+                used = tuple(bool(x) for x in (gs.used > 0).tolist())
+                self.host_syncs += 1
         for p, v, u in zip(gs.params, gs.views, used):
             p.grad = v if u else None

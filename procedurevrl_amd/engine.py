@@ -45,9 +45,11 @@ class GradStore:
             off += (s + 63) // 64 * 64
         self.end = off                     # end of the parameter gradients
         # tail: one float per parameter, "this rank produced a gradient for it" -- summed over ranks inside the last
-        # chunk of the data-parallel all-reduce (distributed.GradReducer, DDP's find_unused_parameters bookkeeping)
-        self.flat = torch.zeros(off + (len(sizes) + 63) // 64 * 64, device=device, dtype=F32)
+        # chunk of the data-parallel all-reduce (distributed.GradReducer, DDP's find_unused_parameters bookkeeping) -- and one
+        # control slot behind them ("a rank asks for a re-synchronisation of the replicas", GradReducer find_unused="cached")
+        self.flat = torch.zeros(off + (len(sizes) + 1 + 63) // 64 * 64, device=device, dtype=F32)
         self.used = self.flat[off:off + len(sizes)]
+        self.ctl = self.flat[off + len(sizes):off + len(sizes) + 1]
         self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.scale = None       # fp16 flavour: device scalar S while an engine's backward runs with S-scaled gradients

@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import lr_policy
-from ._lib import lib
+from ._lib import OPERAND, lib
 
 
 def _inner(model):
@@ -36,6 +36,13 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.steps = 0             # optimiser steps taken (informational; the arithmetic uses the per-parameter counts)
         self.param_steps = None    # per parameter of the flat store: updates applied so far (torch.optim's state["step"];
         self.grad_scale = 1.0      # a parameter without a gradient is skipped and its count does not advance)
+        # Device-side `misc.check_nan_losses` (tools/train_net.py:174 raises in front of optimizer.step()): `skip_flag` is a device
+        # scalar the training loop sets to "this iteration's loss is not finite"; the update kernels leave weights and state
+        # untouched when it is non-zero, and the loop raises at its next log point -- the bad step is never applied, no
+        # host sync per iteration.  `check_grads` adds one pass over the flat gradient buffer (inf / nan in any gradient also
+        # raises the flag): default for the fp16-operand flavour, whose scaled backward can overflow where the loss cannot.
+        self.skip_flag = None
+        self.check_grads = os.environ.get("PVRL_CHECK_GRADS", "1" if OPERAND == "f16" else "0") == "1"
 
     # -- flat storage -----------------------------------------------------------------------
     def _ensure_flat(self):
@@ -89,24 +96,45 @@ class FusedOptimizer(torch.optim.Optimizer):
         base_2 = self.buf2.data_ptr() if self.buf2 is not None else 0
         vp = ctypes.c_void_p
         ps = self._steps(gs)
+        skip = None
+        if self.check_grads:
+            if self.skip_flag is None:
+                self.skip_flag = torch.zeros((), device=gs.flat.device)
+            L.call("pvrl_nonfinite_flag_f32", vp(base_g), gs.end, vp(self.skip_flag.data_ptr()), stream)
+        if self.skip_flag is not None:
+            skip = vp(self.skip_flag.data_ptr())
         for g in self.param_groups:
             for a, b, done in self._runs(gs, g["params"], had_grad):
                 n, o = b - a, 4 * a
                 if self.method == "sgd":
                     L.call("pvrl_sgd_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), n, float(g["lr"]),
                            float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]),
-                           1 if g["nesterov"] else 0, 1 if done == 0 else 0, float(self.grad_scale), stream)
+                           1 if g["nesterov"] else 0, 1 if done == 0 else 0, float(self.grad_scale), skip, stream)
                 else:
                     L.call("pvrl_adam_step", vp(base_p + o), vp(base_g + o), vp(base_1 + o), vp(base_2 + o), n,
                            float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                            float(g["weight_decay"]), done + 1, float(self.grad_scale),
-                           1 if self.method == "adamw" else 0, stream)
+                           1 if self.method == "adamw" else 0, skip, stream)
             for p in g["params"]:
                 i = gs.index.get(id(p))
                 if i is not None and had_grad[i]:
                     ps[i] += 1
         self._bump(gs)
         return None
+
+    def broadcast_state(self, src=0):
+        """every rank takes rank `src`'s parameters, optimiser state and per-parameter step counts (one broadcast per flat buffer):
+        what restores identical replicas after ranks disagreed about which parameters a step updates
+        (distributed.GradReducer find_unused="cached" -> `on_resync`)"""
+        import torch.distributed as dist
+        gs = self._ensure_flat()
+        for t in (self.flat_p, self.buf1, self.buf2):
+            if t is not None:
+                dist.broadcast(t, src)
+        steps = torch.tensor(self._steps(gs), dtype=torch.int64, device=self.flat_p.device)
+        dist.broadcast(steps, src)
+        self.param_steps = [int(x) for x in steps.tolist()]
+        self._bump(gs)
 
     def _bump(self, gs):
         # parameters changed in place through the flat buffer: tell the bf16 operand cache to refresh

@@ -1,7 +1,8 @@
 """Training loop of the pre-training path (reference: tools/train_net.py `train` :417-524, `train_epoch` :56-248).
 
 Kept from the reference: per-iteration LR set (:123-124), `meta` reshape (:146), the model call and KL + MSE loss
-(:147-162), NaN check (:174), the accumulation branch to GLOBAL_BATCH_SIZE (:176-192, folded into the optimiser's
+(:147-162), NaN check (:174: the bad step is never applied -- device-side skip flag into the fused optimiser, raised at the
+next log point), the accumulation branch to GLOBAL_BATCH_SIZE (:176-192, folded into the optimiser's
 grad_scale), top-k error on the logits vs a dummy label (:226-231), the fine-tuning branch (:149-150, 163-169: cross entropy /
 `smooth` on model(inputs); EPIC-Kitchens verb + noun heads with their accuracies :195-222), json_stats logging, checkpoint /
 auto-resume.  Not built: MIXUP (no shipped ProcedureVRL config enables it).
@@ -101,6 +102,7 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
     optimizer.grad_scale = 1.0 / (world * (num_iters if accumulate else 1))
     dev = next(model.parameters()).device
     window = []
+    skipped = []
     last_line = None
     pretrain = is_pretraining(cfg)
     t_last = time.perf_counter()
@@ -120,14 +122,24 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
         else:                                                  # fine-tuning (train_net.py:149-150,163-169): logits -> cross entropy
             pred = model(inputs)
             loss, task_losses = finetune_loss(pred, labels, cfg)
-        if not accumulate or cur_iter % num_iters == 0:
+        first_micro = not accumulate or cur_iter % num_iters == 0
+        if first_micro:
             optimizer.zero_grad(set_to_none=True)
         last_micro = not accumulate or (cur_iter + 1) % num_iters == 0
+        # misc.check_nan_losses(loss) (train_net.py:174) raises BEFORE the step of a bad iteration.  Here the test stays on the
+        # device: the optimiser's skip flag = "a loss of this (accumulated) iteration is not finite" (+ any non-finite gradient when
+        # optimizer.check_grads), its update kernels do nothing when it is set, and the host raises at the next log point.
+        bad = (~loss.detach().isfinite()).float().reshape(())
+        if hasattr(optimizer, "skip_flag"):
+            if optimizer.skip_flag is None or optimizer.skip_flag.device != bad.device:
+                optimizer.skip_flag = torch.zeros((), device=bad.device)
+            optimizer.skip_flag.copy_(bad if first_micro else torch.maximum(optimizer.skip_flag, bad))
         reducer.sync = last_micro          # DDP no_sync() on the other micro-iterations: accumulate locally, reduce once
         loss.backward()
         if last_micro:
             reducer.finish()
             optimizer.step()
+        skipped.append(optimizer.skip_flag.clone() if getattr(optimizer, "skip_flag", None) is not None else bad)
         with torch.no_grad():
             if task_losses is not None:                        # EPIC-Kitchens (train_net.py:195-222): verb / noun / action accuracies
                 v1, v5 = topk_accuracies(pred[0], labels["verb"], (1, 5))
@@ -136,16 +148,22 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
                 stats = du.all_reduce_scalars([loss.detach(), 100.0 - a1, 100.0 - a5, task_losses[0].detach(), task_losses[1].detach(),
                                                v1, v5, n1, n5, a1, a5])
             else:
-                # pre-training ignores the labels: the first one is copied to the prediction's length (train_net.py:226-227)
-                lab = labels[0].expand(pred.size(0)) if cfg.DEV.ORDER_PRETRAIN_ENABLED and pretrain else labels
-                k5 = min(5, pred.shape[1])
+                # "since labels during pretraining are not used, copy label to the same shape of prediction" (train_net.py:225-227:
+                # whenever DEV.ORDER_PRETRAIN_ENABLED is set, pre-training or not)
+                lab = labels[0].expand(pred.size(0)) if cfg.DEV.ORDER_PRETRAIN_ENABLED else labels
+                assert lab.numel() == pred.size(0), (lab.shape, pred.shape)
+                k5 = min(5, pred.shape[0], pred.shape[1])      # train_net.py:230 takes min(5, preds.shape[0])
                 c1, c5 = topks_correct(pred, lab, (1, k5))
                 stats = du.all_reduce_scalars([loss.detach(), (1.0 - c1 / pred.size(0)) * 100.0, (1.0 - c5 / pred.size(0)) * 100.0])
         window.append(stats)
         if (cur_iter + 1) % cfg.LOG_PERIOD == 0 or cur_iter + 1 == data_size:
             w = torch.stack(window)
-            vals = torch.cat([w.median(0).values, w[:, 0].isfinite().all().float().view(1)]).tolist()   # one host sync per LOG_PERIOD
-            if vals[3] == 0.0 or any(math.isnan(v) or math.isinf(v) for v in vals):
+            # one host sync per LOG_PERIOD: the medians, "every loss of the window is finite", "no step of the window was skipped"
+            vals = torch.cat([w.median(0).values, w[:, 0].isfinite().all().float().view(1),
+                              torch.stack(skipped).max().view(1).to(w.device)]).tolist()
+            finite, dropped = vals[-2], vals[-1]
+            vals = vals[:-2]
+            if finite == 0.0 or dropped != 0.0 or any(math.isnan(v) or math.isinf(v) for v in vals):
                 raise RuntimeError("ERROR: Got NaN losses {}".format(time.time()))   # misc.check_nan_losses, on EVERY loss of the window
             now = time.perf_counter()
             dt = (now - t_last) / len(window)
@@ -155,12 +173,13 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
                     "iter": "{}/{}".format(cur_iter + 1, data_size), "dt": dt, "loss": vals[0],
                     "top1_err": vals[1], "top5_err": vals[2], "lr": lr, "clips_per_s": nclip * world / dt}
             if task_losses is not None:                        # EPICTrainMeter's extra columns (lib/utils/meters.py)
-                m = w.median(0).values.tolist()
+                m = vals
                 line.update({"verb_loss": m[3], "noun_loss": m[4], "verb_top1_acc": m[5], "verb_top5_acc": m[6],
                              "noun_top1_acc": m[7], "noun_top5_acc": m[8], "top1_acc": m[9], "top5_acc": m[10]})
             log_json_stats(line)
             last_line = line
             window = []
+            skipped = []
     return last_line
 
 
@@ -215,25 +234,77 @@ class ValMeter:
         return self.stats
 
 
+class EPICValMeter:
+    """lib/utils/meters.py:798-960: verb / noun / action (verb AND noun) accuracies -- windowed medians for the `val_iter` lines,
+    sample-weighted epoch accuracies and their running maxima for the `val_epoch` line."""
+    KEYS = ("verb_top1_acc", "noun_top1_acc", "top1_acc", "verb_top5_acc", "noun_top5_acc", "top5_acc")
+
+    def __init__(self, max_iter, cfg):
+        self._cfg = cfg
+        self.max_iter = max_iter
+        self.best = {"max_" + k: 0.0 for k in self.KEYS}
+        self.reset()
+
+    def reset(self):
+        self.win = {k: [] for k in self.KEYS}
+        self.cor = {k: 0.0 for k in self.KEYS}
+        self.num_samples = 0
+        self.t0 = time.perf_counter()
+
+    def update_stats(self, top1_acc, top5_acc, mb_size):
+        """top1_acc / top5_acc: (verb, noun, action) of the minibatch"""
+        for k, v in zip(self.KEYS, tuple(top1_acc) + tuple(top5_acc)):
+            self.win[k] = (self.win[k] + [v])[-self._cfg.LOG_PERIOD:]
+            self.cor[k] += v * mb_size
+        self.num_samples += mb_size
+
+    def update_predictions(self, preds, labels):
+        pass                                                    # (EPICValMeter.update_stats clears its lists: nothing is kept)
+
+    def log_iter_stats(self, cur_epoch, cur_iter):
+        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
+            return
+        line = {"_type": "val_iter", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
+                "iter": "{}/{}".format(cur_iter + 1, self.max_iter)}
+        line.update({k: float(torch.tensor(w).median()) for k, w in self.win.items()})
+        log_json_stats(line)
+
+    def log_epoch_stats(self, cur_epoch):
+        acc = {k: c / self.num_samples for k, c in self.cor.items()}
+        for k, v in acc.items():
+            self.best["max_" + k] = max(self.best["max_" + k], v)
+        self.stats = {"_type": "val_epoch", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
+                      "time_diff": time.perf_counter() - self.t0, **acc, **self.best}
+        log_json_stats(self.stats)
+        return self.stats
+
+
 @torch.no_grad()
 def eval_epoch(val_loader, model, val_meter, cur_epoch, cfg):
-    """tools/train_net.py:251-350 (single-label branch; the EPIC verb/noun branch is outside SURVEY 8): eval-mode forward
-    (softmax probabilities, vit.py:355-356), top-1 / top-5 error of the minibatch, averaged over ranks (`du.all_reduce`,
-    here as ONE two-float collective), fed to the ValMeter; `val_iter` / `val_epoch` json lines."""
+    """tools/train_net.py:251-350: eval-mode forward (softmax probabilities, vit.py:355-356; (verb, noun) for EPIC-Kitchens),
+    top-1 / top-5 error of the minibatch -- or the verb / noun / action accuracies of :296-322 -- averaged over ranks (`du.all_reduce`,
+    here as ONE collective), fed to the meter; `val_iter` / `val_epoch` json lines."""
     model.eval()
     dev = next(model.parameters()).device
     world = du.get_world_size()
     for cur_iter, (inputs, labels, _index, _meta) in enumerate(val_loader):
         inputs = inputs.to(dev, non_blocking=True)
-        labels = labels.to(dev)
+        labels = {k: v.to(dev).view(-1) for k, v in labels.items()} if isinstance(labels, dict) else labels.to(dev)
         preds = model(inputs)
-        if labels.dim() > 1 and labels.numel() == preds.size(0):       # [b, clips] labels of a clips-per-video batch
-            labels = labels.reshape(-1)
-        k5 = min(5, preds.shape[1])
-        c1, c5 = topks_correct(preds, labels, (1, k5))
-        errs = du.all_reduce_scalars([(1.0 - c1 / preds.size(0)) * 100.0, (1.0 - c5 / preds.size(0)) * 100.0])
-        top1_err, top5_err = errs.tolist()                             # train_net.py:340: the reference syncs here too
-        val_meter.update_stats(top1_err, top5_err, inputs.size(0) * max(world, 1))
+        if isinstance(labels, dict) and cfg.TRAIN.DATASET == "Epickitchens":
+            v1, v5 = topk_accuracies(preds[0], labels["verb"], (1, 5))
+            n1, n5 = topk_accuracies(preds[1], labels["noun"], (1, 5))
+            a1, a5 = multitask_topk_accuracies((preds[0], preds[1]), (labels["verb"], labels["noun"]), (1, 5))
+            v1, n1, a1, v5, n5, a5 = du.all_reduce_scalars([v1, n1, a1, v5, n5, a5]).tolist()   # the reference syncs here too (:302-318)
+            val_meter.update_stats((v1, n1, a1), (v5, n5, a5), inputs.size(0) * max(world, 1))
+        else:
+            if labels.dim() > 1 and labels.numel() == preds.size(0):       # [b, clips] labels of a clips-per-video batch
+                labels = labels.reshape(-1)
+            k5 = min(5, preds.shape[1])
+            c1, c5 = topks_correct(preds, labels, (1, k5))
+            errs = du.all_reduce_scalars([(1.0 - c1 / preds.size(0)) * 100.0, (1.0 - c5 / preds.size(0)) * 100.0])
+            top1_err, top5_err = errs.tolist()                             # train_net.py:340: the reference syncs here too
+            val_meter.update_stats(top1_err, top5_err, inputs.size(0) * max(world, 1))
         val_meter.update_predictions(preds, labels)
         val_meter.log_iter_stats(cur_epoch, cur_iter)
     stats = val_meter.log_epoch_stats(cur_epoch)
@@ -256,9 +327,10 @@ def train(cfg, max_iters=None):
     start_epoch = cu.load_train_checkpoint(cfg, model, optimizer)
     # DDP(find_unused_parameters=True) of lib/models/build.py:51 without a host sync per step: see GradReducer
     reducer = du.GradReducer(model.model, find_unused=os.environ.get("PVRL_FIND_UNUSED", "cached"))
+    reducer.on_resync = lambda: optimizer.broadcast_state(0)   # replicas that disagreed about a step's parameter set: rank 0's state wins
     train_loader = construct_loader(cfg, "train")
     val_loader = construct_loader(cfg, "val")
-    val_meter = ValMeter(len(val_loader), cfg)
+    val_meter = (EPICValMeter if cfg.TRAIN.DATASET == "Epickitchens" else ValMeter)(len(val_loader), cfg)   # train_net.py:470-475
     dev = next(model.parameters()).device
     if dev.type == "cuda":
         train_loader = DevicePrefetcher(train_loader, dev)       # H2D copy of batch i+1 under step i

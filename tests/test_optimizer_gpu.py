@@ -141,3 +141,67 @@ def test_resume_from_a_torch_optim_sgd_checkpoint_keeps_the_momentum():
     torch.cuda.synchronize()
     worst = max(float((p.detach().cpu() - cpu[n].detach()).abs().max() / cpu[n].detach().abs().max()) for n, p in named)
     assert worst <= TOL, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["adamw", "sgd"])
+def test_non_finite_step_is_dropped_on_the_device(method):
+    """tools/train_net.py:174 `misc.check_nan_losses(loss)` raises in front of optimizer.step(): a bad iteration never touches the
+    weights.  Here the check stays on the device: with an inf in ONE gradient (optimizer.check_grads) or a non-finite loss flag
+    (optimizer.skip_flag set by the loop) the update kernels return at once -- parameters and state bit-equal -- and a clean
+    step afterwards updates as usual."""
+    import e2e_checks as ec
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    from procedurevrl_amd.optimizer import construct_optimizer, set_lr
+    torch.manual_seed(0)
+    cfg = ec.make_cfg(2, 32, 64)
+    cfg.SOLVER.OPTIMIZING_METHOD = method
+    model = ec.build(cfg, synthetic_label_emb(64, 512, seed=1))
+    opt = construct_optimizer(model, cfg)
+    set_lr(opt, 1e-3)
+    gs = model.model.grad_store()
+    gen = torch.Generator(device=gs.flat.device).manual_seed(3)
+
+    def fill():
+        opt.zero_grad(set_to_none=True)
+        for p, v in zip(gs.params, gs.views):
+            v.copy_(torch.randn(v.shape, device=v.device, generator=gen) * 1e-2)
+            p.grad = v
+
+    fill(); opt.step()                                            # a clean first step (creates the state)
+    snap = lambda: (opt.flat_p.clone(), opt.buf1.clone(), None if opt.buf2 is None else opt.buf2.clone())
+    # (a) inf in one gradient element, gradient check on
+    opt.check_grads = True
+    before = snap()
+    fill()
+    gs.views[5].view(-1)[3] = float("inf")
+    opt.skip_flag = torch.zeros((), device=gs.flat.device)
+    opt.step()
+    after = snap()
+    assert float(opt.skip_flag) == 1.0
+    assert all(b is None or torch.equal(a, b) for a, b in zip(after, before)), "a step with an inf gradient changed weights or state"
+    # (b) the loop's loss flag alone
+    opt.check_grads = False
+    fill()
+    opt.skip_flag.fill_(1.0)
+    opt.step()
+    assert all(b is None or torch.equal(a, b) for a, b in zip(snap(), before))
+    # (c) clean again: the step is applied
+    opt.skip_flag.zero_()
+    fill()
+    opt.step()
+    assert not torch.equal(snap()[0], before[0])
+    # nan counts as well; finite values never raise the flag
+    from procedurevrl_amd._lib import lib
+    import ctypes
+    flag = torch.zeros((), device=gs.flat.device)
+    x = torch.randn(100003, device=gs.flat.device)[3:]            # (unaligned start is refused: the flat buffers are 256-byte aligned)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(Exception):
+        lib().call("pvrl_nonfinite_flag_f32", ctypes.c_void_p(x.data_ptr()), x.numel(), ctypes.c_void_p(flag.data_ptr()), stream)
+    y = torch.randn(100003, device=gs.flat.device)
+    lib().call("pvrl_nonfinite_flag_f32", ctypes.c_void_p(y.data_ptr()), y.numel(), ctypes.c_void_p(flag.data_ptr()), stream)
+    assert float(flag) == 0.0
+    y[-1] = float("nan")
+    lib().call("pvrl_nonfinite_flag_f32", ctypes.c_void_p(y.data_ptr()), y.numel(), ctypes.c_void_p(flag.data_ptr()), stream)
+    assert float(flag) == 1.0

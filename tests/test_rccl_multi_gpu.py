@@ -40,13 +40,14 @@ def test_bench_two_ranks_over_rccl():
 
 @pytest.mark.gpu
 @needs2
-@pytest.mark.parametrize("grad_comm", ["f32", "bf16"])
-def test_grad_reducer_two_ranks_rccl(tmp_path, grad_comm):
+@pytest.mark.parametrize("grad_comm,grad_coll", [("f32", "allreduce"), ("bf16", "allreduce"), ("f32", "rsag"), ("bf16", "rsag")])
+def test_grad_reducer_two_ranks_rccl(tmp_path, grad_comm, grad_coll):
     """two ranks on two GPUs, five data-parallel steps (eager, captured, replayed with the per-block hook between the staged
-    graphs): the reduced buffer equals the sum of the ranks' own gradients on both ranks"""
+    graphs): the reduced buffer equals the sum of the ranks' own gradients on both ranks -- through the all-reduce and through the
+    in-place reduce-scatter + all-gather pair (PVRL_GRAD_COLL=rsag)"""
     import torch.multiprocessing as mp
     from test_two_rank_gloo_gpu import _worker
-    mp.spawn(_worker, args=(2, _port(), str(tmp_path), "nccl", grad_comm), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), "nccl", grad_comm, grad_coll), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["backend"] == "nccl" and {r0["device"], r1["device"]} == {"cuda:0", "cuda:1"}
     assert r0["staged"] and r1["staged"]
@@ -87,8 +88,14 @@ def _comm_worker(rank, world, uid_path, out_dir):
         src = torch.full((4096,), rank + 7, device="cuda", dtype=torch.uint8)
         y = torch.empty(4096 * world, device="cuda", dtype=torch.uint8)
         L.call("pvrl_comm_allgather", comm, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(y.data_ptr()), 4096, stream)
+        # reduce-scatter in place (recv = this rank's shard of send), then all-gather of the shards = the two-step all-reduce
+        z = torch.arange(world * 1024, device="cuda", dtype=torch.float32) * (rank + 1)
+        shard = z[rank * 1024:(rank + 1) * 1024]
+        L.call("pvrl_comm_reducescatter_f32", comm, ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(shard.data_ptr()), 1024, stream)
+        L.call("pvrl_comm_allgather", comm, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(z.data_ptr()), 4096, stream)
     st.synchronize()
     ok = bool(torch.all(x == sum(range(1, world + 1)))) and all(bool(torch.all(y[4096 * r:4096 * (r + 1)] == r + 7)) for r in range(world))
+    ok = ok and bool(torch.equal(z.cpu(), torch.arange(world * 1024, dtype=torch.float32) * sum(range(1, world + 1))))
     L.call("pvrl_comm_destroy", comm)
     open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(ok))
 

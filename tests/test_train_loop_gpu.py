@@ -167,14 +167,7 @@ def test_finetune_branch_trains(tmp_path, dataset, capsys):
         cfg.TRAIN.EVAL_PERIOD = 100
         cfg.SOLVER.MAX_EPOCH = 3
     torch.manual_seed(0)
-    from procedurevrl_amd import train_net as tn
-    real_eval = tn.eval_epoch
-    if dataset == "Epickitchens":
-        tn.eval_epoch = lambda *a, **k: None                      # (the verb/noun eval meter is outside SURVEY 8; train loop only)
-    try:
-        model, opt = train(cfg)
-    finally:
-        tn.eval_epoch = real_eval
+    model, opt = train(cfg)                                      # (ends with the evaluation of the last epoch, train_net.py:516-518)
     out = capsys.readouterr().out
     lines = [json.loads(l.split("json_stats: ", 1)[1]) for l in out.splitlines() if "json_stats: " in l and '"train_iter"' in l]
     assert len(lines) >= 3
@@ -185,7 +178,53 @@ def test_finetune_branch_trains(tmp_path, dataset, capsys):
             assert key in lines[-1]
         assert abs(lines[-1]["loss"] - 0.5 * (lines[-1]["verb_loss"] + lines[-1]["noun_loss"])) < 5e-2
         assert model.model.head_v.weight.grad is not None
+        val = [json.loads(l.split("json_stats: ", 1)[1]) for l in out.splitlines() if "json_stats: " in l and '"val_epoch"' in l]
+        assert val, "the EPIC run must end with a val_epoch line (EPICValMeter, lib/utils/meters.py:926-960)"
+        for key in ("verb_top1_acc", "noun_top1_acc", "top1_acc", "top5_acc", "max_top1_acc"):
+            assert key in val[-1] and 0.0 <= val[-1][key] <= 100.0
+        assert val[-1]["top5_acc"] <= min(val[-1]["verb_top5_acc"], val[-1]["noun_top5_acc"]) + 1e-6   # action = verb AND noun
     else:
         assert "top1_err" in lines[-1] and 0.0 <= lines[-1]["top1_err"] <= 100.0
         assert model.model.head_cls.weight.grad is not None
     assert not any(p.requires_grad for p in model.model.head.parameters())
+
+
+@pytest.mark.gpu
+def test_non_finite_loss_never_reaches_the_weights_and_raises_at_the_log_point(tmp_path):
+    """tools/train_net.py:174: `misc.check_nan_losses(loss)` raises before the optimiser step of the bad iteration.  The loop here
+    syncs with the device once per LOG_PERIOD, so the bad step is dropped ON the device (optimizer.skip_flag) and the same error is
+    raised at the next log point: the weights are those of the last good iteration."""
+    from procedurevrl_amd import train_net as tn
+    cfg = _cfg(tmp_path)
+    cfg.SOLVER.MAX_EPOCH = 1
+    cfg.LOG_PERIOD = 4
+    cfg.SYNTHETIC.NUM_VIDEOS = 8                                   # 4 iterations: good, BAD, bad, bad -> raise at the log point
+    real = tn.pretrain_loss
+    calls = {"n": 0}
+    snaps = {}
+
+    def loss_fn(pred, teacher, mse, c):
+        loss, l1, l2 = real(pred, teacher, mse, c)
+        calls["n"] += 1
+        if calls["n"] == 2:                                        # weights after the one good step
+            snaps["w"] = {k: v.detach().clone() for k, v in snaps["model"].state_dict().items() if v.is_floating_point()}
+        if calls["n"] >= 2:
+            loss = loss * float("inf")
+        return loss, l1, l2
+
+    real_build = tn.build_model
+
+    def build(c, *a, **k):
+        snaps["model"] = real_build(c, *a, **k)
+        return snaps["model"]
+
+    tn.pretrain_loss, tn.build_model = loss_fn, build
+    try:
+        with pytest.raises(RuntimeError, match="Got NaN losses"):
+            tn.train(cfg)
+    finally:
+        tn.pretrain_loss, tn.build_model = real, real_build
+    assert calls["n"] == 4
+    now = snaps["model"].state_dict()
+    for k, v in snaps["w"].items():
+        assert torch.equal(now[k], v), f"{k} was changed by an iteration whose loss was not finite"

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", grad_comm="f32"):
+def _worker(rank, world, port, out_dir, backend="gloo", grad_comm="f32", grad_coll="allreduce"):
     """backend "gloo": both ranks on cuda:0 (one GPU is enough); "nccl": REAL RCCL, rank r on cuda:r
     (tests/test_rccl_multi_gpu.py, needs >= 2 GPUs)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_dir, backend="gloo", grad_comm="f32"):
         return gs.flat[:gs.end].clone()
 
     own = step(None)                                                         # this rank's gradients, no communication
-    reducer = du.GradReducer(vt, grad_comm=grad_comm)
+    reducer = du.GradReducer(vt, grad_comm=grad_comm, grad_coll=grad_coll)
     assert reducer.enabled and vt.engine.grad_hook is not None and dist.get_world_size() == world
     res = []
     for _ in range(vt.engine.GRAPH_WARMUP + 3):                              # eager, eager, capture (staged), replay, replay
@@ -62,10 +62,11 @@ def _worker(rank, world, port, out_dir, backend="gloo", grad_comm="f32"):
 
 
 @pytest.mark.gpu
-def test_two_rank_data_parallel_steps_with_staged_graphs(tmp_path):
+@pytest.mark.parametrize("grad_coll", ["allreduce", "rsag"])
+def test_two_rank_data_parallel_steps_with_staged_graphs(tmp_path, grad_coll):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "gloo", "f32", grad_coll), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert r0["staged"] and r1["staged"], "the backward was not captured as per-block graphs"
