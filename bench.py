@@ -252,6 +252,8 @@ def main():
             # HBM bytes per launch come from the committed PMC passes of THIS configuration (profiles/): configs[1] only
             base_cfg = args.arch == "vit" and args.frames == 8 and B == 32
             out["roofline"]["traffic"] = pmc_traffic(timing["roofline"]["kernel"]) if base_cfg else None
+            if base_cfg:
+                out["roofline"]["traffic_source"] = getattr(pmc_traffic, "note", None)
             if isolated:
                 out["roofline"]["isolated"] = isolated
             out["kernels"] = timing["summary"]
@@ -260,20 +262,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # noqa
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
-        if args.parity_probe and world == 1 and args.arch == "vit":
+        # north_star's tolerance, stated for THIS flavour in THIS line: the default single-GPU run (and --parity-probe) checks 2 clips of
+        # the full-size model against the CPU oracle after the timed region (the oracle is the checker, never the path)
+        default_run = world == 1 and args.arch == "vit" and args.frames == 8 and not args.no_side and not args.no_cpu_baseline
+        if world == 1 and args.arch == "vit" and (args.parity_probe or default_run):
             del model, vt, optimizer, reducer, frames, teacher
             torch.cuda.empty_cache()
             try:
                 out["parity"] = parity_probe()
             except Exception as e:  # noqa
                 out["parity"] = {"error": repr(e)[:200]}
-            args.no_side = True
-        if world == 1 and args.arch == "vit" and args.frames == 8 and not args.no_side and not args.no_cpu_baseline:
+        if default_run:
             # the other single-GPU configurations BASELINE names, timed by the same script in child processes (their own
             # model, graphs and memory): configs[3] long clips (T = 32) and configs[4] MViTv2-S.  Informational: `value` above
             # is the headline metric; a failing side run is reported, never fatal.
-            del model, vt, optimizer, reducer, frames, teacher
-            torch.cuda.empty_cache()
             out["side"] = side_measurements()
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -350,15 +352,34 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def csrc_sha16():
+    """hash of the kernel sources a profile was taken from / the library was built from (tools/summarize_pmc.py stores it)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "procedurevrl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r2_b_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent.
+    (profiles/rN_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction); None when absent OR when the profile was
+    taken from other kernel sources than the ones this run uses (`_meta.csrc_sha16`): stale bytes are not reported.
     A weight-gradient launch = the (grouped) TN kernel + the partial-sum reduces it issues."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r3_traffic.json", "r2_b_traffic.json", "r1_j_traffic.json"))
-                 if os.path.exists(q)), None)
-    if path is None:
+    import re
+    cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_traffic\.json", f)),
+                   key=lambda f: int(f[1:f.index("_")]), reverse=True)
+    if not cands:
         return None
-    t = json.load(open(path))
+    t = json.load(open(os.path.join(ROOT, "profiles", cands[0])))
+    meta = t.pop("_meta", {})
+    if meta.get("csrc_sha16") != csrc_sha16():
+        pmc_traffic.note = f"profiles/{cands[0]} was taken from other kernel sources (csrc sha {meta.get('csrc_sha16')}, now {csrc_sha16()}): re-profile"
+        return None
+    pmc_traffic.note = f"profiles/{cands[0]}"
     epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
     if kernel.startswith("gemm_tn"):
         cands = ([k for k in t if k.startswith("gemm_tn_") and k.endswith("grouped_kernel")] if "grouped" in kernel else
@@ -374,7 +395,7 @@ def pmc_traffic(kernel):
             b += red["hbm_bytes_per_launch"]
         return round(b, 0)
     e = epi.get(kernel[kernel.find("<") + 1:kernel.find(">")], -1)
-    keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},")]
+    keys = [k for k in t if k.startswith(f"gemm_nt_kernel<{e},") or k.startswith(f"gemm_nt8_kernel<{e}>")]
     if not keys:
         return None
     main = max(keys, key=lambda k: t[k]["avg_us"])
@@ -383,20 +404,27 @@ def pmc_traffic(kernel):
 
 def cpu_baseline(args):
     """the CPU restatement of the reference's path (oracle/, pinned to the reference by golden vectors) timed on
-    ALL of this host's cores on BASELINE configs[0] -- 2 videos x 9 clips, the FULL pre-training step (text teacher + order
-    transformer + KL + MSE + AdamW) -- bounded to about a minute; when that does not fit (memory, time) the 4-clip contrastive-only
-    step of earlier rounds.  The checker timed as a reported baseline: never the product, never the target."""
-    from oracle import timesformer_oracle as orc
+    ALL physical cores of this host on BASELINE configs[0] -- 2 videos x 9 clips, the FULL pre-training step (text teacher + order
+    transformer + KL + MSE + AdamW).  Bounded: the sample runs in a child process under a timeout; when it does not finish (eager
+    PyTorch scales badly past a few dozen threads), the 4-clip contrastive-only step of earlier rounds on the same cores.
+    The checker timed as a reported baseline: never the product, never the target."""
+    import subprocess
+    note = ""
     if args.arch == "vit" and args.frames == 8:
+        code = ("import json, sys; sys.path.insert(0, %r); from oracle import timesformer_oracle as orc; "
+                "print('CPUBASE ' + json.dumps(orc.timed_full_step(videos=2, frames=%d, classes=%d, budget_s=25.0)))" % (ROOT, args.frames, args.classes))
         try:
-            return orc.timed_full_step(videos=2, frames=args.frames, classes=args.classes, budget_s=45.0)
-        except Exception as e:  # noqa  (e.g. MemoryError on a small host): fall through to the bounded 4-clip sample
-            note = f"; configs[0] full step failed ({type(e).__name__}), 4-clip contrastive step instead"
-    else:
-        note = ""
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+            line = [l for l in r.stdout.splitlines() if l.startswith("CPUBASE ")]
+            if line:
+                return json.loads(line[-1][len("CPUBASE "):])
+            note = f"; configs[0] full step failed (rc {r.returncode}), 4-clip contrastive step instead"
+        except subprocess.TimeoutExpired:
+            note = "; configs[0] (18 clips, full pre-training step) did not finish one step in 60 s on these cores, 4-clip contrastive step instead"
+    from oracle import timesformer_oracle as orc
     model, phys, logical = orc.host_cpu()
-    r = orc.timed_train_step(clips=max(1, 32 // args.frames), frames=args.frames, classes=args.classes, threads=logical, repeats=2)
-    r["sample"] += f"; {r['cores']} threads of {logical} logical / {phys} physical cores, {model}" + note
+    r = orc.timed_train_step(clips=max(1, 32 // args.frames), frames=args.frames, classes=args.classes, threads=min(phys, logical), repeats=2)
+    r["sample"] += f"; {r['cores']} threads (host: {phys} physical / {logical} logical cores, {model})" + note
     return r
 
 

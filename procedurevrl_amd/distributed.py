@@ -227,9 +227,9 @@ class GradReducer:
         if self.grad_coll == "rsag" and world > 1 and n % world == 0:
             rank = dist.get_rank()
             own = c.view(world, n // world)[rank]
-            if c.is_cuda:      # RCCL: in place (recv = send + rank * count for the reduce-scatter, send = recv + rank * count for the gather)
+            if dist.get_backend() == "nccl":   # RCCL: in place (recv = send + rank * count for the reduce-scatter, send = recv + rank * count for the gather)
                 return [dist.reduce_scatter_tensor(own, c, async_op=True), dist.all_gather_into_tensor(c, own, async_op=True)]
-            shard = torch.empty_like(own)                       # CPU / gloo: through a private shard
+            shard = torch.empty_like(own)                       # gloo (tests): no aliasing guarantees -- through a private shard
             dist.reduce_scatter_tensor(shard, c)
             return [dist.all_gather_into_tensor(c, shard, async_op=True)]
         return [dist.all_reduce(c, async_op=True)]

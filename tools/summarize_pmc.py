@@ -5,6 +5,7 @@ usage: python tools/summarize_pmc.py <fetch.csv> <write.csv> <mfma.csv> <out.csv
 import collections
 import csv
 import json
+import os
 import sys
 
 from summarize_prof import short
@@ -44,6 +45,10 @@ def main():
         wtr.writerow(["kernel", "launches", "avg_us", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "hbm_GBps",
                       "mfma_busy_pct_of_1024_SIMDs"])
         wtr.writerows(rows)
+    # which kernel sources the passes were taken from: bench.py reports `traffic` only while they are the ones it runs
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    traffic["_meta"] = {"csrc_sha16": bench.csrc_sha16()}
     json.dump(traffic, open(sys.argv[5], "w"), indent=1)
 
 
