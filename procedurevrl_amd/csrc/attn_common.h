@@ -111,6 +111,30 @@ __device__ __forceinline__ void load_head_tile(const op_t* base, long ld, int co
   }
 }
 
+// kernel arguments shared by attn_mfma.hip (forward, two-pass backward) and attn_bwd_fused.hip
+struct AttnArgs {
+  const op_t* qkv; long ld;   // packed [rows][3*H*64]: q | k | v, head h at columns h*64
+  int H, nseq;
+  SeqMap mp;
+  float scale;
+  int causal;
+  const unsigned char* kpm;   // [nseq][S], 1 = key masked, or null
+  // forward
+  op_t* o; op_t* o_cls; long ldo;
+  float* lse;                 // [nseq][H][S]
+  // backward
+  const op_t* d_o; const op_t* d_o_cls; const op_t* ofw; const op_t* ofw_cls;
+  float* dvec;                // [nseq][H][S]  rowsum(dO * O)
+  op_t* dqkv; op_t* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
+};
+
+// row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
+template <typename T>
+__device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, const SeqRows& sr, int seq, int j) {
+  if (mp.mode == 1 && j == 0) return cls + (long)seq * ld;
+  return tok + row_of(sr, j) * ld;
+}
+
 __device__ __forceinline__ unsigned pack_opx2(float a, float b) {
   union { opx2 v; unsigned u; } x;
   x.v[0] = (op_t)a; x.v[1] = (op_t)b;

@@ -21,40 +21,26 @@
 // kernel is not latency-bound: an item costs ~8 us of CU time whatever hides its loads -- 700 MFMAs (1.4 us), 43 k exp2
 // (1.3 us at quarter rate), ~6 VALU operations per score (2 us) and 650 KB of LDS fragment reads (3-5 us) that 8-16 waves
 // do not overlap with each other -- 12 items per CU = the 96 us measured (3.3 TB/s is a consequence, not the limit).
-// Round 2 measured a PERSISTENT form of the forward kernel (one workgroup per CU walking its (sequence, head) items, K / V in two
-// LDS slots filled by LDS-DMA one item ahead, counted vmcnt so output stores are not waited for; 8 waves sharing each K / V
-// fragment between two query tiles, or 16 waves): 121-127 us and 157 us against 100 us for this kernel at 3,072 items.  The
-// kernel is not latency-bound: an item costs ~8 us of CU time whatever hides its loads -- 700 MFMAs (1.4 us), 43 k exp2
-// (1.3 us at quarter rate), ~6 VALU operations per score (2 us) and 650 KB of LDS fragment reads (3-5 us) that 8-16 waves
-// do not overlap with each other -- 12 items per CU = the 96 us measured (3.3 TB/s is a consequence, not the limit).
 // The number of 16-key tiles NKT is a template parameter (1, 2, 3, 5, 13): every loop over keys is
 // straight-line code the compiler can software-pipeline (a run-time tile count cost 5x in branches).
 #include "attn_common.h"
 #include "../../include/pvrl.h"
+#include <stdlib.h>
+
+// attn_bwd_fused.hip: the one-kernel backward for 80 < S <= 224 without masks
+bool pvrl_attn_bwd_fused_ok(const AttnArgs& p);
+int pvrl_attn_bwd_fused_launch(const AttnArgs& p, hipStream_t s);
 
 namespace {
 
-struct AttnArgs {
-  const op_t* qkv; long ld;   // packed [rows][3*H*64]: q | k | v, head h at columns h*64
-  int H, nseq;
-  SeqMap mp;
-  float scale;
-  int causal;
-  const unsigned char* kpm;   // [nseq][S], 1 = key masked, or null
-  // forward
-  op_t* o; op_t* o_cls; long ldo;
-  float* lse;                 // [nseq][H][S]
-  // backward
-  const op_t* d_o; const op_t* d_o_cls; const op_t* ofw; const op_t* ofw_cls;
-  float* dvec;                // [nseq][H][S]  rowsum(dO * O)
-  op_t* dqkv; op_t* dqkv_cls; long ldd;   // dqkv_cls: [nseq][3*H*64] partial rows for token 0 (mode 1)
-};
-
-// row pointer helpers for per-token outputs / inputs that keep token 0 in a side buffer (mode 1)
-template <typename T>
-__device__ __forceinline__ T* tok_ptr(T* tok, T* cls, long ld, const SeqMap& mp, const SeqRows& sr, int seq, int j) {
-  if (mp.mode == 1 && j == 0) return cls + (long)seq * ld;
-  return tok + row_of(sr, j) * ld;
+// PVRL_ATTN_BWD_FUSED=0 sends every case back to the two-pass kernels (A/B runs); read once
+int attn_bwd_fused_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_ATTN_BWD_FUSED");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
+  }
+  return on;
 }
 
 // key-padding bits of the 4*NKT keys a lane owns in the "lane = query" layout (key = 16 kt + 4 q4 + r)
@@ -582,6 +568,7 @@ extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (!o || !d_o || !lse || !dvec || !dqkv || (ldo % 8) || (ldd % 4)) return PVRL_EINVAL;
   if (mode == 1 && (!o_cls || !d_o_cls || !dqkv_cls)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (attn_bwd_fused_enabled() && pvrl_attn_bwd_fused_ok(p)) return pvrl_attn_bwd_fused_launch(p, s);
   if (S <= 16) return launch_bwd<1, 4>(p, s);
   if (S <= 32) return launch_bwd<2, 4>(p, s);
   if (S <= 48) return launch_bwd<3, 4>(p, s);

@@ -1,0 +1,116 @@
+"""Spatial attention backward, fused (one kernel) vs two-pass, at the benchmark geometry (32 clips x 8 frames x 12 heads, S = 197).
+
+  python tools/probe/attn_bwd_ab.py check        parity of both forms against fp32 math (tests/kernel_checks.py cases)
+  python tools/probe/attn_bwd_ab.py time         event-timed forward / backward, each arm in its own process (the switch is read once)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timeit(fn, reps=30, warm=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def arm():
+    import torch
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.ops import OP16
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    for (B, T, N, H) in [(32, 8, 196, 12)]:
+        HD = H * 64; S = N + 1; R = B * N * T; nseq = B * T
+        sets = []
+        for _ in range(3):      # cycle operand sets so L2 / MALL do not serve the re-reads
+            qkv = torch.randn(R + B, 3 * HD, device=dev, generator=g).to(OP16)
+            obuf = torch.zeros(R + nseq, HD, device=dev, dtype=OP16)
+            do = torch.randn(R + nseq, HD, device=dev, generator=g).to(OP16)
+            dbuf = torch.zeros(R + B + nseq, 3 * HD, device=dev, dtype=OP16)
+            _, _, lse = ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
+            sets.append((qkv, obuf, do, dbuf, lse))
+        k = [0]
+
+        def fwd():
+            qkv, obuf, do, dbuf, lse = sets[k[0] % 3]; k[0] += 1
+            ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:], lse=lse)
+
+        def bwd():
+            qkv, obuf, do, dbuf, lse = sets[k[0] % 3]; k[0] += 1
+            ops.attn_bwd(qkv, obuf[:R], obuf[R:], do[:R], do[R:], lse, nseq, S, H, 0.125, mode=1, T=T, cls_base=R,
+                         dqkv=dbuf[:R + B], dqkv_cls=dbuf[R + B:])
+        tf = [timeit(fwd) for _ in range(3)]
+        tb = [timeit(bwd) for _ in range(3)]
+        print(f"  B={B} T={T} S={S} H={H}: fwd {min(tf):7.1f} us   bwd {min(tb):7.1f} us   (runs: fwd {tf}, bwd {tb})", flush=True)
+
+
+def trace():
+    """PVRL_LIB_PATH = a -DPVRL_FB_TRACE=1 build: cycle stamps of every wave of workgroup 8 (dumped through the dvec argument)."""
+    import torch
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.ops import OP16, _ptr, _ld, _stream
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    B, T, N, H = 32, 8, 196, 12
+    HD = H * 64; S = N + 1; R = B * N * T; nseq = B * T
+    qkv = torch.randn(R + B, 3 * HD, device=dev, generator=g).to(OP16)
+    obuf = torch.zeros(R + nseq, HD, device=dev, dtype=OP16)
+    do = torch.randn(R + nseq, HD, device=dev, generator=g).to(OP16)
+    dbuf = torch.zeros(R + B + nseq, 3 * HD, device=dev, dtype=OP16)
+    _, _, lse = ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
+    dvec = torch.zeros_like(lse)
+    for _ in range(3):
+        L.call("pvrl_attn_bwd", _ptr(qkv), _ld(qkv), nseq, S, H, 1, T, R, 0.125, 0, None, _ptr(obuf[:R]), _ptr(obuf[R:]),
+               _ptr(do[:R]), _ptr(do[R:]), _ld(obuf), _ptr(lse), _ptr(dvec), _ptr(dbuf[:R + B]), _ptr(dbuf[R + B:]), _ld(dbuf), _stream())
+    torch.cuda.synchronize()
+    st = dvec.view(-1)[:8 * 64 * 2].view(torch.int64).view(8, 8, 8).cpu()
+    t0 = int(st[:, 7, 0].min())
+    print("cycles since the first wave's entry; per block: key waves [top | S,dP issued | P,dS done | dK,dV + dS stores issued | barrier passed], dQ wave [at barrier | passed | block done]")
+    for w in range(8):
+        k = st[w, 7] - t0
+        print(f"wave {w}: entry {int(k[0])} loads issued {int(k[1])} prologue done {int(k[2])} barrier passed {int(k[3])} exit {int(k[4])}")
+        for jb in range(7):
+            r = st[w, jb] - t0
+            n = 3 if w == 7 else 5
+            print(f"    jb {jb}: " + " ".join(f"{int(r[i]):7d}" for i in range(n)) + "   d: " + " ".join(f"{int(r[i + 1] - r[i]):5d}" for i in range(n - 1)))
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "time"
+    if mode == "arm":
+        return arm()
+    if mode == "trace":
+        return trace()
+    if mode == "check":
+        import kernel_checks as kc
+        bad = 0
+        for fn in (kc.check_attn_mfma_contig, kc.check_attn_mfma_spatial):
+            for name, err, tol in fn():
+                flag = "ok " if err <= tol else "BAD"
+                bad += err > tol
+                print(f"  {flag} {name:50s} err {err:.3e} tol {tol:.1e}")
+        print("CHECK", "OK" if not bad else f"FAILED ({bad})")
+        return
+    for tag, val in (("two-pass", "0"), ("fused", "1"), ("two-pass", "0"), ("fused", "1")):
+        env = dict(os.environ, PVRL_ATTN_BWD_FUSED=val)
+        print(f"--- {tag} (PVRL_ATTN_BWD_FUSED={val})", flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "arm"], env=env, check=False)
+
+
+if __name__ == "__main__":
+    main()
