@@ -78,15 +78,16 @@ def trace():
         L.call("pvrl_attn_bwd", _ptr(qkv), _ld(qkv), nseq, S, H, 1, T, R, 0.125, 0, None, _ptr(obuf[:R]), _ptr(obuf[R:]),
                _ptr(do[:R]), _ptr(do[R:]), _ld(obuf), _ptr(lse), _ptr(dvec), _ptr(dbuf[:R + B]), _ptr(dbuf[R + B:]), _ld(dbuf), _stream())
     torch.cuda.synchronize()
-    st = dvec.view(-1)[:8 * 64 * 2].view(torch.int64).view(8, 8, 8).cpu()
+    st = dvec.view(-1)[:8 * 64].view(torch.int32).view(8, 8, 8).cpu().to(torch.int64) & 0xffffffff
     t0 = int(st[:, 7, 0].min())
-    print("cycles since the first wave's entry; per block: key waves [top | S,dP issued | P,dS done | dK,dV + dS stores issued | barrier passed], dQ wave [at barrier | passed | block done]")
+    print("second item of workgroup 8; cycles since the first wave left the item seam; per block: key waves [top | S,dP issued | P,dS done | dK,dV + dS stores issued | barrier passed], "
+          "dQ wave [at barrier | passed | start values of a streamed slot written | block done]")
     for w in range(8):
         k = st[w, 7] - t0
-        print(f"wave {w}: entry {int(k[0])} loads issued {int(k[1])} prologue done {int(k[2])} barrier passed {int(k[3])} exit {int(k[4])}")
+        print(f"wave {w} ({'dQ wave' if w == 7 else 'key wave'}): seam left {int(k[0])}  item done {int(k[4])}")
         for jb in range(7):
             r = st[w, jb] - t0
-            n = 3 if w == 7 else 5
+            n = 4 if w == 7 else 5
             print(f"    jb {jb}: " + " ".join(f"{int(r[i]):7d}" for i in range(n)) + "   d: " + " ".join(f"{int(r[i + 1] - r[i]):5d}" for i in range(n - 1)))
 
 
