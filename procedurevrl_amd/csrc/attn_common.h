@@ -28,6 +28,7 @@ __device__ __forceinline__ long seq_row(const SeqMap& mp, int seq, int j) {
 constexpr int ATT_MAX_TILES = 13;               // S <= 208
 constexpr int ATT_ROWS = ATT_MAX_TILES * 16;    // 208
 constexpr int ATT_ROWS_PAD = 224;               // rounded to 32 for the K=32 MFMA steps
+constexpr int ATT_ROWS_LONG = 26 * 16;          // 416: the long-sequence instantiations of the same kernels (NKT = 17, 26)
 constexpr int ATT_RM_BYTES = ATT_ROWS_PAD * 128;  // row-major [224][64] bf16 tile, 28 KiB
 constexpr int ATT_BL_BYTES = ATT_ROWS_PAD * 128;  // blocked [56][4][4][16] bf16 tile, 28 KiB
 

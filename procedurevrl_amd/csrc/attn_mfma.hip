@@ -1,4 +1,5 @@
-// Multi-head self-attention (head_dim 64) on MFMA, forward + backward, S <= 208 tokens.
+// Multi-head self-attention (head_dim 64) on MFMA, forward + backward, S <= 416 tokens (tuned for S <= 208; the reference takes any
+// crop through its pos-embed resize, lib/models/vit.py:374-386 -- 256^2 gives 257 tokens, 320^2 gives 401).
 //
 // Reference semantics: Attention.forward, lib/models/vit.py:75-92
 //     attn = softmax((q @ k^T) * scale);  x = attn @ v
@@ -63,13 +64,13 @@ __device__ __forceinline__ unsigned long long pad_bits_q(const AttnArgs& p, int 
 
 // Cooperative load of one head slice [S rows][64] of a packed activation into the blocked LDS image, in two halves so a
 // kernel can put EVERY global load it needs (both tiles + its waves' own fragments) in flight before the first wait.
-template <int NT>
-struct TileRegs { u32x4 v[(ATT_ROWS_PAD * 8 + NT - 1) / NT]; };
+template <int NT, int ROWS = ATT_ROWS_PAD>
+struct TileRegs { u32x4 v[(ROWS * 8 + NT - 1) / NT]; };
 
-template <int NT>
-__device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const op_t* base, long ld, int col0, const SeqRows& sr, int S,
+template <int NT, int ROWS = ATT_ROWS_PAD>
+__device__ __forceinline__ void tile_issue(TileRegs<NT, ROWS>& t, const op_t* base, long ld, int col0, const SeqRows& sr, int S,
                                            const op_t* src0, int rows, int tid) {
-  constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
+  constexpr int ITERS = (ROWS * 8 + NT - 1) / NT;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + NT * it;
@@ -93,9 +94,9 @@ __device__ __forceinline__ void tile_issue(TileRegs<NT>& t, const op_t* base, lo
 #endif
   }
 }
-template <int NT>
-__device__ __forceinline__ void tile_commit(const TileRegs<NT>& t, char* bl, int rows, int tid) {
-  constexpr int ITERS = (ATT_ROWS_PAD * 8 + NT - 1) / NT;
+template <int NT, int ROWS = ATT_ROWS_PAD>
+__device__ __forceinline__ void tile_commit(const TileRegs<NT, ROWS>& t, char* bl, int rows, int tid) {
+  constexpr int ITERS = (ROWS * 8 + NT - 1) / NT;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + NT * it;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void tile_commit(const TileRegs<NT>& t, char* bl, int
 // forward
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW, int SC = 0>
-__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NKT > 13 ? 2 : (NW + 1) / 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * BL];
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
     qf[t][1] = *reinterpret_cast<const opx8*>(qp + 32);
   }
   {
-    TileRegs<64 * NW> kr, vr;
-    tile_issue<64 * NW>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
-    tile_issue<64 * NW>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
-    tile_commit<64 * NW>(kr, Kb, NKS2 * 32, tid);
-    tile_commit<64 * NW>(vr, Vb, NKS2 * 32, tid);
+    TileRegs<64 * NW, NKS2 * 32> kr, vr;
+    tile_issue<64 * NW, NKS2 * 32>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_issue<64 * NW, NKS2 * 32>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_commit<64 * NW, NKS2 * 32>(kr, Kb, NKS2 * 32, tid);
+    tile_commit<64 * NW, NKS2 * 32>(vr, Vb, NKS2 * 32, tid);
   }
   __syncthreads();
 
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_fwd_kernel(AttnArg
 // backward, pass 1: dQ (and D = rowsum(dO * O)); waves own query tiles exactly as in the forward.
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW, int SC = 0>
-__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NKT > 13 ? 2 : (NW + 1) / 2) void attn_bwd_q_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int BL = NKS2 * 32 * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * BL];
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
       of[t][1] = *reinterpret_cast<const opx8*>(ofp + 32);
       lse2[t] = p.lse[((long)seq * p.H + h) * S + qj] * 1.4426950408889634f;
     }
-    TileRegs<64 * NW> kr, vr;
-    tile_issue<64 * NW>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
-    tile_issue<64 * NW>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    TileRegs<64 * NW, NKS2 * 32> kr, vr;
+    tile_issue<64 * NW, NKS2 * 32>(kr, p.qkv, p.ld, HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
+    tile_issue<64 * NW, NKS2 * 32>(vr, p.qkv, p.ld, 2 * HD + h * 64, sr, S, nullptr, NKS2 * 32, tid);
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       float dsum = 0.f;
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
       const int query = (wave + t * NW) * 16 + i;
       if (q4 == 0 && query < S) p.dvec[((long)seq * p.H + h) * S + query] = dsum;
     }
-    tile_commit<64 * NW>(kr, Kb, NKS2 * 32, tid);
-    tile_commit<64 * NW>(vr, Vb, NKS2 * 32, tid);
+    tile_commit<64 * NW, NKS2 * 32>(kr, Kb, NKS2 * 32, tid);
+    tile_commit<64 * NW, NKS2 * 32>(vr, Vb, NKS2 * 32, tid);
   }
   __syncthreads();
 
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_q_kernel(AttnA
 // Needs lse and dvec from the forward / pass 1.
 // ------------------------------------------------------------------------------------------
 template <int NKT, bool GEN, int NW, int SC = 0>
-__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NKT > 13 ? 2 : (NW + 1) / 2) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int NKS2 = (NKT + 1) / 2;
   constexpr int ROWS = NKS2 * 32;
   constexpr int T = ROWS * 128;
@@ -406,16 +407,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
   }
   {
     const op_t* src0 = p.mp.mode == 1 ? p.d_o_cls + (long)seq * p.ldo : nullptr;   // dO of token 0 lives in the side buffer
-    TileRegs<64 * NW> qr, dr;
-    tile_issue<64 * NW>(qr, p.qkv, p.ld, h * 64, sr, S, nullptr, ROWS, tid);
-    tile_issue<64 * NW>(dr, p.d_o, p.ldo, h * 64, sr, S, src0, ROWS, tid);
+    TileRegs<64 * NW, ROWS> qr, dr;
+    tile_issue<64 * NW, ROWS>(qr, p.qkv, p.ld, h * 64, sr, S, nullptr, ROWS, tid);
+    tile_issue<64 * NW, ROWS>(dr, p.d_o, p.ldo, h * 64, sr, S, src0, ROWS, tid);
     for (int idx = tid; idx < ROWS; idx += 64 * NW) {
       const long stat = ((long)seq * p.H + h) * S + idx;
       lse_s[idx] = idx < S ? p.lse[stat] * 1.4426950408889634f : 0.f;
       dv_s[idx] = idx < S ? p.dvec[stat] * p.scale : 0.f;
     }
-    tile_commit<64 * NW>(qr, Qb, ROWS, tid);
-    tile_commit<64 * NW>(dr, Db, ROWS, tid);
+    tile_commit<64 * NW, ROWS>(qr, Qb, ROWS, tid);
+    tile_commit<64 * NW, ROWS>(dr, Db, ROWS, tid);
   }
   __syncthreads();
 
@@ -486,9 +487,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void attn_bwd_kv_kernel(Attn
 }
 
 int check_common(const AttnArgs& p) {
-  if (!p.qkv || p.H <= 0 || p.nseq < 0 || p.mp.S <= 0 || p.mp.S > ATT_ROWS) return PVRL_EINVAL;
+  if (!p.qkv || p.H <= 0 || p.nseq < 0 || p.mp.S <= 0 || p.mp.S > ATT_ROWS_LONG) return PVRL_EINVAL;
   if ((p.ld % 8)) return PVRL_EINVAL;
   if (p.mp.mode == 1 && (p.mp.T <= 0 || (p.nseq % p.mp.T))) return PVRL_EINVAL;
+  if ((p.causal || p.kpm) && p.mp.S > ATT_ROWS) return PVRL_EINVAL;      // the masked forms keep their key bits in one 64-bit word per 16 tiles
   return PVRL_OK;
 }
 
@@ -549,7 +551,10 @@ extern "C" int pvrl_attn_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (S <= 32) return launch_fwd<2, 4>(p, s);
   if (S <= 48) return launch_fwd<3, 4>(p, s);
   if (S <= 80) return launch_fwd<5, 4>(p, s);
-  return launch_fwd<13, 8>(p, s);
+  if (S <= 208) return launch_fwd<13, 8>(p, s);
+  // longer crops (256^2 -> 257 tokens, 320^2 -> 401): the same kernels with more key tiles, one 8-wave workgroup per CU
+  if (S <= 272) return launch_fwd<17, 8>(p, s);
+  return launch_fwd<26, 8>(p, s);
 }
 
 extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int mode, int64_t T,
@@ -573,5 +578,7 @@ extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (S <= 32) return launch_bwd<2, 4>(p, s);
   if (S <= 48) return launch_bwd<3, 4>(p, s);
   if (S <= 80) return launch_bwd<5, 4>(p, s);
-  return launch_bwd<13, 8>(p, s);
+  if (S <= 208) return launch_bwd<13, 8>(p, s);
+  if (S <= 272) return launch_bwd<17, 8>(p, s);
+  return launch_bwd<26, 8>(p, s);
 }

@@ -364,6 +364,12 @@ def check_train_step_t32_full_res():
     return _hip_vs_oracle(2, 224, 512, 1, frames=32, seed=13, tag="T=32 224^2: ", rounding_model=False)
 
 
+def check_train_step_crop256():
+    """A 256^2 crop (257 spatial tokens per frame -- the reference runs any crop, lib/models/vit.py:374-386): one training step
+    of a 2-block model vs the oracle; spatial attention takes the long-sequence instantiation of the MFMA kernels."""
+    return _hip_vs_oracle(2, 256, 128, 1, seed=19, tag="256^2 crop: ", rounding_model=False)
+
+
 def check_timed_config_train_step():
     """The benchmark's OWN configuration -- 32 clips of 8x224^2, 12 blocks, K = 9871 (BASELINE configs[1]) -- one training
     step (forward, step logits, top-5 KL loss, backward) against the oracle run in micro-batches on the host cores:
@@ -611,5 +617,5 @@ def check_hip_graph_replay():
 
 
 ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
-              check_train_step_t4, check_train_step_t32, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
+              check_train_step_t4, check_train_step_t32, check_train_step_crop256, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
               check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step]

@@ -342,7 +342,10 @@ def check_attn_mfma_contig():
     g = torch.Generator().manual_seed(6)
     out = []
     for (nseq, S, H, causal, pad) in [(5, 77, 8, True, False), (6, 9, 8, False, True), (3, 197, 12, False, False),
-                                      (4, 32, 12, False, False), (2, 208, 2, False, False), (3, 16, 2, True, True)]:
+                                      (4, 32, 12, False, False), (2, 208, 2, False, False), (3, 16, 2, True, True),
+                                      # longer crops: 224 (fused backward's last size), 257 = 256^2 / 16^2 + cls, 401 = 320^2
+                                      (2, 224, 2, False, False), (2, 257, 2, False, False), (1, 401, 2, False, False),
+                                      (3, 100, 2, False, False), (2, 150, 3, False, False)]:
         HD = H * 64
         qkv = torch.randn(nseq * S, 3 * HD, generator=g)
         qb = bf(qkv).view(nseq, S, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
@@ -381,7 +384,9 @@ def check_attn_mfma_spatial():
     out = []
     # (11, 8, 196, 12): 88 sequences x 12 heads = 1,056 (sequence, head) items -> the persistent LDS-DMA forward kernel,
     # ragged over the 256 workgroups (some walk 5 items, some 4) and over the XCDs (11 sequences each)
-    for (B, T, N, H) in [(2, 4, 16, 2), (2, 8, 196, 12), (11, 8, 196, 12)]:
+    # (1, 2, 256, 2): a 256^2 crop's 257-token spatial sequences (long-sequence instantiation of the two-pass kernels);
+    # (3, 4, 120, 2): 121 tokens -> four query blocks in the fused backward's run-time-loop form, 12 sequences x 2 heads
+    for (B, T, N, H) in [(2, 4, 16, 2), (2, 8, 196, 12), (11, 8, 196, 12), (1, 2, 256, 2), (3, 4, 120, 2)]:
         HD = H * 64
         S = N + 1
         R = B * N * T
