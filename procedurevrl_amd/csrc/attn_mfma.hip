@@ -28,7 +28,7 @@
 #include "../../include/pvrl.h"
 #include <stdlib.h>
 
-// attn_bwd_fused.hip: the one-kernel backward for 80 < S <= 224 without masks
+// attn_bwd_fused.hip: the persistent, LDS-DMA-streamed one-kernel backward for 96 < S <= 224 without masks
 bool pvrl_attn_bwd_fused_ok(const AttnArgs& p);
 int pvrl_attn_bwd_fused_launch(const AttnArgs& p, hipStream_t s);
 
