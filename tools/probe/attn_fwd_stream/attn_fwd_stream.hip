@@ -14,6 +14,9 @@
 //     O           transposed through this wave's 4 KB of LDS and stored as whole 128-byte rows (8 rows per instruction)
 //   one barrier per item.
 // 140 KB of LDS (2 x (K + V) images + 7 x 4 KB of staging), <= 256 registers, one workgroup per CU.
+// (probe, not part of the library: to measure it again, copy the file next to csrc/attn_stream.h, add the two declarations +
+//  `if (pvrl_attn_fwd_stream_ok(p)) return pvrl_attn_fwd_stream_launch(p, s);` in front of pvrl_attn_fwd's size dispatch in
+//  csrc/attn_mfma.hip, build; result and trace: profiles/r4_attn_bwd_fused.txt section 7)
 #include "attn_stream.h"
 #include "../../include/pvrl.h"
 #include <stdlib.h>
