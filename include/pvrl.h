@@ -123,7 +123,8 @@ int pvrl_attn_t8_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t H, float
  * tfm_model.py:43-48 with key_padding_mask; CLIP text causal mask).  S <= 416 without masks (the reference takes any crop
  * through its pos-embed resize, vit.py:374-386: 224^2 -> 197 tokens, 256^2 -> 257, 320^2 -> 401), S <= 208 with a causal /
  * key-padding mask; PVRL_EINVAL beyond.  The backward of 96 < S <= 224 without masks and with a power-of-two `scale` is ONE
- * persistent kernel (csrc/attn_bwd_fused.hip; PVRL_ATTN_BWD_FUSED=0 selects the two-pass kernels); `dvec` is then unused.
+ * persistent kernel (csrc/attn_bwd_fused.hip; PVRL_ATTN_BWD_FUSED=0 selects the two-pass kernels), that of 16 < S <= 32 contiguous
+ * tokens one wave per (sequence, head) (csrc/attn_bwd_s32.hip; PVRL_ATTN_BWD_S32=0); `dvec` is then unused.
  * mode 0: row(seq, j) = seq*S + j.   mode 1 (TimeSformer spatial, seq = b*T + t): token 0 = cls row
  * cls_base + b, token j>=1 = row b*(S-1)*T + (j-1)*T + t; token-0 outputs go to the *_cls side buffers
  * ([nseq] rows).  lse/dvec: [nseq][H][S] fp32. */

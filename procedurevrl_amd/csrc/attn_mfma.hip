@@ -31,6 +31,9 @@
 // attn_bwd_fused.hip: the persistent, LDS-DMA-streamed one-kernel backward for 96 < S <= 224 without masks
 bool pvrl_attn_bwd_fused_ok(const AttnArgs& p);
 int pvrl_attn_bwd_fused_launch(const AttnArgs& p, hipStream_t s);
+// attn_bwd_s32.hip: one wave per (sequence, head) for 16 < S <= 32 contiguous tokens without masks (temporal attention at 32 frames)
+bool pvrl_attn_bwd_s32_ok(const AttnArgs& p);
+int pvrl_attn_bwd_s32_launch(const AttnArgs& p, hipStream_t s);
 
 namespace {
 
@@ -574,6 +577,7 @@ extern "C" int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t 
   if (mode == 1 && (!o_cls || !d_o_cls || !dqkv_cls)) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (attn_bwd_fused_enabled() && pvrl_attn_bwd_fused_ok(p)) return pvrl_attn_bwd_fused_launch(p, s);
+  if (pvrl_attn_bwd_s32_ok(p)) return pvrl_attn_bwd_s32_launch(p, s);
   if (S <= 16) return launch_bwd<1, 4>(p, s);
   if (S <= 32) return launch_bwd<2, 4>(p, s);
   if (S <= 48) return launch_bwd<3, 4>(p, s);

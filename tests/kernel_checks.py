@@ -345,7 +345,9 @@ def check_attn_mfma_contig():
                                       (4, 32, 12, False, False), (2, 208, 2, False, False), (3, 16, 2, True, True),
                                       # longer crops: 224 (fused backward's last size), 257 = 256^2 / 16^2 + cls, 401 = 320^2
                                       (2, 224, 2, False, False), (2, 257, 2, False, False), (1, 401, 2, False, False),
-                                      (3, 100, 2, False, False), (2, 150, 3, False, False)]:
+                                      (3, 100, 2, False, False), (2, 150, 3, False, False),
+                                      # one-wave-per-item backward (16 < S <= 32): ragged sequence lengths, more items than one workgroup's four
+                                      (7, 24, 3, False, False), (5, 17, 2, False, False), (130, 32, 12, False, False)]:
         HD = H * 64
         qkv = torch.randn(nseq * S, 3 * HD, generator=g)
         qb = bf(qkv).view(nseq, S, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)

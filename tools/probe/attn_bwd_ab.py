@@ -57,6 +57,35 @@ def arm():
         print(f"  B={B} T={T} S={S} H={H}: fwd {min(tf):7.1f} us   bwd {min(tb):7.1f} us   (runs: fwd {tf}, bwd {tb})", flush=True)
 
 
+def arm32():
+    """temporal attention at 32 frames (BASELINE configs[3]): 8 clips x 196 patches = 1,568 contiguous sequences of 32 tokens, 12 heads"""
+    import torch
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.ops import OP16
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    nseq, S, H = 8 * 196, 32, 12
+    HD = H * 64
+    sets = []
+    for _ in range(3):
+        qkv = torch.randn(nseq * S, 3 * HD, device=dev, generator=g).to(OP16)
+        do = torch.randn(nseq * S, HD, device=dev, generator=g).to(OP16)
+        o, _, lse = ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=0)
+        sets.append((qkv, o, do, torch.empty_like(qkv), lse))
+    k = [0]
+
+    def fwd():
+        qkv, o, do, dq, lse = sets[k[0] % 3]; k[0] += 1
+        ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=0, o=o, lse=lse)
+
+    def bwd():
+        qkv, o, do, dq, lse = sets[k[0] % 3]; k[0] += 1
+        ops.attn_bwd(qkv, o, None, do, None, lse, nseq, S, H, 0.125, mode=0, dqkv=dq)
+    tf = [timeit(fwd) for _ in range(3)]
+    tb = [timeit(bwd) for _ in range(3)]
+    print(f"  nseq={nseq} S={S} H={H}: fwd {min(tf):7.1f} us   bwd {min(tb):7.1f} us", flush=True)
+
+
 def trace():
     """PVRL_LIB_PATH = a -DPVRL_FB_TRACE=1 build: cycle stamps of every wave of workgroup 8 (dumped through the dvec argument)."""
     import torch
@@ -95,6 +124,14 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "time"
     if mode == "arm":
         return arm()
+    if mode == "arm32":
+        return arm32()
+    if mode == "time32":
+        for tag, val in (("two-pass", "0"), ("one wave per item", "1"), ("two-pass", "0"), ("one wave per item", "1")):
+            env = dict(os.environ, PVRL_ATTN_BWD_S32=val)
+            print(f"--- {tag} (PVRL_ATTN_BWD_S32={val})", flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "arm32"], env=env, check=False)
+        return
     if mode == "trace":
         return trace()
     if mode == "check":
