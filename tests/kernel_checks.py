@@ -423,6 +423,43 @@ def check_attn_mfma_spatial():
     return out
 
 
+def check_attn_bwd_repeatable():
+    """The persistent (S = 197, mode 1) and the one-wave (S = 32, mode 0) backward kernels stream their operands with counted waits
+    and no workgroup-wide drains: launched repeatedly next to an uneven load on a second stream, every result must be BIT-identical
+    to the first (a race on an LDS image or a wait that is one short shows as a run-to-run difference)."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(21)
+    out = []
+    burn = torch.randn(4096, 4096, device=dev())
+    side = torch.cuda.Stream()
+    for (B, T, N, H, mode) in [(8, 8, 196, 12, 1), (392, 1, 31, 12, 0)]:
+        HD = H * 64
+        if mode == 1:
+            S = N + 1; R = B * N * T; nseq = B * T
+            qd = torch.randn(R + B, 3 * HD, generator=g).to(dev(), BF)
+            obuf = torch.zeros(R + nseq, HD, device=dev(), dtype=BF)
+            dod = torch.randn(R + nseq, HD, generator=g).to(dev(), BF)
+            _, _, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
+            run = lambda: ops.attn_bwd(qd, obuf[:R], obuf[R:], dod[:R], dod[R:], lse, nseq, S, H, 0.125, mode=1, T=T, cls_base=R)
+        else:
+            nseq, S = B, N + 1
+            qd = torch.randn(nseq * S, 3 * HD, generator=g).to(dev(), BF)
+            dod = torch.randn(nseq * S, HD, generator=g).to(dev(), BF)
+            o, _, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=0)
+            run = lambda: ops.attn_bwd(qd, o, None, dod, None, lse, nseq, S, H, 0.125, mode=0)
+        ref = [x.clone() for x in run() if x is not None]
+        diff = 0
+        for it in range(8):
+            if it % 3 != 0:
+                with torch.cuda.stream(side):
+                    burn @ burn
+            res = [x for x in run() if x is not None]
+            diff += sum(int(not torch.equal(a.view(torch.int16), b.view(torch.int16))) for a, b in zip(ref, res))
+        torch.cuda.synchronize()
+        out.append((f"attn bwd S={S} mode {mode}: launches that differ from the first (of 8)", float(diff), 0.0))
+    return out
+
+
 def check_elementwise():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(8)
@@ -576,4 +613,4 @@ def check_input_pipeline():
 
 
 ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
-              check_attn_mfma_contig, check_attn_mfma_spatial, check_elementwise, check_loss]
+              check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]

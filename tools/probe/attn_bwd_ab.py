@@ -86,6 +86,46 @@ def arm32():
     print(f"  nseq={nseq} S={S} H={H}: fwd {min(tf):7.1f} us   bwd {min(tb):7.1f} us", flush=True)
 
 
+def race(n=30):
+    """the fused / one-wave backward kernels launched n times next to an uneven load: a race on the streamed LDS images (or a counted
+    wait that is one short) shows as a run-to-run difference; every result is compared bit for bit with the first"""
+    import torch
+    from procedurevrl_amd import ops
+    from procedurevrl_amd.ops import OP16
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(3)
+    bad = 0
+    burn = torch.randn(8192, 8192, device=dev)
+    side = torch.cuda.Stream()
+    for (B, T, N, H, mode) in [(32, 8, 196, 12, 1), (5, 4, 120, 3, 1), (1568, 1, 31, 12, 0)]:
+        HD = H * 64
+        if mode == 1:
+            S = N + 1; R = B * N * T; nseq = B * T
+            qkv = torch.randn(R + B, 3 * HD, device=dev, generator=g).to(OP16)
+            obuf = torch.zeros(R + nseq, HD, device=dev, dtype=OP16)
+            do = torch.randn(R + nseq, HD, device=dev, generator=g).to(OP16)
+            _, _, lse = ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
+            run = lambda: ops.attn_bwd(qkv, obuf[:R], obuf[R:], do[:R], do[R:], lse, nseq, S, H, 0.125, mode=1, T=T, cls_base=R)
+        else:
+            nseq, S = B, N + 1
+            qkv = torch.randn(nseq * S, 3 * HD, device=dev, generator=g).to(OP16)
+            do = torch.randn(nseq * S, HD, device=dev, generator=g).to(OP16)
+            o, _, lse = ops.attn_fwd(qkv, nseq, S, H, 0.125, mode=0)
+            run = lambda: ops.attn_bwd(qkv, o, None, do, None, lse, nseq, S, H, 0.125, mode=0)
+        ref = [x.clone() if x is not None else None for x in run()]
+        for it in range(n):
+            if it % 3 != 0:
+                with torch.cuda.stream(side):
+                    burn @ burn                     # uneven load on another stream next to the launch
+            out = run()
+            for a, b in zip(ref, out):
+                if a is not None and not torch.equal(a.view(torch.int16), b.view(torch.int16)):
+                    bad += 1
+        torch.cuda.synchronize()
+        print(f"race B={B} T={T} S={N + 1} H={H} mode {mode}: {n} launches, mismatching so far {bad}", flush=True)
+    print("RACE", "FAILED" if bad else "OK", flush=True)
+
+
 def trace():
     """PVRL_LIB_PATH = a -DPVRL_FB_TRACE=1 build: cycle stamps of every wave of workgroup 8 (dumped through the dvec argument)."""
     import torch
@@ -126,6 +166,8 @@ def main():
         return arm()
     if mode == "arm32":
         return arm32()
+    if mode == "race":
+        return race()
     if mode == "time32":
         for tag, val in (("two-pass", "0"), ("one wave per item", "1"), ("two-pass", "0"), ("one wave per item", "1")):
             env = dict(os.environ, PVRL_ATTN_BWD_S32=val)
