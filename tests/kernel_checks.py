@@ -440,13 +440,16 @@ def check_attn_bwd_repeatable():
             obuf = torch.zeros(R + nseq, HD, device=dev(), dtype=BF)
             dod = torch.randn(R + nseq, HD, generator=g).to(dev(), BF)
             _, _, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=1, T=T, cls_base=R, o=obuf[:R], o_cls=obuf[R:])
-            run = lambda: ops.attn_bwd(qd, obuf[:R], obuf[R:], dod[:R], dod[R:], lse, nseq, S, H, 0.125, mode=1, T=T, cls_base=R)
+            # (explicit zeroed outputs: the kernel leaves the cls rows of dqkv untouched -- token 0's gradients go to dqkv_cls)
+            run = lambda: ops.attn_bwd(qd, obuf[:R], obuf[R:], dod[:R], dod[R:], lse, nseq, S, H, 0.125, mode=1, T=T, cls_base=R,
+                                       dqkv=torch.zeros(R + B, 3 * HD, device=dev(), dtype=BF),
+                                       dqkv_cls=torch.zeros(nseq, 3 * HD, device=dev(), dtype=BF))
         else:
             nseq, S = B, N + 1
             qd = torch.randn(nseq * S, 3 * HD, generator=g).to(dev(), BF)
             dod = torch.randn(nseq * S, HD, generator=g).to(dev(), BF)
             o, _, lse = ops.attn_fwd(qd, nseq, S, H, 0.125, mode=0)
-            run = lambda: ops.attn_bwd(qd, o, None, dod, None, lse, nseq, S, H, 0.125, mode=0)
+            run = lambda: ops.attn_bwd(qd, o, None, dod, None, lse, nseq, S, H, 0.125, mode=0, dqkv=torch.zeros_like(qd))
         ref = [x.clone() for x in run() if x is not None]
         diff = 0
         for it in range(8):
