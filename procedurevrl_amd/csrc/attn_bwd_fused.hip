@@ -22,15 +22,18 @@
 // Hiding the loads (traced: a workgroup that loads, then computes, spends 17k of its 44k cycles in the load burst, and the
 // one-workgroup-per-CU turn-around costs another ~4 us per item): the workgroup is persistent and streams item i + 1 in while item i
 // computes, by LDS-DMA (no registers).  A block's 32 rows of the Q and dO images are dead once every key wave has passed that
-// block's barrier, so right behind barrier jb the key waves send item i + 1's rows 32jb .. 32jb+31 of Q and dO into the freed
-// slots, the same rows of O into a three-slot ring and their lse next to it (13 copies of 1 KB, two per wave).  Each wave waits
-// `vmcnt(2)` before the next barrier -- its copies of the PREVIOUS block have landed -- so two barriers after a slot was sent the
-// dQ wave reads dO and O back, computes D = rowsum(dO * O) and writes the start values -lse/scale and -D*scale of those rows
-// (the last two slots of an item are finished during its own first two blocks).  The K image of item i + 1 goes into the second
-// K buffer (four pieces per key wave at the top of item i), its V rows into 16 registers per lane.  `scale` must be a power of
-// two (1/8 for head_dim 64): it is folded into the V operand and into D, both exactly.  The DMA cannot zero padding rows (they
-// hold copies of the last row): rows past the sequence start at -inf, so P = 0 there without a compare, and the wave that owns
-// keys past the sequence zeroes their dS.  The first item of a workgroup has nothing to hide behind: all eight waves
+// block's barrier, so from inside block jb + 1 (under its first MFMAs) waves 0-4 send item i + 1's rows 32jb .. 32jb+31 of Q and dO
+// into the freed slots, the same rows of O into a three-slot ring and their lse next to it (13 copies of 1 KB: three on each of
+// waves 0-3, the lse on wave 4).  Each sender waits `vmcnt(<its copies per slot>)` before a barrier -- all but its newest slot's
+// copies have landed -- so a slot is complete two barriers after the block it replaces, and at the top of the block after that
+// waves 0-3 (a quarter slot each) read dO and O back, compute D = rowsum(dO * O) and write the start values -lse/scale and
+// -D*scale of those rows (the last three slots of an item are finished at the seam and during its own first two blocks).  The K
+// image of item i + 1 goes into the second K buffer (four pieces per key wave at the top of item i), its V rows into 16 registers per
+// lane.  Outputs leave as whole 128-byte rows: dQ through the block's own dS^T buffer (the dQ wave is its only reader), dK / dV
+// through each wave's 2 KB of the buffer the last block did not use.  `scale` must be a power of two (1/8 for head_dim 64): it is
+// folded into the V operand and into D, both exactly.  The DMA cannot zero padding rows (they hold copies of the last row): rows
+// past the sequence start at -inf, so P = 0 there without a compare, and the wave that owns keys past the sequence zeroes their
+// dS.  The first item of a workgroup has nothing to hide behind: all eight waves
 // compute its D straight from global memory.  156 KB of LDS, one workgroup per CU.
 #include "attn_stream.h"
 #include "../../include/pvrl.h"
