@@ -95,18 +95,33 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32 round-off class): one v_exp, one v_rcp
-// and five FMAs instead of the ~40-instruction ocml erff; `e` returns exp(-x^2) for reuse by the derivative.
+// Exact-erf GELU (nn.GELU(), lib/models/vit.py:29-41) and its derivative for the GEMM epilogues, whose outputs are 16-bit: ONE
+// transcendental per element and no reciprocal.  With x = min(|u|, 6) and h(x) = Phi(-x) (the normal CDF's lower tail):
+//     gelu(u)  = max(u, 0) - x h(x)                       (u >= 0: u (1 - h);  u < 0: u h)
+//     gelu'(u) = 1/2 + copysign(1/2 - G(x), u),   G(x) = Phi(-x) - x phi(x)     (gelu'(-x) = G, gelu'(x) = 1 - G)
+//     h(x) = 2^-(1 + x R(x)),            R of degree 5:  |error| <= 2.8e-7 absolute and <= 5.7e-4 relative down to h(6) = 1e-9
+//     G(x) = 2^(-x^2 log2(e) / 2) N(x),  N of degree 10, N(0) = 1/2:  |error| <= 2e-7
+// Minimax fits over [0, 6] and the check against the exact functions in emulated fp32: tools/probe/gelu_fit.py -- |gelu error| <=
+// 5.4e-7, |gelu' error| <= 1.9e-7, the class of the Abramowitz-Stegun 7.1.26 form used before (4.6e-7 / 3.0e-7; v_rcp + v_exp + 17
+// VALU instructions per element).  Measured on MI355X (profiles/r4_nt_epilogue.txt): v_exp_f32 / v_rcp_f32 issue in 6 cycles per wave,
+// v_fma_f32 in 4.3, v_pk_fma_f32 in 5 (two elements); the GELU GEMM 313 -> 305 us, the dGELU GEMM and the step unchanged within noise (the
+// epilogues are bound by their store traffic, the math runs under it).  Beyond |u| = 6 both saturate (gelu -> u or -6e-9, gelu' -> 1 or 0); a NaN goes
+// through the select and comes out as NaN.
+#ifndef PVRL_GELU_FORM
+#define PVRL_GELU_FORM 1      // 0: the Abramowitz-Stegun form (A/B builds, tools/build_variant.py)
+#endif
+#ifndef PVRL_DGELU_FORM
+#define PVRL_DGELU_FORM PVRL_GELU_FORM
+#endif
+__device__ __forceinline__ float gelu_clamp6(float u) {
+  const float a = fabsf(u);
+  return a > 6.0f ? 6.0f : a;       // (not fminf: v_min_f32 drops a NaN)
+}
+// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute): v_rcp_f32 (1 ulp, not the 10-instruction IEEE division), v_exp
+// and five FMAs; `e` returns exp(-x^2) for reuse by the derivative.  Kept for A/B builds (PVRL_GELU_FORM=0).
 __device__ __forceinline__ float erf_as(float x, float& e) {
   const float ax = fabsf(x);
-  // v_rcp_f32 (1 ulp), NOT __frcp_rn / a division: those expand to the IEEE sequence (2 v_div_scale, v_rcp, 4 FMA, v_div_fmas,
-  // v_div_fixup = 10 of the GELU epilogue's 21 VALU instructions per element -- round 3: the two-output GELU and the dGELU GEMMs spent
-  // ~10 us of VALU time per 256x256 tile there, what had been booked as store time)
-#if defined(PVRL_GELU_IEEE_DIV)      // A/B builds only (tools/build_variant.py)
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-#else
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-#endif
   e = __expf(-ax * ax);
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
@@ -116,13 +131,60 @@ __device__ __forceinline__ float erf_as(float x, float& e) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float u) {
+#if PVRL_GELU_FORM == 0
   float e;
   return 0.5f * u * (1.0f + erf_as(u * 0.70710678118654752440f, e));
+#else
+  const float x = gelu_clamp6(u);
+  float p = fmaf(-2.9932052711956203e-05f, x, 0.0007281892467290163f);
+  p = fmaf(p, x, -0.007909782230854034f);
+  p = fmaf(p, x, 0.053108397871255875f);
+  p = fmaf(p, x, 0.45901164412498474f);
+  p = fmaf(p, x, 1.1511247158050537f);
+  p = fmaf(p, x, 1.0f);
+  const float h = __builtin_amdgcn_exp2f(-p);
+  return fmaf(-x, h, fmaxf(u, 0.0f));
+#endif
+}
+// two elements at a time: packed-fp32 FMAs (v_pk_fma_f32, two lanes' worth per issue slot) -- written out because under the GELU
+// GEMM's register pressure the compiler otherwise falls back to one v_fmaak_f32 per element and coefficient
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t u) {
+#if PVRL_GELU_FORM == 0
+  return (f32x2_t){gelu_erf(u[0]), gelu_erf(u[1])};
+#else
+  const f32x2_t x = {gelu_clamp6(u[0]), gelu_clamp6(u[1])};
+  f32x2_t p = __builtin_elementwise_fma((f32x2_t)(-2.9932052711956203e-05f), x, (f32x2_t)(0.0007281892467290163f));
+  p = __builtin_elementwise_fma(p, x, (f32x2_t)(-0.007909782230854034f));
+  p = __builtin_elementwise_fma(p, x, (f32x2_t)(0.053108397871255875f));
+  p = __builtin_elementwise_fma(p, x, (f32x2_t)(0.45901164412498474f));
+  p = __builtin_elementwise_fma(p, x, (f32x2_t)(1.1511247158050537f));
+  p = __builtin_elementwise_fma(p, x, (f32x2_t)(1.0f));
+  const f32x2_t h = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+  const f32x2_t r = {fmaxf(u[0], 0.0f), fmaxf(u[1], 0.0f)};
+  return __builtin_elementwise_fma(-x, h, r);
+#endif
 }
 __device__ __forceinline__ float gelu_erf_grad(float u) {
+#if PVRL_DGELU_FORM == 0
   float e;  // = exp(-u^2 / 2)
   const float cdf = 0.5f * (1.0f + erf_as(u * 0.70710678118654752440f, e));
   return fmaf(u * 0.39894228040143267794f, e, cdf);
+#else
+  const float x = gelu_clamp6(u);
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+  float n = fmaf(1.678248281677952e-06f, x, -3.60403792001307e-05f);
+  n = fmaf(n, x, 0.00034598674392327666f);
+  n = fmaf(n, x, -0.002000307897105813f);
+  n = fmaf(n, x, 0.008002669550478458f);
+  n = fmaf(n, x, -0.024410134181380272f);
+  n = fmaf(n, x, 0.061244383454322815f);
+  n = fmaf(n, x, -0.13256259262561798f);
+  n = fmaf(n, x, 0.24993102252483368f);
+  n = fmaf(n, x, -0.7978806495666504f);
+  n = fmaf(n, x, 0.5f);
+  return 0.5f + copysignf(0.5f - e * n, u);
+#endif
 }
 __device__ __forceinline__ float quick_gelu(float u) {
   return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));

@@ -122,6 +122,8 @@ int nt_cus_per_xcd() {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
       n = 256;
     cus = n / 8;
+    const char* e = getenv("PVRL_NT_CUS");      // probe runs: fewer persistent workgroups per XCD
+    if (e && atoi(e) > 0 && atoi(e) < cus) cus = atoi(e);
   }
   return cus;
 }

@@ -86,13 +86,21 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t tile_rsrc(const void* base, long row0, long ld, int elem, int rows) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + row0 * ld * elem), 0, (int)(rows * ld * elem), 0x00020000);
 }
+// Probe builds only (tools/probe/nt8_ab.py epi; results are garbage): bit 0 = the epilogue's stores are dropped (values kept alive),
+// bit 1 = the activation math is replaced by the identity, bit 2 = the epilogue's loads (residual / pre-activation) are dropped
+#ifndef PVRL_NT_EPI_ABLATE
+#define PVRL_NT_EPI_ABLATE 0
+#endif
 template <int AUX> __device__ __forceinline__ void bst16(rsrc_t r, unsigned off, f32x4 v) {
+  if (PVRL_NT_EPI_ABLATE & 1) { asm volatile("" :: "v"(v), "v"(off)); return; }
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX);
 }
 template <int AUX> __device__ __forceinline__ void bst16(rsrc_t r, unsigned off, opx8 v) {
+  if (PVRL_NT_EPI_ABLATE & 1) { asm volatile("" :: "v"(v), "v"(off)); return; }
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX);
 }
 template <int AUX, typename T> __device__ __forceinline__ T bld16(rsrc_t r, unsigned off) {
+  if (PVRL_NT_EPI_ABLATE & 4) { u32x4 z = {off, 0x3c003c00u, 0x3c003c00u, off}; asm volatile("" : "+v"(z)); return __builtin_bit_cast(T, z); }
   return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
 }
 
@@ -231,9 +239,17 @@ __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][
           } else if constexpr (TWO) {
             opx8 u0, g0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 8; e += 2) {
               u0[e] = (op_t)v[e];
-              g0[e] = (op_t)(EPI == PVRL_EPI_GELU ? gelu_erf(v[e]) : quick_gelu(v[e]));
+              u0[e + 1] = (op_t)v[e + 1];
+              if constexpr (EPI == PVRL_EPI_GELU) {
+                const f32x2_t gg = (PVRL_NT_EPI_ABLATE & 2) ? (f32x2_t){v[e] + 1.f, v[e + 1] + 1.f} : gelu_erf2((f32x2_t){v[e], v[e + 1]});
+                g0[e] = (op_t)gg[0];
+                g0[e + 1] = (op_t)gg[1];
+              } else {
+                g0[e] = (op_t)quick_gelu(v[e]);
+                g0[e + 1] = (op_t)quick_gelu(v[e + 1]);
+              }
             }
             bst16<ST>(r0, o0off, u0);
             bst16<ST>(r1, ml * (unsigned)p.ld1 * 2u + (unsigned)ncol[c] * 2u, g0);
@@ -242,7 +258,7 @@ __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][
             opx8 o0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float d = EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
+              const float d = (PVRL_NT_EPI_ABLATE & 2) ? (float)ua[e] : EPI == PVRL_EPI_DGELU ? gelu_erf_grad((float)ua[e]) : quick_gelu_grad((float)ua[e]);
               o0[e] = (op_t)(rs * v[e] * d);
             }
             bst16<ST>(r0, o0off, o0);

@@ -255,8 +255,50 @@ def ablate(rounds=5, reps=10):
             print(f"  {t:40s} {med:8.1f} us  ({fl / med:6.0f} TF-equivalent)", flush=True)
 
 
+def gelu_ab(rounds=7, reps=10):
+    """the GELU / dGELU GEMMs of the MLP with the one-transcendental GELU forms (product build) next to variant builds:
+    gelu0 = -DPVRL_GELU_FORM=0 (Abramowitz-Stegun, both directions), dgelu0 = -DPVRL_DGELU_FORM=0 (derivative only)"""
+    vdir = os.path.join(HERE, "..", "..", "procedurevrl_amd", "csrc", "variants")
+    libs = {"new": load("g_new", {"PVRL_NT8": "1"})}
+    for tag in ("gelu0", "dgelu0"):
+        src = os.path.join(vdir, f"libpvrl_hip_{tag}.so")
+        if os.path.exists(src):
+            libs[tag] = load("g_" + tag, {"PVRL_NT8": "1"}, src)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M = 50208
+    for (label, M_, N, K, name) in [("fc1 gelu", M, 3072, 768, "GELU"), ("dfc2 dgelu", M, 3072, 768, "DGELU"), ("plain bf16", M, 3072, 768, "BF16")]:
+        A, W, kw = operands(M_, N, K, EPI[name], g)
+        outs = run(libs["new"], A, W, EPI[name], **kw)
+        outs_l = [o for o in outs if o is not None]
+        ref = [o.clone() for o in outs_l]
+        fns = {t: (lambda t=t: run(libs[t], A, W, EPI[name], outs=outs, **kw)) for t in libs}
+        line = f"{label:12s} M {M_} N {N} K {K}"
+        res = {t: [] for t in libs}
+        for t in libs:
+            timeit(fns[t], 3)
+        for _ in range(rounds):
+            for t in libs:
+                res[t].append(timeit(fns[t], reps))
+        for t in libs:
+            fns[t]()
+            torch.cuda.synchronize()
+            diff = max(float((o.float() - r.float()).abs().max()) for o, r in zip(outs_l, ref))
+            nd = sum(int((o != r).sum()) for o, r in zip(outs_l, ref))
+            line += f" | {t} {statistics.median(res[t]):7.1f} us (min {min(res[t]):.1f}; vs new: max abs diff {diff:.2e}, {nd} elements differ)"
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
+    if what == ["window"]:
+        store_window()
+        sys.exit(0)
+    if what == ["epi"]:
+        epi_ablate()
+        sys.exit(0)
+    if what == ["gelu"]:
+        gelu_ab()
+        sys.exit(0)
     libs = {"old": load("old", {"PVRL_NT8": "0"}), "new": load("new", {"PVRL_NT8": "1"}),
             "new_nt": load("new_nt", {"PVRL_NT8": "1", "PVRL_NT_TAILS": "0"})}
     rc = 0
