@@ -1,6 +1,7 @@
 // bf16 MFMA GEMM, "TN" form (weight gradients): the C-ABI entry points.  The kernels live in gemm_tn_core.h.
 #include <algorithm>
-#include "gemm_tn_core.h"
+#include <cstdlib>
+#include "gemm_tn8_core.h"
 
 namespace {
 
@@ -8,6 +9,17 @@ namespace {
 // zero columns) whenever N and K are multiples of 128 and dW has at least one full tile; otherwise the 128x128
 // transposing-read kernel.  (Measured-and-rejected alternatives live under tools/probe/, outside this library.)
 bool tn_use_rt(int64_t N, int64_t K) { return (N % 128 == 0) && (K % 128 == 0) && N * K >= 256 * 256; }
+// The ping-pong LDS-DMA kernel (gemm_tn8_core.h) takes the shapes made of whole 256x256 tiles -- every Linear of the ViT-B encoder;
+// PVRL_TN8=0 sends them back to the register-transposed kernel (A/B runs; read once).  Results are bit-identical either way.
+bool tn8_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_TN8");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
+  }
+  return on != 0;
+}
+bool tn_use_tn8(int64_t N, int64_t K) { return tn8_enabled() && (N % 256 == 0) && (K % 256 == 0); }
 
 }  // namespace
 
@@ -83,7 +95,8 @@ int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t
     p.tiles_nk = (int)cdiv(N, 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = cdiv(p.npairs, 8);
-    hipLaunchKernelGGL(gemm_tn_rt8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
+    if (tn_use_tn8(N, K)) hipLaunchKernelGGL(gemm_tn8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(gemm_tn_rt8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
   } else {
     p.tiles_k = (int)(K / 128);
     p.tiles_nk = (int)(N / 128) * p.tiles_k;
@@ -188,7 +201,10 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
   g.first[nprob] = first;
   g.total = first;
   g.per_xcd = cdiv(first, 8);
-  hipLaunchKernelGGL(gemm_tn_rt8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
+  bool all8 = true;
+  for (int i = 0; i < nprob; ++i) all8 = all8 && tn_use_tn8(problems[i].N, problems[i].K);
+  if (all8) hipLaunchKernelGGL(gemm_tn8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_rt8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
   PVRL_LAUNCH_CHECK();
   static_assert(TN_RED_MAX >= TN_GROUP_MAX, "reduce table too small");
   TnReduceGroup r = {};

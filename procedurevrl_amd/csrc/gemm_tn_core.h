@@ -280,7 +280,13 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   // Round 3: a half tile's stages used to take the masked path below for EVERY stage -- plain loads whose values the mask consumes
   // at once, i.e. an s_waitcnt vmcnt(0) inside gload and the load latency exposed once per stage (2.45 us per stage at N = 128
   // against 1.9 for full tiles).  They now take the asm loads like everyone else; the mask is applied when the set is waited for.
+  // Probe builds only (tools/probe/tn_ab.py; results are garbage, only the time means something): bit 0 = no global loads, bit 1 = no
+  // twrites (v_perm + ds_write_b128), bit 2 = no fragment reads, bit 3 = no MFMAs, bit 4 = no barriers
+#ifndef PVRL_TN_ABLATE
+#define PVRL_TN_ABLATE 0
+#endif
   auto gload = [&](u32x4* r, int st) {
+    if (PVRL_TN_ABLATE & 1) return;
     if ((st + 1) * TS <= rows) {
       const char* b = ubase + (long)st * TS * ld2;
 #pragma unroll
@@ -305,6 +311,7 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
     }
   };
   auto twrite = [&](const u32x4* r, int j, char* slot) {   // column j of the lane's 8: gather its 8 m, store 16 B
+    if (PVRL_TN_ABLATE & 2) return;
     u32x4 o;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -320,7 +327,10 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
     frd[t] = q * 4096 + (slot << 4) + t * 256;
   }
   const int pbase = wn * 2048, qbase = OPB + wk * 1024;
-  auto rfrag = [&](const char* slot, int off, int h) { return *reinterpret_cast<const opx8*>(slot + off + h * 16384); };
+  auto rfrag = [&](const char* slot, int off, int h) {
+    if (PVRL_TN_ABLATE & 4) { opx8 z = (opx8)(op_t)0.5f; asm volatile("" : "+v"(z)); return z; }
+    return *reinterpret_cast<const opx8*>(slot + off + h * 16384);
+  };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -333,7 +343,7 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
   ones2[0] = (op_t)1.0f; ones2[1] = (op_t)1.0f;
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(PVRL_TN_ABLATE & 16)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   u32x4 ra[8];
@@ -365,8 +375,10 @@ __device__ __forceinline__ void tn_rt8_pair(const GemmTN& p, const int pair, cha
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-            acc[4 * half + nt][kt] = MFMA_16x16x32(qf[kt], pf[nt], acc[4 * half + nt][kt], 0, 0, 0);
+          for (int kt = 0; kt < 4; ++kt) {
+            if (PVRL_TN_ABLATE & 8) asm volatile("" :: "v"(qf[kt]), "v"(pf[nt]));
+            else acc[4 * half + nt][kt] = MFMA_16x16x32(qf[kt], pf[nt], acc[4 * half + nt][kt], 0, 0, 0);
+          }
           if (nt & 1) twrite(r, 4 * h + 2 * half + (nt >> 1), ws);
         }
       }
