@@ -16,6 +16,9 @@
 //     MEMORY segment (8-16 transposing reads into registers, the LDS-DMA instructions of the stage two ahead, the counted wait)
 //     and a COMPUTE segment (16 MFMAs on registers), so one wave of every SIMD computes while the other reads;
 //   * loads run two stages ahead with counted waits (vmcnt(8)), as in the NT kernel -- same hazard argument (gemm_nt8_core.h).
+// Measured and dropped (profiles/r4_tn_ablation.txt): a ring of five 32-row stages (128 KiB in flight instead of 96: 3 % slower), one
+// descriptor per stage instead of the stage offset in the scalar offset (4 % slower), an L2 touch 3-6 stages ahead by the tile's first
+// reader in its XCD (7-10 % slower).
 // Every accumulator sums its rows in the same order as tn_rt8_pair (stage by stage, m half 0 then 1): results are bit-identical.
 // Replaces the autograd backward of nn.Linear's weight / bias (lib/models/vit.py:54-60, 75-92, 133; tools/train_net.py:176-181).
 #pragma once
@@ -31,7 +34,13 @@ constexpr int TN8_BUF = 4 * TN8_HALF;    // one stage: P0 P1 Q0 Q1
 #pragma clang diagnostic ignored "-Winline-asm"
 // one 1 KiB LDS-DMA copy through a buffer descriptor: lane l's 16 bytes at r.base + soff + voff land at LDS byte lds + 16 l; offsets
 // past the descriptor's size read as zero.  (s_nop 4: SGPRs written by v_readfirstlane -> vector-memory instruction; s_nop 0: M0.)
+// Probe builds only (tools/probe/tn_ab.py; results are garbage, only the time means something): bit 0 = no LDS-DMA, bit 1 = no fragment
+// reads, bit 2 = no MFMAs
+#ifndef PVRL_TN8_ABLATE
+#define PVRL_TN8_ABLATE 0
+#endif
 __device__ __forceinline__ void tn8_dma16(tn_rsrc_t r, unsigned voff, unsigned soff, unsigned lds) {
+  if (PVRL_TN8_ABLATE & 1) return;
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :: "v"(voff), "s"(r), "s"(soff), "s"(lds) : "memory", "m0");
 }
@@ -99,7 +108,9 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
     }
   }
   const unsigned stepP = 64u * (unsigned)p.ldp * 2u, stepQ = 64u * (unsigned)p.ldq * 2u;     // bytes per stage
-  // descriptors over the slice's rows of the tile's 256 columns; the first byte behind (rows - 1, column 255) is out of range
+  // descriptors over the slice's rows of the tile's 256 columns; the first byte behind (rows - 1, column 255) is out of range.  The stage
+  // offset travels in the instruction's scalar offset, which gfx950 includes in the range check (tests/kernel_checks.py
+  // check_gemm_tn_rows_behind_the_end); a descriptor per stage was measured 4 % slower (scalar work in every memory segment).
   const tn_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.P + (long)mbeg * p.ldp + n0), 0, (int)(((long)(rows - 1) * p.ldp + 256) * 2), 0x00020000);
   const tn_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Q + (long)mbeg * p.ldq + k0), 0, (int)(((long)(rows - 1) * p.ldq + 256) * 2), 0x00020000);
   auto issueP1 = [&](int h, int e, unsigned lb, unsigned soff) { tn8_dma16(rP, voffP[h][e], soff, lb + h * TN8_HALF + wave * 2048 + e * 1024); };
@@ -114,17 +125,34 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
   opx8 ra[4][2], rb0[2][2], rb1[2][2];                     // [n tile][m half], [h2][m half] (rb0 / rb1: k half 0 / 1)
   f32x4 acc[2][4][4];                                      // [n half][n tile][2 c + h2]
   float cacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (PVRL_TN8_ABLATE & 2) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ra[t][ks] = (opx8)(op_t)0.5f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { rb0[h][ks] = (opx8)(op_t)0.25f; rb1[h][ks] = (opx8)(op_t)0.125f; }
+  }
   opx2 ones2;
   ones2[0] = (op_t)1.0f; ones2[1] = (op_t)1.0f;
   auto rdP = [&](const char* buf, int mh, int ks) {        // 8 reads: the n half's 4 tiles of this wave, m half ks
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ra[t][ks] = tr_frag(buf + mh * TN8_HALF + ks * 8192 + t * 128, xb, xb + 1024);
+    for (int t = 0; t < 4; ++t) {
+      if (PVRL_TN8_ABLATE & 2) asm volatile("" : "+v"(ra[t][ks]));
+      else ra[t][ks] = tr_frag(buf + mh * TN8_HALF + ks * 8192 + t * 128, xb, xb + 1024);
+    }
   };
   auto rdQ = [&](const char* buf, int ks) {                // 8 reads: both k halves, m half ks (kept for both n halves)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      rb0[h][ks] = tr_frag(buf + 2 * TN8_HALF + ks * 8192 + h * 128, wb, wb + 1024);
-      rb1[h][ks] = tr_frag(buf + 3 * TN8_HALF + ks * 8192 + h * 128, wb, wb + 1024);
+      if (PVRL_TN8_ABLATE & 2) {
+        asm volatile("" : "+v"(rb0[h][ks]), "+v"(rb1[h][ks]));
+      } else {
+        rb0[h][ks] = tr_frag(buf + 2 * TN8_HALF + ks * 8192 + h * 128, wb, wb + 1024);
+        rb1[h][ks] = tr_frag(buf + 3 * TN8_HALF + ks * 8192 + h * 128, wb, wb + 1024);
+      }
     }
   };
   auto mmk = [&](f32x4 (&a)[4][4], int mh, int ks) {       // 16 MFMAs on 16 different accumulators
@@ -132,8 +160,12 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        a[t][h] = MFMA_16x16x32(rb0[h][ks], ra[t][ks], a[t][h], 0, 0, 0);
-        a[t][2 + h] = MFMA_16x16x32(rb1[h][ks], ra[t][ks], a[t][2 + h], 0, 0, 0);
+        if (PVRL_TN8_ABLATE & 4) {
+          asm volatile("" :: "v"(rb0[h][ks]), "v"(rb1[h][ks]), "v"(ra[t][ks]));
+        } else {
+          a[t][h] = MFMA_16x16x32(rb0[h][ks], ra[t][ks], a[t][h], 0, 0, 0);
+          a[t][2 + h] = MFMA_16x16x32(rb1[h][ks], ra[t][ks], a[t][2 + h], 0, 0, 0);
+        }
       }
     if (do_csum) {                                         // column sums of P
 #pragma unroll

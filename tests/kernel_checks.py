@@ -142,6 +142,33 @@ def check_gemm_tn():
     return out
 
 
+def check_gemm_tn_rows_behind_the_end():
+    """the operands are the first M rows of larger buffers whose following rows hold large values: a staging path that reads past
+    the last slice's end (M not a multiple of the 64-row stage) shows as a gross error.  Whole-256 shapes (LDS-DMA kernel) and a
+    half-tile shape (register-transposed kernel), single and grouped launches."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(35)
+    out = []
+    probs, refs = [], []
+    for (M, N, K, splits) in [(1569, 768, 256, None), (1000, 256, 512, 3), (333, 256, 256, 1), (1569, 384, 256, None)]:
+        Pb = torch.full((M + 300, N), 1000.0); Qb = torch.full((M + 300, K), -1000.0)
+        Pb[:M] = torch.randn(M, N, generator=g); Qb[:M] = torch.randn(M, K, generator=g)
+        Pd, Qd = Pb.to(dev(), BF), Qb.to(dev(), BF)
+        ref = bf(Pb[:M]).t() @ bf(Qb[:M])
+        dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
+        ops.gemm_tn(Pd[:M], Qd[:M], dW, db, beta=0.0, splits=splits)
+        out.append((f"gemm_tn rows behind the end dW {M}x{N}x{K} s={splits}", rel(dW, ref), 1e-4))
+        out.append((f"gemm_tn rows behind the end dbias {M}x{N}x{K}", rel(db, bf(Pb[:M]).sum(0)), 1e-4))
+        if N % 256 == 0 and K % 256 == 0:
+            probs.append((Pd[:M], Qd[:M], torch.zeros(N, K, device=dev()), torch.zeros(N, device=dev()), 0.0))
+            refs.append((ref, bf(Pb[:M]).sum(0)))
+    ops.gemm_tn_grouped(probs)
+    for (_, _, dW, db, _), (rw, rb) in zip(probs, refs):
+        out.append((f"gemm_tn_grouped rows behind the end dW {tuple(dW.shape)}", rel(dW, rw), 1e-4))
+        out.append((f"gemm_tn_grouped rows behind the end dbias {tuple(dW.shape)}", rel(db, rb), 1e-4))
+    return out
+
+
 def check_gemm_tn_into():
     """zero-padded operands reduced straight into an un-padded, odd-width destination (pvrl_gemm_tn_into_bf16): the MViT
     engine's weight gradients (96 -> 128, 441 -> 512 columns); separate betas for weight and bias"""
@@ -615,5 +642,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
