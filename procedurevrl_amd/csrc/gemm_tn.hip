@@ -19,7 +19,10 @@ bool tn8_enabled() {
   }
   return on != 0;
 }
-bool tn_use_tn8(int64_t N, int64_t K) { return tn8_enabled() && (N % 256 == 0) && (K % 256 == 0); }
+// (its buffer descriptors and per-lane offsets are 32-bit: a slice's rows x the row pitch must stay below 2 GiB)
+bool tn_use_tn8(int64_t N, int64_t K, int64_t slice_rows, int64_t ldp, int64_t ldq) {
+  return tn8_enabled() && (N % 256 == 0) && (K % 256 == 0) && (slice_rows + 64) * std::max(ldp, ldq) * 2 < (int64_t(1) << 31) - 4096;
+}
 
 }  // namespace
 
@@ -95,7 +98,7 @@ int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t
     p.tiles_nk = (int)cdiv(N, 256) * p.tiles_k;
     p.npairs = (int)splits * p.tiles_nk;
     p.Ms_pairs = cdiv(p.npairs, 8);
-    if (tn_use_tn8(N, K)) hipLaunchKernelGGL(gemm_tn8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
+    if (tn_use_tn8(N, K, p.Ms, ldp, ldq)) hipLaunchKernelGGL(gemm_tn8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_rt8_kernel, dim3((unsigned)(8 * p.Ms_pairs)), dim3(512), 0, s, p);
   } else {
     p.tiles_k = (int)(K / 128);
@@ -202,7 +205,7 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
   g.total = first;
   g.per_xcd = cdiv(first, 8);
   bool all8 = true;
-  for (int i = 0; i < nprob; ++i) all8 = all8 && tn_use_tn8(problems[i].N, problems[i].K);
+  for (int i = 0; i < nprob; ++i) all8 = all8 && tn_use_tn8(problems[i].N, problems[i].K, g.prob[i].Ms, problems[i].ldp, problems[i].ldq);
   if (all8) hipLaunchKernelGGL(gemm_tn8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
   else hipLaunchKernelGGL(gemm_tn_rt8_grouped_kernel, dim3((unsigned)(8 * g.per_xcd)), dim3(512), 0, s, g);
   PVRL_LAUNCH_CHECK();

@@ -80,7 +80,7 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
   const int q = lane >> 4, i = lane & 15;
   float* part = p.part + (long)s * p.N * p.K;
   const bool has_csum = p.cpart != nullptr && tk == 0;
-  const bool do_csum = has_csum && wn == 0;                // the wn == 0 waves sum the columns of their P fragments (VALU in the MFMAs' shadow)
+  const bool do_csum = has_csum && wn == wm;               // waves 0 and 5 (two different SIMDs) sum the columns of their P fragments (VALU in the MFMAs' shadow)
   if (rows <= 0) {                                         // empty slice: its partial tile must still be zero
     for (int mh = 0; mh < 2; ++mh)
       for (int t = 0; t < 4; ++t)
