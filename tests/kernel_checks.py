@@ -169,6 +169,38 @@ def check_gemm_tn_rows_behind_the_end():
     return out
 
 
+def check_gemm_tn_repeatable():
+    """The weight-gradient kernel for whole-256 shapes keeps its LDS-DMA copies in flight across barriers with counted waits: launched
+    repeatedly next to an uneven load on a second stream, every result must be BIT-identical to the first (a wait that is one short or a
+    slot re-staged too early shows as a run-to-run difference), and identical to the register-transposed kernel's order of summation
+    (checked against fp32 matmul within rounding)."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(36)
+    out = []
+    burn = torch.randn(4096, 4096, device=dev())
+    side = torch.cuda.Stream()
+    shapes = [(6273, 768, 768), (6273, 2304, 768), (6272, 768, 3072), (6273, 3072, 768)]       # a block's gradients at 4 clips (ragged last stage)
+    P = [(torch.randn(m, N, generator=g) * 0.05).to(dev(), BF) for m, N, K in shapes]
+    Q = [torch.randn(m, K, generator=g).to(dev(), BF) for m, N, K in shapes]
+
+    def run():
+        dW = [torch.empty(N, K, device=dev()) for m, N, K in shapes]
+        db = [torch.empty(N, device=dev()) for m, N, K in shapes]
+        ops.gemm_tn_grouped([(P[i], Q[i], dW[i], db[i], 0.0) for i in range(len(shapes))])
+        return dW + db
+    ref = [x.clone() for x in run()]
+    diff = 0
+    for it in range(8):
+        if it % 3 != 0:
+            with torch.cuda.stream(side):
+                burn @ burn
+        diff += sum(int(not torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(ref, run()))
+    torch.cuda.synchronize()
+    out.append(("gemm_tn_grouped (LDS-DMA kernel): results that differ from the first launch (8 launches x 8 tensors)", float(diff), 0.0))
+    out.append(("gemm_tn_grouped (LDS-DMA kernel) dW vs fp32 matmul", rel(ref[1], P[1].float().cpu().t() @ Q[1].float().cpu()), 1e-4))
+    return out
+
+
 def check_gemm_tn_into():
     """zero-padded operands reduced straight into an un-padded, odd-width destination (pvrl_gemm_tn_into_bf16): the MViT
     engine's weight gradients (96 -> 128, 441 -> 512 columns); separate betas for weight and bias"""
@@ -642,5 +674,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
