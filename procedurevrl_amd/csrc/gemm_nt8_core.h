@@ -9,13 +9,14 @@
 //     [128 + 32 wn, +32): every wave touches all four 16 KiB half-tiles (A0 A1 B0 B1: 128 rows x 64 k) of a K-tile, one after
 //     the other, so a half-tile's LDS is free -- and refilled -- a quarter of a K-tile after its first use.
 //   * the two waves of a SIMD run PING-PONG: waves 0-3 (one per SIMD) are one barrier interval ahead of waves 4-7.  A K-tile is
-//     four phases (the wave's four 64x32 accumulator quadrants, 16 MFMAs each); a phase is a MEMORY segment (fragment reads into
-//     registers, two to four 1 KiB LDS-DMA instructions for the K-tile two ahead, the counted wait) and a COMPUTE segment (16
-//     back-to-back MFMAs on registers only, s_setprio 1), separated by workgroup barriers.  While one wave of a SIMD computes,
+//     two phases (the wave's upper / lower 64 rows, both k halves: 32 MFMAs each; four phases of 16 until late in round 4, same
+//     results, 2.5-4.5 % slower); a phase is a MEMORY segment (fragment reads into registers, two or six 1 KiB LDS-DMA
+//     instructions for the K-tile two ahead, the counted wait) and a COMPUTE segment (32 back-to-back MFMAs on registers only,
+//     s_setprio 1), separated by workgroup barriers.  While one wave of a SIMD computes,
 //     its partner is in its memory segment: the matrix pipe never waits for an LDS read.
 //   * LDS-DMA is raw ISA (buffer_load_dwordx4 ... lds) with COUNTED waits: the loads of K-tile u + 2 go out during K-tile u
 //     (into the slots K-tile u has just finished reading) and are waited for at the end of K-tile u + 1 with vmcnt(8), i.e. up to
-//     64 KB per CU stay in flight across every barrier, each half-tile has at least four phases (~1 us) to land.
+//     64 KB per CU stay in flight across every barrier, each half-tile has at least two phases (~1 us) to land.
 //   * the workgroup is PERSISTENT: one per CU walks its XCD's tile list (the order the one-tile kernel is dispatched in).  The
 //     load stream runs two K-tiles ahead ACROSS tile seams, so a tile's first two K-tiles arrive under the previous tile's last
 //     two and under its epilogue, and the epilogue's stores drain under the next tile's K loop (counted waits never ask for
@@ -63,6 +64,9 @@ __host__ __device__ inline Nt8Plan nt8_plan(int cm, int tiles_n, int cus, int en
 // loads K offset 0 (the same 64 KB per tile: L2-hot), bit 6 = every tile loads tile (0, 0) as well (one 64 KB image for the whole chip)
 #ifndef PVRL_NT8_ABLATE
 #define PVRL_NT8_ABLATE 0
+#endif
+#ifndef PVRL_NT8_PH2
+#define PVRL_NT8_PH2 1      // 0: four phases of 16 MFMAs per K-tile (A/B builds)
 #endif
 
 #pragma clang diagnostic push
@@ -323,6 +327,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
       const bool seam = primed && kt == 0;                  // the previous epilogue's NST stores sit in the queue behind the prefetch
       // Every memory segment issues its fragment reads FIRST and the LDS-DMA behind them: a DMA instruction blocks its wave while the
       // CU's address path takes the 1 KiB (16 cycles each, the group's four waves queue up), and the reads complete underneath.
+#if PVRL_NT8_PH2
+      // TWO phases per K-tile (row half, both k halves: 32 MFMAs each): half the barriers of the four-phase form below, the same copies,
+      // waits and hazards (a half-tile is re-staged in the phase after its last read, read in the phase after its wait); 2.5-4.5 % faster on
+      // every shape, bit-identical (profiles/r4_nt8_ablation.txt section 7)
+      rdAk(rbuf, 0, 0); rdBk(rbuf, 0); rdAk(rbuf, 0, 1); rdBk(rbuf, 1);
+      if (on1) {
+        issueA1(1, 0, lo, a1, so1); issueA1(1, 1, lo, a1, so1);
+        if (seam) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      NT8_MEM_END(1);
+      mmk(acc[0], 0);
+      mmk(acc[0], 1);
+      NT8_CMP_END(1);
+      rdAk(rbuf, 1, 0); rdAk(rbuf, 1, 1);
+      if (on2) {
+        issueW1(0, 0, lb, w2, so2); issueW1(0, 1, lb, w2, so2); issueA1(0, 0, lb, a2, so2);
+        issueA1(0, 1, lb, a2, so2); issueW1(1, 0, lb, w2, so2); issueW1(1, 1, lb, w2, so2);
+        if (seam) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      NT8_MEM_END(3);
+      mmk(acc[1], 0);
+      mmk(acc[1], 1);
+      NT8_CMP_END(3);
+#else
       // ---- phase 0: rows 0, k half 0 ----
       NT8_STAMP(0, 0);
       rdAk(rbuf, 0, 0);
@@ -367,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNT p) {
       NT8_MEM_END(3);
       mmk(acc[1], 1);
       NT8_CMP_END(3);
+    #endif
     }
     if (wm == 0) NT8_BARRIER();                             // G0 waits for G1's last compute segment: both groups run the epilogue together
 #if PVRL_NT8_TRACE

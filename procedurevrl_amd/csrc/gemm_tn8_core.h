@@ -12,9 +12,9 @@
 //     rows behind the slice's end read as zero through the descriptor's bounds check;
 //   * wave (wm, wn) = (wave >> 2, wave & 3) owns n rows [64 wm, +64) of both n halves and k columns [32 wn, +32) of both k halves:
 //     8 x 4 accumulators of v_mfma_f32_16x16x32 (128 registers);
-//   * waves 0-3 (one per SIMD) run one barrier interval ahead of waves 4-7: a stage is four phases (n half, m half), each a
-//     MEMORY segment (8-16 transposing reads into registers, the LDS-DMA instructions of the stage two ahead, the counted wait)
-//     and a COMPUTE segment (16 MFMAs on registers), so one wave of every SIMD computes while the other reads;
+//   * waves 0-3 (one per SIMD) run one barrier interval ahead of waves 4-7: a stage is two phases (n half 0 / 1, both m halves), each
+//     a MEMORY segment (16-32 transposing reads into registers, the LDS-DMA instructions of the stage two ahead, the counted wait)
+//     and a COMPUTE segment (32 MFMAs on registers), so one wave of every SIMD computes while the other reads;
 //   * loads run two stages ahead with counted waits (vmcnt(8)), as in the NT kernel -- same hazard argument (gemm_nt8_core.h).
 // Measured and dropped (profiles/r4_tn_ablation.txt): a ring of five 32-row stages (128 KiB in flight instead of 96: 3 % slower), one
 // descriptor per stage instead of the stage offset in the scalar offset (4 % slower), an L2 touch 3-6 stages ahead by the tile's first
@@ -38,6 +38,9 @@ constexpr int TN8_BUF = 4 * TN8_HALF;    // one stage: P0 P1 Q0 Q1
 // reads, bit 2 = no MFMAs
 #ifndef PVRL_TN8_ABLATE
 #define PVRL_TN8_ABLATE 0
+#endif
+#ifndef PVRL_TN8_PH2
+#define PVRL_TN8_PH2 1      // 0: four phases of 16 MFMAs per K-tile (A/B builds)
 #endif
 __device__ __forceinline__ void tn8_dma16(tn_rsrc_t r, unsigned voff, unsigned soff, unsigned lds) {
   if (PVRL_TN8_ABLATE & 1) return;
@@ -200,6 +203,32 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
     const unsigned lb = sbase + cur * TN8_BUF, lo = sbase + (cur ^ 1) * TN8_BUF;
     // every memory segment issues its fragment reads FIRST and the LDS-DMA behind them (a DMA instruction blocks its wave while the
     // CU's address path takes the 1 KiB; the reads complete underneath)
+#if PVRL_TN8_PH2
+    // TWO phases per stage (n half, both m halves: 32 MFMAs each): half the barriers of the four-phase form below, same copies and waits; ~1 % faster
+    rdP(rbuf, 0, 0); rdQ(rbuf, 0); rdP(rbuf, 0, 1); rdQ(rbuf, 1);
+    if (on1) {
+      issueP1(1, 0, lo, sP1); issueP1(1, 1, lo, sP1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TN8_MEM_END();
+    mmk(acc[0], 0, 0);
+    mmk(acc[0], 0, 1);
+    TN8_CMP_END();
+    rdP(rbuf, 1, 0); rdP(rbuf, 1, 1);
+    if (on2) {
+      issueQ1(0, 0, lb, sQ2); issueQ1(0, 1, lb, sQ2); issueP1(0, 0, lb, sP2);
+      issueP1(0, 1, lb, sP2); issueQ1(1, 0, lb, sQ2); issueQ1(1, 1, lb, sQ2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TN8_MEM_END();
+    mmk(acc[1], 1, 0);
+    mmk(acc[1], 1, 1);
+    TN8_CMP_END();
+#else
     // ---- phase 0: n half 0, m half 0 ----
     rdP(rbuf, 0, 0);
     rdQ(rbuf, 0);
@@ -236,6 +265,7 @@ __device__ __forceinline__ void tn8_pair(const GemmTN& p, const int pair, char* 
     TN8_MEM_END();
     mmk(acc[1], 1, 1);
     TN8_CMP_END();
+  #endif
   }
   if (wm == 0) TN8_BARRIER();                              // both groups leave the loop together
 

@@ -35,9 +35,10 @@ def test_tn8_kernel_code(asm, name):
     # LDS-DMA: 14 (cold start) + 8 (one stage); the compiler may peel the loop's first iteration (+ 8)
     assert len(re.findall(r"buffer_load_dwordx4 .* lds", body)) in (22, 30)
     assert body.count("s_waitcnt vmcnt(8)") in (2, 4) and body.count("s_waitcnt vmcnt(6)") == 1
-    # every MFMA of the loop sits in a 16-instruction cluster between s_setprio 1 / 0; only the bias-gradient dot products share it
+    # every MFMA of the loop sits in a 32-instruction cluster between s_setprio 1 / 0 (two phases per stage); only the bias-gradient dot
+    # products share it
     assert body.count("s_setprio 1") == body.count("s_setprio 0")
-    assert body.count("v_mfma_f32_16x16x32") == 16 * body.count("s_setprio 1")
+    assert body.count("v_mfma_f32_16x16x32") == 32 * body.count("s_setprio 1")
     # fragments come through the transposing read: 48 per stage and wave
     assert body.count("ds_read_b64_tr_b16") % 48 == 0 and body.count("ds_read_b64_tr_b16") > 0
     assert "ds_write" not in body.split("s_barrier")[1].split("s_barrier")[0]       # nothing is staged through registers

@@ -105,7 +105,7 @@ def check(libs):
                     kw["aux"] = torch.randn(197, N, device=DEV, generator=g)
                     kw["aux_rowmod"] = 197
                 ref = run(libs["old"], A, W, epi, **kw)
-                for tag in ("new", "new_nt"):
+                for tag in [t for t in libs if t != "old"]:
                     out = run(libs[tag], A, W, epi, **kw)
                     for a, b in zip(ref, out):
                         if a is None:
@@ -301,6 +301,8 @@ if __name__ == "__main__":
         sys.exit(0)
     libs = {"old": load("old", {"PVRL_NT8": "0"}), "new": load("new", {"PVRL_NT8": "1"}),
             "new_nt": load("new_nt", {"PVRL_NT8": "1", "PVRL_NT_TAILS": "0"})}
+    for tag in filter(None, os.environ.get("NT8_EXTRA", "").split(",")):       # variant builds (tools/build_variant.py <tag> ...) next to the product
+        libs[tag] = load(tag, {"PVRL_NT8": "1"}, os.path.join(HERE, "..", "..", "procedurevrl_amd", "csrc", "variants", f"libpvrl_hip_{tag}.so"))
     rc = 0
     if "trace" in what:
         trace()
