@@ -42,16 +42,17 @@ struct GemmNT {
 };
 
 constexpr int BK = 64;
-// rasterisation group height (tile rows per group).  Round 3 sweep with the variants interleaved in random order
-// (profiles/r3_nt_cache_policy.txt): 2, 3, 4, 6, 8 are within +-1.5 % on every 50k-row shape; 4 fetches 10-16 % fewer bytes
-// than 2 on the wide outputs (N >= 2304: the group's 2 A panels no longer cycle the whole W through L2 per 24 tiles) and
-// 5-10 % more on N = 768, where 2 keeps both the A panels and the 1.2-4.7 MB W resident.  In-step (same box, interleaved):
-// gm 4 everywhere 579-581 clips/s, gm 2 575-576, gm 3 573-575 -> 4 for wide outputs, 2 otherwise.
+// rasterisation group height (tile rows per group).  The 32 workgroups an XCD runs at a time cover gm A panels x 32 / gm W tiles: the
+// distinct lines they ask the XCD's L2 for per K-tile go with gm + 32 / gm, least at gm = sqrt(32) = 5.7.  Measured in the step (round 4,
+// two-phase persistent kernel, three interleaved pairs each against "4 for N >= 2048, else 2", the choice of round 3's per-kernel sweep
+// of 2 / 3 / 4 / 6 / 8): gm 2 +0.3 %, 3 +-0, 5 +0.9 %, 6 +0.8 ... +1.0 % (twice), 8 +0.3 %, 12 +0.4 % -> 6 for every shape (with three or
+// fewer tile columns the group height does not change what runs together).  The gain is in the L2, not in HBM bytes: FETCH_SIZE per
+// launch went UP 8-15 % on the wide shapes (profiles/r4_pmc_hbm_mfma.csv) while the kernels got 1-3 % shorter.
 #ifndef PVRL_NT_GM
 #define PVRL_NT_GM 0
 #endif
-constexpr int NT_GM = PVRL_NT_GM;       // 0 = by shape (nt_gm_for), otherwise forced (probe builds)
-static inline int nt_gm_for(int tiles_n) { return NT_GM ? NT_GM : (tiles_n >= 8 ? 4 : 2); }
+constexpr int NT_GM = PVRL_NT_GM;       // 0 = the default below, otherwise forced (probe builds)
+static inline int nt_gm_for(int tiles_n) { (void)tiles_n; return NT_GM ? NT_GM : 6; }
 
 __device__ __forceinline__ int swz_x(int row) { return (row >> 1) & 7; }
 // W rows are read in a permuted order so that the lanes of one epilogue store instruction write contiguous bytes:
