@@ -318,6 +318,21 @@ int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* problems, void*
 int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out_t, int64_t ldt, int64_t R, int64_t C,
                               const float* bias, float* bias_out, void* stream);
 
+/* The cls rows' own chain in fp32 (csrc/cls_chain.hip).  One cls token per clip passes every block (vit.py:139-157: mean over
+ * the T frames of the spatial attention's cls outputs -> attn.proj -> residual; norm2 -> mlp.fc1 -> GELU -> mlp.fc2 ->
+ * residual) and only those B rows reach the head (vit.py:418-421).  Their rounding errors do not average out the way the
+ * patch tokens' do inside the attention, so these few rows are computed from the fp32 MASTER weights:
+ *   epilogue 0:  out[m][n] = aux[m][n] + rowscale[m] * (X[m] . W[n]) + biasscale[m] * bias[n]      (each of aux / rowscale /
+ *                biasscale / bias may be null = 0 / 1 / 1 / 0; rowscale = biasscale = the DropPath factor of vit.py:157, or
+ *                biasscale = the mean DropPath factor over the T frames of vit.py:144-149)
+ *   epilogue 1:  u = X[m] . W[n] + bias[n];  out = GELU_erf(u) (nn.GELU, vit.py:45); out16_pre / out16_act (optional, the
+ *                library's 16-bit operand type, leading dimension ld16) receive u / GELU(u)
+ * X [M, K], W [N, K], out fp32; N % 16 == 0, K % 128 == 0; HBM-bound on W, deterministic (fixed summation order). */
+int pvrl_cls_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t M, int64_t N,
+                        int64_t K, int epilogue, const float* rowscale, const float* biasscale, const float* aux,
+                        int64_t ld_aux, float* out, int64_t ldo, void* out16_pre, void* out16_act, int64_t ld16,
+                        void* stream);
+
 /* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
 int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);
 

@@ -341,6 +341,8 @@ class EncoderEngine(GraphReplay):
         self.overlap_wgrad = True     # weight-gradient GEMMs on a side stream, concurrent with the dgrad chain
         self._side = None
         self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
+        # the B cls rows' projection + MLP in fp32 on the master weights (csrc/cls_chain.hip; PVRL_CLS_FP32=0: A/B runs)
+        self.cls_fp32 = os.environ.get("PVRL_CLS_FP32", "1") == "1"
         self._wq = []
         self._wpost = []
         self._side_keep = []
@@ -552,7 +554,9 @@ class EncoderEngine(GraphReplay):
         s2_seq = s2.contiguous()
         s2_tok = s2.reshape(nb, B, 1, T).expand(nb, B, N, T).reshape(nb, -1)          # [nb, B*N*T]
         s3_all = torch.cat([s3.repeat_interleave(N * T, dim=1), s3], 1)               # [nb, B*N*T + B]
-        return [None if rates[i] == 0.0 else dict(s1_tok=s1_tok[i], s2_seq=s2_seq[i], s2_tok=s2_tok[i], s3_all=s3_all[i])
+        s2_mean = s2.reshape(nb, B, T).mean(2)                                        # [nb, B]: the cls rows' bias factor
+        return [None if rates[i] == 0.0 else dict(s1_tok=s1_tok[i], s2_seq=s2_seq[i], s2_tok=s2_tok[i], s3_all=s3_all[i],
+                                                  s2_mean=s2_mean[i])
                 for i in range(nb)]
 
     @staticmethod
@@ -560,7 +564,7 @@ class EncoderEngine(GraphReplay):
         s1_tok = s1.repeat_interleave(T).contiguous()
         s2_tok = s2.view(B, 1, T).expand(B, N, T).reshape(-1).contiguous()
         s3_all = torch.cat([s3.repeat_interleave(N * T), s3]).contiguous()
-        return dict(s1_tok=s1_tok, s2_seq=s2.contiguous(), s2_tok=s2_tok, s3_all=s3_all)
+        return dict(s1_tok=s1_tok, s2_seq=s2.contiguous(), s2_tok=s2_tok, s3_all=s3_all, s2_mean=s2.view(B, T).mean(1))
 
     # ------------------------------------------------------------------ embeddings
     def _pos_time(self, N, T, Wp):
@@ -667,8 +671,15 @@ class EncoderEngine(GraphReplay):
         wproj = self._weight(blk.attn.proj.weight).w
         ops.gemm_nt(o_s[:R], wproj, L.PVRL_EPI_RESID_F32, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1[:R],
                     out0=x2[:R])
-        pc = ops.gemm_nt(o_s[R:], wproj, L.PVRL_EPI_F32, bias=P(blk.attn.proj.bias))
-        ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1[R:], out=x2[R:])
+        if self.cls_fp32:
+            # the cls rows' own chain in fp32 on the master weights (csrc/cls_chain.hip): the projection is linear, so the mean over
+            # the T frames (vit.py:147-149) is taken first -- B rows instead of B * T
+            om = ops.group_reduce(o_s[R:], B, T, scale=s2_seq, alpha=1.0 / T)
+            ops.cls_linear(om, P(blk.attn.proj.weight), P(blk.attn.proj.bias), biasscale=dp["s2_mean"] if dp else None,
+                           aux=x1[R:], out=x2[R:])
+        else:
+            pc = ops.gemm_nt(o_s[R:], wproj, L.PVRL_EPI_F32, bias=P(blk.attn.proj.bias))
+            ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1[R:], out=x2[R:])
 
         # ---- MLP (vit.py:155-157) ----
         h_m, mean_m, rstd_m = ops.layernorm_fwd(x2, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
@@ -676,6 +687,13 @@ class EncoderEngine(GraphReplay):
         x3 = torch.empty_like(x0)
         ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
                     rowscale=s3_all, aux=x2, out0=x3)
+        if self.cls_fp32:       # (the 16-bit path's cls rows of h_m / u / g stay what the backward reads; x3's are replaced)
+            hc, _, _ = ops.layernorm_fwd(x2[R:], P(blk.norm2.weight), P(blk.norm2.bias), self.eps, out_dtype=F32,
+                                         save_stats=False)
+            gc = ops.cls_linear(hc, P(blk.mlp.fc1.weight), P(blk.mlp.fc1.bias), gelu=True)
+            s3c = s3_all[R:] if s3_all is not None else None
+            ops.cls_linear(gc, P(blk.mlp.fc2.weight), P(blk.mlp.fc2.bias), rowscale=s3c, biasscale=s3c, aux=x2[R:],
+                           out=x3[R:])
         if save:
             sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
                                      lse_t=lse_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,

@@ -120,6 +120,21 @@ def gemm_nt_f32(A, B, bias=None, alpha=1.0, out=None):
     return out
 
 
+def cls_linear(X, W, bias=None, gelu=False, rowscale=None, biasscale=None, aux=None, out=None):
+    """The cls rows' fp32 chain (pvrl_cls_linear_f32): out = aux + rowscale * (X W^T) + biasscale * bias, or GELU(X W^T + bias).
+    X fp32 [M, K], W fp32 [N, K] (the MASTER weight, not its 16-bit operand copy)."""
+    L = lib()
+    _chk2d(X, F32); _chk2d(W, F32)
+    M, K = X.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=X.device, dtype=F32)
+    L.call("pvrl_cls_linear_f32", _ptr(X), _ld(X), _ptr(W), _ld(W), _ptr(bias), M, N, K, 1 if gelu else 0, _ptr(rowscale),
+           _ptr(biasscale), _ptr(aux), _ld(aux) if aux is not None else 0, _ptr(out), _ld(out), None, None, 0, _stream())
+    return out
+
+
 _ws_cache = {}
 
 

@@ -123,6 +123,34 @@ def check_gemm_f32_small():
     return out
 
 
+def check_cls_linear():
+    """pvrl_cls_linear_f32: the cls rows' fp32 projection / MLP (vit.py:147-157) vs fp64 math on the same fp32 inputs."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(12)
+    out = []
+    for (M, N, K) in [(32, 768, 768), (36, 3072, 768), (32, 768, 3072), (2, 768, 768), (50, 3072, 768), (7, 768, 3072), (3, 512, 512),
+                      (5, 256, 128)]:
+        X = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * 0.05
+        bias = torch.randn(N, generator=g)
+        rs = torch.rand(M, generator=g) + 0.5
+        bs = torch.rand(M, generator=g) + 0.5
+        aux = torch.randn(M, N, generator=g)
+        Xd, Wd, bd = X.to(dev()), W.to(dev()), bias.to(dev())
+        acc = X.double() @ W.double().t()
+        o = ops.cls_linear(Xd, Wd, bd)
+        out.append((f"cls_linear {M}x{N}x{K}", rel(o, acc + bias), TOL_F32))
+        o = ops.cls_linear(Xd, Wd, bd, rowscale=rs.to(dev()), biasscale=bs.to(dev()), aux=aux.to(dev()))
+        out.append((f"cls_linear residual {M}x{N}x{K}", rel(o, aux + rs[:, None] * acc + bs[:, None] * bias), TOL_F32))
+        o = ops.cls_linear(Xd, Wd, bd, gelu=True)
+        out.append((f"cls_linear gelu {M}x{N}x{K}", rel(o, F.gelu((acc + bias).float())), TOL_F32))
+        # a strided view as the engine passes it (rows of a larger buffer)
+        big = torch.zeros(M + 5, N + 64, device=dev())
+        ops.cls_linear(Xd, Wd, None, out=big[5:, :N])
+        out.append((f"cls_linear strided out {M}x{N}x{K}", rel(big[5:, :N], acc), TOL_F32))
+    return out
+
+
 def check_gemm_tn():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -674,5 +702,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
