@@ -68,15 +68,23 @@ int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* B, int64_t 
  * workspace >= pvrl_gemm_tn_workspace_bytes(N, K, splits). */
 int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K);
 int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t splits);
+/* Common tail of the entry points that WRITE PARAMETER GRADIENTS (this one, _into, _grouped, pvrl_layernorm_bwd):
+ *   gscale    device scalar or null: the new contribution is multiplied by it, dW = beta*dW + gscale * (P^T Q).  The fp16-operand
+ *             flavour runs a backward in S-scaled units (5 exponent bits; engine.GradStore.begin_scaled picks the power of two S on
+ *             the device) and the kernel that writes a parameter gradient takes 1/S out again -- no separate pass over the buffer;
+ *   nonfinite device flag or null: set to 1 when a value written is inf / nan.  It is the `skip` flag of pvrl_adam_step /
+ *             pvrl_sgd_step: misc.check_nan_losses (tools/train_net.py:174) raises in front of optimizer.step(); here the bad step is
+ *             dropped on the device and reported at the next log point.  Only ever raised; pvrl_flag_roll re-arms it. */
 int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float beta, float* dW, float* dbias, void* workspace, int64_t workspace_bytes,
-                      void* stream);
+                      const float* gscale, float* nonfinite, void* stream);
 /* The same product reduced straight into an UN-PADDED destination: dW[n][k] (leading dimension ldw) for n < n_valid,
  * k < k_valid only, dbias[n] for n < n_valid (its own beta_bias) -- zero-padded operands (MViT widths 96 / 288 / 441 ...
  * padded to the tile multiples) write their weight gradient directly into parameter.grad. */
 int pvrl_gemm_tn_into_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
                            int64_t splits, float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid,
-                           float* dbias, float beta_bias, void* workspace, int64_t workspace_bytes, void* stream);
+                           float* dbias, float beta_bias, void* workspace, int64_t workspace_bytes, const float* gscale,
+                           float* nonfinite, void* stream);
 
 /* Several weight gradients of the same backward pass in ONE launch (a transformer block's seven nn.Linear dW,
  * loss.backward(), tools/train_net.py:176-181): the (row slice, 256x256 tile) work items of all problems share the 256 CUs,
@@ -91,6 +99,8 @@ typedef struct pvrl_tn_problem {
   float beta;
   float* dW;                      /* fp32 [N, K] */
   float* dbias;                   /* fp32 [N] or null */
+  const float* gscale;            /* device scalar or null (see pvrl_gemm_tn_bf16) */
+  float* nonfinite;               /* device flag or null */
 } pvrl_tn_problem;
 int64_t pvrl_gemm_tn_grouped_plan_splits(int nprob, const pvrl_tn_problem* problems);
 int64_t pvrl_gemm_tn_grouped_workspace_bytes(int nprob, const pvrl_tn_problem* problems, int64_t splits);
@@ -102,7 +112,8 @@ int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* problems, int64_
  * bwd: dx_out = dx_in(optional) + dLN; dgamma/dbeta = beta_acc * old + sums over rows; optionally also writes
  *      dxs_bf16[m] = bf16(dxs_scale[m] * dx_out[m]) for m < dxs_rows (the next stage's bf16 GEMM operand, DropPath-scaled)
  *      and dxsum[c] = beta_acc * old + sum over m < dxs_rows of dx_out[m][c] (the UNscaled column sums = the gradient of a
- *      bias added after the DropPath scale, optional). */
+ *      bias added after the DropPath scale, optional).  gscale / nonfinite: see pvrl_gemm_tn_bf16 (dgamma, dbeta and dxsum are
+ *      parameter gradients: beta_acc * old + gscale * sums). */
 int pvrl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                        int64_t ldy, int out_is_f32, float* mean, float* rstd, int64_t M, int64_t C, void* stream);
 int64_t pvrl_layernorm_bwd_workspace_bytes(int64_t M, int64_t C);
@@ -110,7 +121,7 @@ int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float*
                        const float* rstd, const float* gamma, const float* dx_in, int64_t ldi, float* dx_out,
                        int64_t ldo, float beta_acc, float* dgamma, float* dbeta, void* workspace,
                        int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16, int64_t ldxs, const float* dxs_scale,
-                       int64_t dxs_rows, float* dxsum, void* stream);
+                       int64_t dxs_rows, float* dxsum, const float* gscale, float* nonfinite, void* stream);
 
 /* Temporal attention for T = 8 (Block.forward temporal branch, vit.py:129-135 via Attention.forward
  * vit.py:75-92): sequences are 8 consecutive rows of the packed qkv [rows][3*H*64]. */
@@ -197,6 +208,9 @@ int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, do
                   double weight_decay, int nesterov, int first_step, double gscale, const float* skip, void* stream);
 /* *flag = 1 when any of x[0, n) is inf / nan; never cleared here (zero it, then chain the buffers to check).  x 16-byte aligned. */
 int pvrl_nonfinite_flag_f32(const float* x, int64_t n, float* flag, void* stream);
+/* End of an optimiser step: *total += 1 when *flag != 0 (total may be null), then *flag = 0 -- the flag's life cycle belongs to the
+ * step that consumed it, whatever loop calls it. */
+int pvrl_flag_roll(float* flag, float* total, void* stream);
 
 /* softmax over the rows of an fp32 logit matrix: the eval-mode output `self.softmax(x)` (vit.py:355-356, mvit.py:203-204) */
 int pvrl_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, void* stream);
@@ -298,13 +312,15 @@ int pvrl_mvit_attn_bwd(const void* q, const void* k, const void* v, const void* 
  * caller-zeroed padded `bias_out` by the same launch. */
 /* y[r] = beta * y[r] + sum_c W[r][c] * x[c] for a small dense matrix W (fp32, or bf16 when w_is_bf16), fp32 x and y:
  * the bias products of the fused temporal branch, b_e = W_fc b_proj and db_proj = W_fc^T db_e (the latter on the
- * transposed bf16 operand copy), vit.py:131-134. */
+ * transposed bf16 operand copy), vit.py:131-134.  gscale (device scalar or null) multiplies the product (see pvrl_gemm_tn_bf16). */
 int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float* x, float beta, float* y,
-                       void* stream);
+                       const float* gscale, void* stream);
 
 /* out[r][c] += a[r] * b[c] (fp32; C and ld multiples of 4): the bias term of the fused temporal branch's chain rule,
- * dW_fc += db_e b_proj^T -- what autograd adds to temporal_fc.weight.grad through proj's bias, vit.py:131-134. */
-int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, void* stream);
+ * dW_fc += gscale * db_e b_proj^T -- what autograd adds to temporal_fc.weight.grad through proj's bias, vit.py:131-134
+ * (gscale: device scalar or null = 1). */
+int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, const float* gscale,
+                       void* stream);
 
 /* pvrl_cast_weight_bf16 for many weight matrices in one launch (the bf16 operand copies of every nn.Linear of the
  * encoder after an optimiser step): out [R][C] and, when out_t is not null, out_t [C][R], both dense. */

@@ -20,6 +20,8 @@ Rounding points (kernel that rounds -> where it appears below):
             attention output o                                   `R(o)`
             temporal branch: proj and temporal_fc folded into ONE matrix W_e = R(RW(W_fc) @ RW(W_proj)) (engine._fused_temporal)
             MLP: pre-activation u stored 16-bit for backward, g = R(gelu(u_fp32))    `GeluStore`
+            EXCEPT the cls rows (round 5, csrc/cls_chain.hip): their attn.proj (from the 16-bit o) and their whole MLP run in fp32 on
+            the master weights -- `linf`; their backward takes the 16-bit path, as in the kernels (`_value_of`)
   backward  the gradient operand of every GEMM is the 16-bit copy of (DropPath scale x fp32 residual gradient), or the
             16-bit output of the previous backward GEMM / attention kernel          backward half of `R`, and `RB`
             dGELU uses the 16-bit stored u; dS and P are rounded for the dQ/dK/dV MFMAs  `GeluStore`, `AttnMFMA`
@@ -122,6 +124,12 @@ class AttnMFMA(torch.autograd.Function):
         return ds @ k, ds.transpose(-2, -1) @ q, _rnd(p).transpose(-2, -1) @ do, None
 
 
+def _value_of(exact, rounded):
+    """the forward VALUE of `exact` with the backward of `rounded`: the cls rows' forward runs in fp32 (csrc/cls_chain.hip) while
+    their backward takes the 16-bit kernels' path on the activations that path saved"""
+    return rounded + (exact - rounded).detach()
+
+
 def attention_core(qkv, B, N, C, num_heads, mfma):
     qkv = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
@@ -141,6 +149,7 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
     s1, s2, s3 = dp if dp is not None else (None, None, None)
     ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), sd[pre + n + ".weight"], sd[pre + n + ".bias"], orc.LN_EPS_VIT)
     lin = lambda t, n: F.linear(t, RW(sd[pre + n + ".weight"]), sd[pre + n + ".bias"])
+    linf = lambda t, n: F.linear(t, sd[pre + n + ".weight"], sd[pre + n + ".bias"])
     # temporal (:129-135).  proj and temporal_fc are one matrix in the HIP engine (only a per-row DropPath scale sits
     # between them): x + fc(rs * proj(o)) = x + rs * (o W_e^T + W_fc b_proj) + b_fc, W_e = W_fc W_proj
     xt = x[:, 1:, :]
@@ -167,7 +176,10 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
     xs = torch.cat((cls_token, xs), 1)
     h = R(ln(xs, "norm1"))
     o = R(attention_core(R(lin(h, "attn.qkv")), xs.shape[0], xs.shape[1], C, num_heads, mfma=True))
-    res_spatial = orc.drop_path_apply(RB(lin(o, "attn.proj")), s2)
+    res_spatial = RB(lin(o, "attn.proj"))
+    if OPERAND is not None:     # the cls rows' projection runs on the fp32 master weight (csrc/cls_chain.hip), from the 16-bit o
+        res_spatial = torch.cat((_value_of(linf(o[:, :1], "attn.proj"), res_spatial[:, :1]), res_spatial[:, 1:]), 1)
+    res_spatial = orc.drop_path_apply(res_spatial, s2)
     cls_token = res_spatial[:, 0, :]
     cls_token = rearrange(cls_token, "(b t) m -> b t m", b=B, t=T)
     cls_token = torch.mean(cls_token, 1, True)
@@ -175,10 +187,14 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
     res_spatial = rearrange(res_spatial, "(b t) (h w) m -> b (h w t) m", b=B, h=H, w=W, t=T)
     # merge + MLP (:155-157)
     x = torch.cat((init_cls_token, xt), 1) + torch.cat((cls_token, res_spatial), 1)
-    h = R(ln(x, "norm2"))
+    hf = ln(x, "norm2")
+    h = R(hf)
     u = RB(lin(h, "mlp.fc1"))
     g = RW(GeluStore.apply(u)) if OPERAND is not None else F.gelu(u)
-    x = x + orc.drop_path_apply(RB(lin(g, "mlp.fc2")), s3)
+    y = RB(lin(g, "mlp.fc2"))
+    if OPERAND is not None:     # the cls rows' MLP in fp32 end to end: LayerNorm output, master weights, exact GELU (csrc/cls_chain.hip)
+        y = torch.cat((_value_of(linf(F.gelu(linf(hf[:, :1], "mlp.fc1")), "mlp.fc2"), y[:, :1]), y[:, 1:]), 1)
+    x = x + orc.drop_path_apply(y, s3)
     return x
 
 

@@ -227,13 +227,15 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 // (W_fc b_proj and W_fc^T db_e of the fused temporal branch: 768 x 768, a few microseconds)
 template <typename TW>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const TW* __restrict__ W, long ld, int R, int C,
-                                                        const float* __restrict__ x, float beta, float* __restrict__ y) {
+                                                        const float* __restrict__ x, float beta, float* __restrict__ y,
+                                                        const float* __restrict__ gscale) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   float a = 0.f;
   for (int c = lane; c < C; c += 64) a += (float)W[(long)r * ld + c] * x[c];
   a = wave_sum(a);
+  if (gscale) a *= *gscale;
   if (lane == 0) y[r] = (beta != 0.f ? beta * y[r] : 0.f) + a;
 }
 
@@ -397,16 +399,16 @@ extern "C" int pvrl_cast_weight_bf16(const float* in, void* out, void* out_t, in
 }
 
 extern "C" int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float* x, float beta,
-                                  float* y, void* stream) {
+                                  float* y, const float* gscale, void* stream) {
   if (R <= 0) return PVRL_OK;
   if (!W || !x || !y || C <= 0 || ld < C) return PVRL_EINVAL;
   const dim3 grid((unsigned)cdiv(R, 4)), blk(256);
   if (w_is_bf16)
     hipLaunchKernelGGL(gemv_rows_kernel<op_t>, grid, blk, 0, (hipStream_t)stream, (const op_t*)W, (long)ld, (int)R, (int)C,
-                       x, beta, y);
+                       x, beta, y, gscale);
   else
     hipLaunchKernelGGL(gemv_rows_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)W, (long)ld, (int)R, (int)C,
-                       x, beta, y);
+                       x, beta, y, gscale);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -472,23 +474,25 @@ extern "C" int pvrl_group_bcast_bf16(const float* in, int64_t ldi, int64_t group
 namespace {
 // out[r][c] += a[r] * b[c]   (torch.addr_ spends 54 us on this 768 x 768 update: a broadcast iterator, 4 bytes per thread)
 __global__ __launch_bounds__(256) void rank1_add_kernel(float* __restrict__ out, long ld, const float* __restrict__ a,
-                                                        const float* __restrict__ b, int R, int C4) {
+                                                        const float* __restrict__ b, int R, int C4,
+                                                        const float* __restrict__ gscale) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)R * C4) return;
   const int r = (int)(idx / C4), c = (int)(idx - (long)r * C4) * 4;
-  const float av = a[r];
+  const float av = gscale ? a[r] * *gscale : a[r];
   const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
   f32x4* o = reinterpret_cast<f32x4*>(out + (long)r * ld + c);
   *o = *o + av * bv;
 }
 }  // namespace
 
-extern "C" int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, void* stream) {
+extern "C" int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C,
+                                  const float* gscale, void* stream) {
   if (R <= 0 || C <= 0) return PVRL_OK;
   if (!out || !a || !b || (C % 4) || (ld % 4)) return PVRL_EINVAL;
   const long n = (long)R * (C / 4);
   hipLaunchKernelGGL(rank1_add_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)ld, a, b, (int)R,
-                     (int)(C / 4));
+                     (int)(C / 4), gscale);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }

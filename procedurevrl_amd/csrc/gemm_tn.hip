@@ -55,28 +55,29 @@ extern "C" int64_t pvrl_gemm_tn_workspace_bytes(int64_t N, int64_t K, int64_t sp
 namespace {
 int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K, int64_t splits,
                  float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid, float* dbias, float beta_bias,
-                 void* workspace, int64_t workspace_bytes, void* stream);
+                 void* workspace, int64_t workspace_bytes, const float* gscale, float* nonfinite, void* stream);
 }
 
 extern "C" int pvrl_gemm_tn_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
                                  int64_t K, int64_t splits, float beta, float* dW, float* dbias, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
-  return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, splits, beta, dW, K, N, K, dbias, beta, workspace, workspace_bytes, stream);
+                                 int64_t workspace_bytes, const float* gscale, float* nonfinite, void* stream) {
+  return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, splits, beta, dW, K, N, K, dbias, beta, workspace, workspace_bytes, gscale,
+                      nonfinite, stream);
 }
 
 extern "C" int pvrl_gemm_tn_into_bf16(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N,
                                       int64_t K, int64_t splits, float beta, float* dW, int64_t ldw, int64_t n_valid,
                                       int64_t k_valid, float* dbias, float beta_bias, void* workspace,
-                                      int64_t workspace_bytes, void* stream) {
+                                      int64_t workspace_bytes, const float* gscale, float* nonfinite, void* stream) {
   if (n_valid < 1 || n_valid > N || k_valid < 1 || k_valid > K || ldw < k_valid) return PVRL_EINVAL;
   return gemm_tn_impl(P, ldp, Q, ldq, M, N, K, splits, beta, dW, ldw, n_valid, k_valid, dbias, beta_bias, workspace,
-                      workspace_bytes, stream);
+                      workspace_bytes, gscale, nonfinite, stream);
 }
 
 namespace {
 int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K, int64_t splits,
                  float beta, float* dW, int64_t ldw, int64_t n_valid, int64_t k_valid, float* dbias, float beta_bias,
-                 void* workspace, int64_t workspace_bytes, void* stream) {
+                 void* workspace, int64_t workspace_bytes, const float* gscale, float* nonfinite, void* stream) {
   if (!P || !Q || !dW || !workspace || N <= 0 || K <= 0 || (N % 128) || (K % 128) || splits < 1 || M < 0)
     return PVRL_EINVAL;
   const bool use_rt = tn_use_rt(N, K);
@@ -112,19 +113,19 @@ int gemm_tn_impl(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t
   if (into) {
     if (beta_bias != beta && dbias) {       // one beta per launch: the bias gets its own pass of the small kernel
       hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(NK >> 2, 64)), dim3(256), 0, s, p.part, p.cpart,
-                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, (float*)nullptr);
+                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, (float*)nullptr, gscale, nonfinite);
       hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, s, p.part, p.cpart,
-                         (int)splits, 0L, (int)N, (int)K, beta_bias, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias);
+                         (int)splits, 0L, (int)N, (int)K, beta_bias, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias, gscale, nonfinite);
     } else {
       hipLaunchKernelGGL(tn_reduce_into_kernel, dim3((unsigned)cdiv(nthreads, 64)), dim3(256), 0, s, p.part, p.cpart,
-                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias);
+                         (int)splits, NK, (int)N, (int)K, beta, dW, (long)ldw, (int)n_valid, (int)k_valid, dbias, gscale, nonfinite);
     }
   } else if (nthreads < 64 * 256 && splits >= 8)
     hipLaunchKernelGGL(tn_reduce_small_kernel, dim3((unsigned)cdiv(nthreads, 64)), dim3(256), 0, s, p.part, p.cpart,
-                       (int)splits, NK, (int)N, beta, dW, dbias);
+                       (int)splits, NK, (int)N, beta, dW, dbias, gscale, nonfinite);
   else
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
-                       (int)splits, NK, (int)N, beta, dW, dbias);
+                       (int)splits, NK, (int)N, beta, dW, dbias, gscale, nonfinite);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
@@ -216,7 +217,7 @@ extern "C" int pvrl_gemm_tn_grouped_bf16(int nprob, const pvrl_tn_problem* probl
   for (int i = 0; i < nprob; ++i) {
     const pvrl_tn_problem& q = problems[i];
     r.part[i] = g.prob[i].part; r.cpart[i] = g.prob[i].cpart; r.out[i] = q.dW; r.bias_out[i] = q.dbias;
-    r.NK[i] = q.N * q.K; r.N[i] = (int)q.N; r.beta[i] = q.beta;
+    r.NK[i] = q.N * q.K; r.N[i] = (int)q.N; r.beta[i] = q.beta; r.gscale[i] = q.gscale; r.nonfinite[i] = q.nonfinite;
     r.first[i] = blocks;
     blocks += (int)cdiv((r.NK[i] >> 2) + (q.dbias ? q.N : 0), 256);
   }

@@ -457,27 +457,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rt8_grouped_kernel(TnGroup g) 
   tn_rt8_pair(p, gp - g.first[q], smem);
 }
 
-// out[n][k] = beta*out + sum_s part[s][n][k];  bias_out[n] = beta*bias_out + sum_s cpart[s][n]
+// Gradient outputs, common tail of every reduce below.  `gscale` (device scalar or null): the sum is multiplied by it -- the fp16-operand
+// flavour runs a backward in S-scaled units (engine.GradStore.begin_scaled) and the kernel that writes a parameter gradient takes the
+// scale out again, instead of a separate pass over the gradient buffer; what is already in `out` (beta) is in true units.  `nonfinite`
+// (device flag or null): raised when a value written is inf / nan -- the optimiser's "skip this step" flag (optim.hip), checked where
+// the gradient is produced instead of by a scan of the whole buffer.  The flag is only ever raised here.
+__device__ __forceinline__ bool nonfinite1(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool nonfinite4(const f32x4& v) { return nonfinite1(v[0]) | nonfinite1(v[1]) | nonfinite1(v[2]) | nonfinite1(v[3]); }
+__device__ __forceinline__ void raise_if(bool bad, float* flag) {
+  if (flag && __any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
+}
+
+// out[n][k] = beta*out + gscale * sum_s part[s][n][k];  bias_out[n] = beta*bias_out + gscale * sum_s cpart[s][n]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                         int splits, long NK, int N, float beta,
-                                                        float* __restrict__ out, float* __restrict__ bias_out) {
+                                                        float* __restrict__ out, float* __restrict__ bias_out,
+                                                        const float* __restrict__ gscale, float* __restrict__ nonfinite) {
   const long idx4 = (long)blockIdx.x * 256 + threadIdx.x;
   const long n4 = NK >> 2;
+  const float gsc = gscale ? *gscale : 1.f;
+  bool bad = false;
   if (idx4 < n4) {
     f32x4 a = reinterpret_cast<const f32x4*>(part)[idx4];
     for (int s = 1; s < splits; ++s) {
       const f32x4 b = reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
       a += b;
     }
+    if (gscale) a *= gsc;
     if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
     reinterpret_cast<f32x4*>(out)[idx4] = a;
+    bad = nonfinite4(a);
   } else if (bias_out && idx4 - n4 < N) {
     const int n = (int)(idx4 - n4);
     float a = 0.f;
     for (int s = 0; s < splits; ++s) a += cpart[(long)s * N + n];
+    if (gscale) a *= gsc;
     if (beta != 0.f) a += beta * bias_out[n];
     bias_out[n] = a;
+    bad = nonfinite1(a);
   }
+  raise_if(bad, nonfinite);
 }
 
 // The same for SMALL outputs (MViT's 96..768-wide layers: a 128 x 128 dW is 4,096 float4s = 16 workgroups above, each
@@ -485,7 +504,8 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // fixed order -- four times the workgroups and a quarter of the serial chain.
 __global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                               int splits, long NK, int N, float beta,
-                                                              float* __restrict__ out, float* __restrict__ bias_out) {
+                                                              float* __restrict__ out, float* __restrict__ bias_out,
+                                                              const float* __restrict__ gscale, float* __restrict__ nonfinite) {
   __shared__ f32x4 red[3][64];
   const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long idx4 = (long)blockIdx.x * 64 + o;
@@ -501,13 +521,19 @@ __global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __res
   __syncthreads();
   if (sl == 0) {
     a = (a + red[0][o]) + (red[1][o] + red[2][o]);
+    if (gscale) a *= *gscale;
+    bool bad = false;
     if (is_w) {
       if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
       reinterpret_cast<f32x4*>(out)[idx4] = a;
+      bad = nonfinite4(a);
     } else if (is_b) {
       const int n = (int)(idx4 - n4);
-      bias_out[n] = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+      const float v = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+      bias_out[n] = v;
+      bad = nonfinite1(v);
     }
+    raise_if(bad, nonfinite);
   }
 }
 
@@ -517,7 +543,8 @@ __global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __res
 __global__ __launch_bounds__(256) void tn_reduce_into_kernel(const float* __restrict__ part, const float* __restrict__ cpart,
                                                              int splits, long NK, int N, int K, float beta,
                                                              float* __restrict__ out, long ldo, int nv, int kv,
-                                                             float* __restrict__ bias_out) {
+                                                             float* __restrict__ bias_out,
+                                                             const float* __restrict__ gscale, float* __restrict__ nonfinite) {
   __shared__ f32x4 red[3][64];
   const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long idx4 = (long)blockIdx.x * 64 + o;
@@ -533,6 +560,8 @@ __global__ __launch_bounds__(256) void tn_reduce_into_kernel(const float* __rest
   __syncthreads();
   if (sl == 0) {
     a = (a + red[0][o]) + (red[1][o] + red[2][o]);
+    if (gscale) a *= *gscale;
+    bool bad = false;
     if (is_w) {
       const int k4 = K >> 2;
       const int n = (int)(idx4 / k4), k = (int)(idx4 - (long)n * k4) * 4;
@@ -540,12 +569,21 @@ __global__ __launch_bounds__(256) void tn_reduce_into_kernel(const float* __rest
         float* dst = out + (long)n * ldo + k;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + e < kv) dst[e] = beta != 0.f ? a[e] + beta * dst[e] : a[e];
+          if (k + e < kv) {
+            const float v = beta != 0.f ? a[e] + beta * dst[e] : a[e];
+            dst[e] = v;
+            bad |= nonfinite1(v);
+          }
       }
     } else if (is_b) {
       const int n = (int)(idx4 - n4);
-      if (n < nv) bias_out[n] = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+      if (n < nv) {
+        const float v = beta != 0.f ? a[0] + beta * bias_out[n] : a[0];
+        bias_out[n] = v;
+        bad = nonfinite1(v);
+      }
     }
+    raise_if(bad, nonfinite);
   }
 }
 
@@ -557,6 +595,7 @@ struct TnReduceGroup {
   const float* part[TN_RED_MAX]; const float* cpart[TN_RED_MAX];
   float* out[TN_RED_MAX]; float* bias_out[TN_RED_MAX];
   long NK[TN_RED_MAX]; int N[TN_RED_MAX]; float beta[TN_RED_MAX];
+  const float* gscale[TN_RED_MAX]; float* nonfinite[TN_RED_MAX];
 };
 __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnReduceGroup g) {
   int q = 0;
@@ -570,20 +609,28 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnReduceGroup g)
   const long NK = g.NK[q];
   const int N = g.N[q];
   const float beta = g.beta[q];
+  const float* gscale = g.gscale[q];
+  const float gsc = gscale ? *gscale : 1.f;
   const long idx4 = (long)((int)blockIdx.x - g.first[q]) * 256 + threadIdx.x;
   const long n4 = NK >> 2;
+  bool bad = false;
   if (idx4 < n4) {
     f32x4 a = reinterpret_cast<const f32x4*>(part)[idx4];
     for (int s = 1; s < g.splits; ++s) a += reinterpret_cast<const f32x4*>(part + (long)s * NK)[idx4];
+    if (gscale) a *= gsc;
     if (beta != 0.f) a += beta * reinterpret_cast<f32x4*>(out)[idx4];
     reinterpret_cast<f32x4*>(out)[idx4] = a;
+    bad = nonfinite4(a);
   } else if (bias_out && idx4 - n4 < N) {
     const int n = (int)(idx4 - n4);
     float a = 0.f;
     for (int s = 0; s < g.splits; ++s) a += cpart[(long)s * N + n];
+    if (gscale) a *= gsc;
     if (beta != 0.f) a += beta * bias_out[n];
     bias_out[n] = a;
+    bad = nonfinite1(a);
   }
+  raise_if(bad, g.nonfinite[q]);
 }
 
 }  // namespace

@@ -160,11 +160,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   }
 }
 
-// out[j] = beta*out[j] + sum_b part[b][j]   (j over 2*C: dgamma then dbeta)
+// out[j] = beta*out[j] + gscale * sum_b part[b][j]   (j over 2*C: dgamma then dbeta); gscale / nonfinite as in gemm_tn_core.h: the
+// scale of the fp16 flavour's S-scaled backward is taken out where the parameter gradient is written, and a non-finite value
+// written raises the optimiser's skip flag
 // 16 columns x 16 row groups per block (64-byte row segments), LDS tree at the end: 96 blocks for C = 768.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta,
                                                              float* __restrict__ out0, float* __restrict__ out1,
-                                                             int half, int pstride) {
+                                                             int half, int pstride, const float* __restrict__ gscale,
+                                                             float* __restrict__ nonfinite) {
   __shared__ float red[16][17];
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
@@ -181,7 +184,10 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][c];
     float* o = (j < half) ? out0 + j : out1 + (j - half);
-    *o = (beta != 0.f ? beta * *o : 0.f) + t;
+    if (gscale) t *= *gscale;
+    const float v = (beta != 0.f ? beta * *o : 0.f) + t;
+    *o = v;
+    if (nonfinite && (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u) *nonfinite = 1.f;
   }
 }
 
@@ -221,7 +227,8 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
                                   const float* mean, const float* rstd, const float* gamma, const float* dx_in,
                                   int64_t ldi, float* dx_out, int64_t ldo, float beta_acc, float* dgamma, float* dbeta,
                                   void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16,
-                                  int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, float* dxsum, void* stream) {
+                                  int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, float* dxsum, const float* gscale,
+                                  float* nonfinite, void* stream) {
   if (M <= 0) return PVRL_OK;
   if (!dy || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta || !workspace) return PVRL_EINVAL;
   if ((ldx % 4) || (lddy % 4) || (ldo % 4) || (dx_in && (ldi % 4))) return PVRL_EINVAL;
@@ -245,11 +252,11 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, s, part, nblk,
-                     (int)(2 * C), beta_acc, dgamma, dbeta, (int)C, pstride);
+                     (int)(2 * C), beta_acc, dgamma, dbeta, (int)C, pstride, gscale, nonfinite);
   PVRL_LAUNCH_CHECK();
   if (dxsum) {
     hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, part + 2 * C, nblk, (int)C,
-                       beta_acc, dxsum, dxsum, (int)C, pstride);
+                       beta_acc, dxsum, dxsum, (int)C, pstride, gscale, nonfinite);
     PVRL_LAUNCH_CHECK();
   }
   return PVRL_OK;

@@ -88,7 +88,20 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
   if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
 }
 
+// end of an optimiser step: count it when it was dropped and re-arm the flag for the next one
+__global__ void flag_roll_kernel(float* __restrict__ flag, float* __restrict__ total) {
+  if (*flag != 0.f && total) *total += 1.f;
+  *flag = 0.f;
+}
+
 }  // namespace
+
+extern "C" int pvrl_flag_roll(float* flag, float* total, void* stream) {
+  if (!flag) return PVRL_EINVAL;
+  hipLaunchKernelGGL(flag_roll_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, total);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
 
 extern "C" int pvrl_nonfinite_flag_f32(const float* x, int64_t n, float* flag, void* stream) {
   if (n <= 0) return PVRL_OK;

@@ -47,20 +47,28 @@ class GradStore:
         # tail: one float per parameter, "this rank produced a gradient for it" -- summed over ranks inside the last
         # chunk of the data-parallel all-reduce (distributed.GradReducer, DDP's find_unused_parameters bookkeeping) -- and one
         # control slot behind them ("a rank asks for a re-synchronisation of the replicas", GradReducer find_unused="cached")
-        self.flat = torch.zeros(off + (len(sizes) + 1 + 63) // 64 * 64, device=device, dtype=F32)
+        # ... and behind it `bad`, the optimiser's "skip this step" flag (csrc/optim.hip): raised on the device by the kernels that
+        # write parameter gradients when a value is inf / nan and by the training loop when a loss is; summed over ranks with the
+        # rest of the tail, so every replica drops the same step (misc.check_nan_losses, tools/train_net.py:174)
+        self.flat = torch.zeros(off + (len(sizes) + 2 + 63) // 64 * 64, device=device, dtype=F32)
         self.used = self.flat[off:off + len(sizes)]
         self.ctl = self.flat[off + len(sizes):off + len(sizes) + 1]
+        self.bad = self.flat[off + len(sizes) + 1:off + len(sizes) + 2]
+        self.fused_checked = set()     # parameters whose gradient producers raise `bad` themselves (target(..., fused=True))
         self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.scale = None       # fp16 flavour: device scalar S while an engine's backward runs with S-scaled gradients
+        self.inv = None         # ... and 1 / S: the `gscale` of the kernels that write parameter gradients (include/pvrl.h)
         self._touched = []
 
     def span(self, i):
         """[a, b) of parameter i in the flat buffer, padding included"""
         return self.offsets[i], (self.offsets[i + 1] if i + 1 < len(self.offsets) else self.end)
 
-    def target(self, p):
-        """-> (grad tensor to write into, beta).  beta = 0 overwrites, 1 accumulates."""
+    def target(self, p, fused=False):
+        """-> (grad tensor to write into, beta).  beta = 0 overwrites, 1 accumulates.
+        `fused`: the caller's kernel computes  grad = beta * grad + self.inv * (its S-scaled result)  itself (`gscale`) and raises
+        `self.bad` on a non-finite value (`nonfinite`): nothing is registered for unscale(), what is already there stays in true units."""
         i = self.index[id(p)]
         v = self.views[i]
         if p.grad is None:
@@ -70,6 +78,10 @@ class GradStore:
             t, beta = v, 1.0
         else:       # a foreign .grad tensor (someone else allocated it): accumulate into it
             t, beta = p.grad, 1.0
+        if fused:
+            if t is v:
+                self.fused_checked.add(i)
+            return t, beta
         if self.scale is not None:
             key = i if t is v else t
             seen = self._seen_idx if t is v else self._seen_ptr
@@ -115,7 +127,9 @@ class GradStore:
         # of two, so the non-finite values flow through to the loss check (train_epoch) instead of poisoning gradients
         # accumulated by earlier micro-iterations
         amax = torch.nan_to_num(g.detach().abs().max(), nan=1.0, posinf=3e38).clamp(1e-30, 3e38)
-        self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)).clamp(-100.0, 100.0))
+        self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1)
+        self.inv = 1.0 / self.scale
+        self.inv_row = self.inv.expand(4096).contiguous()      # 1 / S as a GEMM epilogue's per-row scale (EncoderEngine._temporal_chain)
         self._touched, self._seen_idx, self._seen_ptr = [], set(), set()
         return g * self.scale
 
@@ -123,7 +137,7 @@ class GradStore:
         """multiply every gradient written since the last call by 1/S (contiguous runs of the flat buffer in one op each)"""
         if self.scale is None or not self._touched:
             return
-        inv = 1.0 / self.scale
+        inv = self.inv
         idx = sorted(set(k for k in self._touched if isinstance(k, int)))
         runs = []
         for i in idx:
@@ -144,8 +158,8 @@ class GradStore:
     def end_scaled(self):
         """-> 1/S (device scalar) for gradients the engine hands back to autograd (StackEngine's dx)"""
         self.unscale()
-        inv = 1.0 / self.scale
-        self.scale = None
+        inv = self.inv
+        self.scale = self.inv = None
         return inv
 
 
@@ -467,16 +481,19 @@ class EncoderEngine(GraphReplay):
         wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
         ef, ep = self._weight(wf), self._weight(wp)
         dwe_b, dwe_t = ops.cast_weight(dwe)                                   # bf16 [out, in] and [in, out]
+        # dW_e / db_e are in the backward's S-scaled units (fp16 flavour; their 16-bit copies above must stay mid-range); the scale
+        # is taken out where the four parameter gradients are written: a row scale of 1 / S in the GEMM epilogues, `gscale` below
+        rs = gs.inv_row if gs.inv is not None else None
         for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t)):            # [out,mid] = dW_e.W_p^T ; [mid,in] = W_f^T.dW_e
-            g, beta = gs.target(lin_w)
+            g, beta = gs.target(lin_w, fused=True)
             if beta == 0.0:
-                ops.gemm_nt(A, W, L.PVRL_EPI_F32, out0=g)
+                ops.gemm_nt(A, W, L.PVRL_EPI_F32, rowscale=rs, out0=g)
             else:
-                ops.gemm_nt(A, W, L.PVRL_EPI_RESID_F32, aux=g, out0=g)
+                ops.gemm_nt(A, W, L.PVRL_EPI_RESID_F32, rowscale=rs, aux=g, out0=g)
         # proj's bias rides through temporal_fc too (b_e = W_fc b_proj): its share of dW_fc is the outer product db_e x b_proj
-        ops.rank1_add(gs.target(wf)[0], dbe, blk.temporal_attn.proj.bias.detach())
-        gb, beta = gs.target(blk.temporal_attn.proj.bias)
-        ops.gemv_rows(ef.t, dbe, out=gb, beta=beta)                           # [mid] = W_fc^T db_e (bf16 operand copy)
+        ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
+        gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
+        ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)            # [mid] = W_fc^T db_e (bf16 operand copy)
 
     def grad_store(self):
         return self.m.grad_store()
@@ -493,10 +510,10 @@ class EncoderEngine(GraphReplay):
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def _wgrad(self, dy, xin, dw, dbias, beta, post=None):
-        """queue dW = beta*dW + dy^T xin (and dbias); `flush_wgrads` issues what is queued.  `post` (optional callable)
+    def _wgrad(self, dy, xin, dw, dbias, beta, post=None, gscale=None, nonfinite=None):
+        """queue dW = beta*dW + gscale * dy^T xin (and dbias); `flush_wgrads` issues what is queued.  `post` (optional callable)
         runs right behind the launch on the same stream (consumers of dW)."""
-        self._wq.append((dy, xin, dw, dbias, beta))
+        self._wq.append((dy, xin, dw, dbias, beta, gscale, nonfinite))
         if post is not None:
             self._wpost.append(post)
         if not self.group_wgrad:
@@ -526,7 +543,7 @@ class EncoderEngine(GraphReplay):
         # record makes EACH later allocation poll its event (measured: torch.empty 2 -> 52 us with ~170 records in flight,
         # 20 ms of host time per step); instead the references are parked here until the launch's event has completed,
         # or until join_side_stream() has ordered the main stream behind the side stream.
-        self._side_keep.append((done, [t for dy, xin, dw, db, _ in q for t in (dy, xin, dw, db) if t is not None]))
+        self._side_keep.append((done, [t for pr in q for t in pr[:4] + pr[5:6] if t is not None]))
         while not self._capturing and self._side_keep and self._side_keep[0][0].query():
             self._side_keep.pop(0)        # (no event queries while capturing: there everything is held until the join)
 
@@ -755,10 +772,9 @@ class EncoderEngine(GraphReplay):
             dfeat = gs.begin_scaled(dfeat)
         dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
         mean, rstd = sv["norm_stats"]
-        (dg, bg), (db, bb) = gs.target(m.norm.weight), gs.target(m.norm.bias)
+        (dg, bg), (db, bb) = gs.target(m.norm.weight, fused=True), gs.target(m.norm.bias, fused=True)
         ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
-                          dx_out=dx[R:], beta_acc=bg)
-        gs.unscale()
+                          dx_out=dx[R:], beta_acc=bg, gscale=gs.inv, nonfinite=gs.bad)
         # dy = bf16(DropPath-scale * dx) is the operand of each block's first backward GEMMs; after the first block it is
         # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
         last = len(m.blocks) - 1
@@ -779,10 +795,13 @@ class EncoderEngine(GraphReplay):
         B, T, N, R, C = sv["B"], sv["T"], sv["N"], sv["R"], self.C
         dz = dy[:R]     # block 0's last LayerNorm backward emitted the unscaled bf16 copy of dx[:R]
         w = m.patch_embed.proj.weight
-        (dw, bw), (dbias, _) = gs.target(w), gs.target(m.patch_embed.proj.bias)
-        self._wgrad(dz, sv["a_pe"], dw.view(C, -1), dbias, bw)
+        (dw, bw), (dbias, _) = gs.target(w, fused=True), gs.target(m.patch_embed.proj.bias, fused=True)
+        self._wgrad(dz, sv["a_pe"], dw.view(C, -1), dbias, bw, gscale=gs.inv, nonfinite=gs.bad)
         G = ops.batch_sum(dx[:R], B, N * T).view(N, T, C)
         dcls_rows = dx[R:].sum(0)
+        if gs.inv is not None:       # the three small embedding gradients below are sums of these: the scale is taken out here
+            G = G * gs.inv           # (a non-finite value in dx reaches the patch-embed weight gradient above, which raises gs.bad)
+            dcls_rows = dcls_rows * gs.inv
         self._acc(gs, m.cls_token, dcls_rows.view(1, 1, C))
         dpos = torch.cat([dcls_rows.unsqueeze(0), G.sum(1)], 0)
         dtime = G.sum(0)
@@ -792,8 +811,6 @@ class EncoderEngine(GraphReplay):
                                       "resizes at inference only, vit.py:374)")
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
-        if gs.scale is not None:
-            self._wpost.append(gs.unscale)      # behind the patch-embed weight gradient, on its stream
         self.flush_wgrads()
         self.join_side_stream()
         if gs.scale is not None:
@@ -802,7 +819,7 @@ class EncoderEngine(GraphReplay):
 
     @staticmethod
     def _acc(gs, p, g):
-        tgt, beta = gs.target(p)
+        tgt, beta = gs.target(p, fused=True)      # (g is in true units already; see _bwd_end)
         if beta == 0.0:
             tgt.copy_(g.view_as(tgt))
         else:
@@ -820,14 +837,16 @@ class EncoderEngine(GraphReplay):
         s3_all = dp["s3_all"] if dp else None
         P = lambda t: t.detach()
 
+        # every parameter gradient of the block is written by a kernel that takes the backward's scale out itself (`gscale` = 1 / S,
+        # fp16 flavour) and raises the optimiser's skip flag on a non-finite value (`nonfinite`): no pass over the gradient buffer
         def wgrad(dy, xin, lin):
-            (dw, bw), (dbias, _) = gs.target(lin.weight), gs.target(lin.bias)
-            self._wgrad(dy, xin, dw, dbias, bw)
+            (dw, bw), (dbias, _) = gs.target(lin.weight, fused=True), gs.target(lin.bias, fused=True)
+            self._wgrad(dy, xin, dw, dbias, bw, gscale=gs.inv, nonfinite=gs.bad)
 
         def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None, dxsum=None, dxsum_beta=None):
-            (dg, bg), (db, _) = gs.target(ln.weight), gs.target(ln.bias)
+            (dg, bg), (db, _) = gs.target(ln.weight, fused=True), gs.target(ln.bias, fused=True)
             ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg,
-                              dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta)
+                              dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta, gscale=gs.inv, nonfinite=gs.bad)
 
         # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
         wgrad(dy, s["g"], blk.mlp.fc2)
@@ -851,7 +870,7 @@ class EncoderEngine(GraphReplay):
         del dqkv, do, dps
         # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
         dz = torch.empty((R, C), device=dev, dtype=OP16)
-        dbf, bbf = gs.target(blk.temporal_fc.bias)
+        dbf, bbf = gs.target(blk.temporal_fc.bias, fused=True)
         lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz, dxs_scale=s1_tok, dxsum=dbf, dxsum_beta=bbf)
 
         # ---- temporal (rows [0, R); cls rows pass straight through): proj + temporal_fc as ONE map W_e (_fused_temporal)
@@ -873,7 +892,5 @@ class EncoderEngine(GraphReplay):
         lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R], dxs=dy_next[:R], dxs_scale=s3p)
         if has_prev:
             ops.cast_scale(dx[R:], s3p[R:] if s3p is not None else None, out=dy_next[R:])
-        if gs.scale is not None:
-            self._wpost.append(gs.unscale)      # this block's gradients are final behind the grouped launch + chain
         self.flush_wgrads()
         return dy_next

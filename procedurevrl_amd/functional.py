@@ -20,7 +20,9 @@ class EncoderFn(torch.autograd.Function):
     def forward(ctx, anchor, frames, owner, droppath):
         eng = owner.engine
         need = bool(ctx.needs_input_grad[0])
-        feat = eng.forward(frames, training=owner.training, droppath=droppath, save=need)
+        # DropPath lives in the blocks (vit.py:110-117): `model.blocks.eval()` of the linear-probing loop (tools/train_net.py:72-85)
+        # switches it off while the wrapper stays in train mode, so the blocks' flag decides, not the wrapper's
+        feat = eng.forward(frames, training=owner.blocks.training, droppath=droppath, save=need)
         ctx.owner = owner
         return feat
 
@@ -36,7 +38,7 @@ class StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, owner, resblocks, nseq, S, causal, kpm, heads, anchor):
         from .tfm_engine import StackEngine
-        eng = StackEngine(resblocks, owner.weight_cache, owner.grad_target, heads=heads)
+        eng = StackEngine(resblocks, owner.weight_cache, owner.grad_target, heads=heads, grad_store=getattr(owner, "grad_store", None))
         need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[8])
         y, saved = eng.forward(x.contiguous(), nseq, S, causal=causal, kpm=kpm, save=need)
         ctx.eng, ctx.saved_acts, ctx.owner_ref = eng, saved, owner

@@ -106,7 +106,7 @@ class PretrainHeadEngine:
         h1 = ops.gemm_nt_f32(E, m1.weight.detach().contiguous(), m1.bias.detach())
         g1 = ops.gelu_f32(h1)
         tm = ops.gemm_nt_f32(g1, m3.weight.detach().contiguous(), m3.bias.detach())           # [levels, C]
-        eng = StackEngine(ot.temporalModelling.resblocks, self._wc, o.grad_target, heads=ot.tfm_heads)
+        eng = StackEngine(ot.temporalModelling.resblocks, self._wc, o.grad_target, heads=ot.tfm_heads, grad_store=o.grad_store)
         inter, levels = [], []
         denoised = None
         for i in range(lv):
@@ -156,22 +156,23 @@ class PretrainHeadEngine:
         if d_inter_mse is not None:
             d_inter = d_inter + d_inter_mse
         # the denoise levels: each level's input is detached from the previous level's output (tfm_model.py:176-178), so the
-        # levels back-propagate independently; parameter gradients of the shared stack accumulate over them
-        D = torch.zeros((b, L, C), device=dev, dtype=F32)
-        d_tm = torch.empty((lv, C), device=dev, dtype=F32)
+        # levels back-propagate independently -- as ONE stack backward over levels x b sequences (the saved activations of the
+        # levels concatenated row-wise: 36-row tensors), a quarter of the launches of four passes; the shared stack's parameter
+        # gradients are then sums over all levels' rows inside one weight-gradient launch each
         eng = sv["eng"]
-        for i in range(lv - 1, -1, -1):
-            d_out = torch.zeros((b * L, C), device=dev, dtype=F32)
-            d_out.index_copy_(0, sv["rows"], d_inter[i * b:(i + 1) * b])
-            if SCALED_GRADS:                     # fp16-operand flavour: the stack's backward runs in S-scaled units
-                d_cur = eng.backward(gs.begin_scaled(d_out), sv["levels"][i])
-                d_cur = d_cur * gs.end_scaled()
-            else:
-                d_cur = eng.backward(d_out, sv["levels"][i])
-            sv["levels"][i] = None
-            d_cur = d_cur.view(b, L, C)
-            d_tm[i] = d_cur.sum((0, 1))
-            D += d_cur
+        d_out = torch.zeros((lv, b * L, C), device=dev, dtype=F32)
+        d_out.index_copy_(1, sv["rows"], d_inter.view(lv, b, C))
+        d_out = d_out.view(lv * b * L, C)
+        allsv = self._merge_levels(sv["levels"])
+        if SCALED_GRADS:                         # fp16-operand flavour: the stack's backward runs in S-scaled units
+            d_cur = eng.backward(gs.begin_scaled(d_out), allsv)
+            d_cur = d_cur * gs.end_scaled()
+        else:
+            d_cur = eng.backward(d_out, allsv)
+        sv["levels"] = None
+        d_cur = d_cur.view(lv, b, L, C)
+        d_tm = d_cur.sum((1, 2))
+        D = d_cur.sum(0)
         is_mask, pad_mask = sv["is_mask"], sv["pad_mask"]
         zero = torch.zeros((), device=dev, dtype=F32)
         d_type = torch.stack((torch.where(is_mask, zero, D).sum((0, 1)), torch.where(is_mask, D, zero).sum((0, 1))))
@@ -202,6 +203,25 @@ class PretrainHeadEngine:
                 t.add_(g.view_as(t))
         self.saved = None
         return d_feat
+
+    @staticmethod
+    def _merge_levels(levels):
+        """saved activations of the denoise levels (StackEngine.forward, one dict per level) -> one dict over levels x b sequences"""
+        first = levels[0]
+        cat = lambda ts: torch.cat(ts, 0)
+        blocks = []
+        for j in range(len(first["blocks"])):
+            per = [lvl["blocks"][j] for lvl in levels]
+            blk = {}
+            for k, v in per[0].items():
+                if isinstance(v, tuple):
+                    blk[k] = tuple(cat([p[k][e] for p in per]) for e in range(len(v)))
+                else:
+                    blk[k] = cat([p[k] for p in per])
+            blocks.append(blk)
+        kpm = first["kpm"]
+        return dict(blocks=blocks, nseq=first["nseq"] * len(levels), S=first["S"], causal=first["causal"],
+                    kpm=None if kpm is None else kpm.repeat(len(levels), 1))
 
     # ------------------------------------------------------------------ HIP graphs
     def _key(self, feat, teacher_x):

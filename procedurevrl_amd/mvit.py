@@ -530,7 +530,8 @@ class MViTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, frames, owner, droppath=None):
         need = bool(ctx.needs_input_grad[0])
-        feat = owner.engine.forward(frames, training=owner.training, save=need, droppath=droppath)
+        # (DropPath belongs to the encoder's blocks: `video_encoder.eval()` of the linear-probing loop, tools/train_net.py:72-85, switches it off)
+        feat = owner.engine.forward(frames, training=owner.video_encoder.training, save=need, droppath=droppath)
         ctx.owner = owner
         return feat
 

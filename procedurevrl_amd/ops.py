@@ -158,8 +158,9 @@ def tn_splits(M, N, K):
     return lib().call("pvrl_gemm_tn_plan_splits", M, N, K)
 
 
-def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
-    """dW[N,K] = beta*dW + P[M,N]^T @ Q[M,K]; dbias = beta*dbias + colsum(P)."""
+def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn", gscale=None, nonfinite=None):
+    """dW[N,K] = beta*dW + gscale * P[M,N]^T @ Q[M,K]; dbias = beta*dbias + gscale * colsum(P).  gscale (device scalar tensor or
+    None = 1) / nonfinite (device flag tensor or None): the common tail of the gradient-writing entry points, include/pvrl.h."""
     L = lib()
     _chk2d(P, OP16); _chk2d(Q, OP16)
     M, N = P.shape
@@ -171,11 +172,11 @@ def gemm_tn(P, Q, dW, dbias=None, beta=0.0, splits=None, ws_tag="tn"):
     ws = workspace(nbytes, P.device, ws_tag)
     _timed("gemm_tn_kernel+reduce", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_tn_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), _ptr(dbias),
-        _ptr(ws), ws.numel(), _stream()))
+        _ptr(ws), ws.numel(), _ptr(gscale), _ptr(nonfinite), _stream()))
     return dW
 
 
-def gemm_tn_into(P, Q, dW, n_valid, k_valid, dbias=None, beta=0.0, beta_bias=0.0, ws_tag="tn"):
+def gemm_tn_into(P, Q, dW, n_valid, k_valid, dbias=None, beta=0.0, beta_bias=0.0, ws_tag="tn", gscale=None, nonfinite=None):
     """dW[:n_valid, :k_valid] (fp32, row stride dW.stride(0)) = beta*dW + (P^T Q)[:n_valid, :k_valid] for zero-padded
     operands P [M, Np], Q [M, Kp]; dbias[:n_valid] likewise with beta_bias."""
     L = lib()
@@ -189,7 +190,7 @@ def gemm_tn_into(P, Q, dW, n_valid, k_valid, dbias=None, beta=0.0, beta_bias=0.0
     ws = workspace(L.call("pvrl_gemm_tn_workspace_bytes", N, K, splits), P.device, ws_tag)
     _timed("gemm_tn_kernel+reduce", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_tn_into_bf16", _ptr(P), _ld(P), _ptr(Q), _ld(Q), M, N, K, splits, float(beta), _ptr(dW), dW.stride(0),
-        n_valid, k_valid, _ptr(dbias), float(beta_bias), _ptr(ws), ws.numel(), _stream()))
+        n_valid, k_valid, _ptr(dbias), float(beta_bias), _ptr(ws), ws.numel(), _ptr(gscale), _ptr(nonfinite), _stream()))
     return dW
 
 
@@ -197,22 +198,22 @@ TN_GROUP_MAX = 8
 
 
 def gemm_tn_grouped(problems, ws_tag="tn_group"):
-    """problems: list of (P, Q, dW, dbias | None, beta), each as gemm_tn -- all issued as ONE grouped launch when every
-    N and K is a multiple of 256 (pvrl_gemm_tn_grouped_bf16), otherwise one gemm_tn per problem."""
+    """problems: list of (P, Q, dW, dbias | None, beta[, gscale | None, nonfinite | None]), each as gemm_tn -- all issued as ONE
+    grouped launch when every N and K is a multiple of 256 (pvrl_gemm_tn_grouped_bf16), otherwise one gemm_tn per problem."""
     from ._lib import TnProblem
     L = lib()
     if not problems:
         return
+    problems = [tuple(pr) + (None,) * (7 - len(pr)) for pr in problems]
     ok = 1 < len(problems) <= TN_GROUP_MAX and all(
-        P.shape[1] % 256 == 0 and Q.shape[1] % 256 == 0 and P.shape[0] >= 1 for P, Q, _, _, _ in problems)
+        pr[0].shape[1] % 256 == 0 and pr[1].shape[1] % 256 == 0 and pr[0].shape[0] >= 1 for pr in problems)
     if not ok:
-        for i in range(0, len(problems), 1):
-            P, Q, dW, dbias, beta = problems[i]
-            gemm_tn(P, Q, dW, dbias, beta=beta, ws_tag=ws_tag)
+        for P, Q, dW, dbias, beta, gsc, nf in problems:
+            gemm_tn(P, Q, dW, dbias, beta=beta, ws_tag=ws_tag, gscale=gsc, nonfinite=nf)
         return
     arr = (TnProblem * len(problems))()
     flops = 0.0
-    for a, (P, Q, dW, dbias, beta) in zip(arr, problems):
+    for a, (P, Q, dW, dbias, beta, gsc, nf) in zip(arr, problems):
         _chk2d(P, OP16); _chk2d(Q, OP16)
         M, N = P.shape
         K = Q.shape[1]
@@ -220,6 +221,7 @@ def gemm_tn_grouped(problems, ws_tag="tn_group"):
         assert dbias is None or (dbias.dtype == F32 and dbias.is_contiguous() and dbias.numel() == N)
         a.P, a.ldp, a.Q, a.ldq, a.M, a.N, a.K = P.data_ptr(), _ld(P), Q.data_ptr(), _ld(Q), M, N, K
         a.beta, a.dW, a.dbias = float(beta), dW.data_ptr(), (None if dbias is None else dbias.data_ptr())
+        a.gscale, a.nonfinite = (None if gsc is None else gsc.data_ptr()), (None if nf is None else nf.data_ptr())
         flops += 2.0 * M * N * K
     ap = ctypes.addressof(arr)
     splits = L.call("pvrl_gemm_tn_grouped_plan_splits", len(problems), ap)
@@ -246,7 +248,7 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0, dxs=None, dxs_scale=None,
-                  dxsum=None, dxsum_beta=None):
+                  dxsum=None, dxsum_beta=None, gscale=None, nonfinite=None):
     """`dxs` (optional bf16 [rows <= M, C]) additionally receives bf16(dxs_scale[m] * dx_out[m]); `dxsum` (optional fp32
     [C]) the unscaled column sums of those rows of dx_out (dxsum = dxsum_beta * dxsum + sums)."""
     L = lib()
@@ -265,7 +267,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
            _ptr(rstd), _ptr(gamma), _ptr(dx_in), _ld(dx_in) if dx_in is not None else 0, _ptr(dx_out), _ld(dx_out),
            float(beta_acc), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _ptr(dxs),
            _ld(dxs) if dxs is not None else 0, _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _ptr(tgt),
-           _stream())
+           _ptr(gscale), _ptr(nonfinite), _stream())
     if tgt is not dxsum:
         if beta_acc != 0.0:
             raise PvrlError("layernorm_bwd: dxsum_beta = 0 with beta_acc != 0 is not supported")
@@ -438,8 +440,8 @@ def cast_weight(w, out=None, out_t=None, need_t=True):
     return out, (out_t if need_t else None)
 
 
-def gemv_rows(W, x, out=None, beta=0.0):
-    """out[r] = beta * out[r] + W[r, :] . x  (W fp32 or bf16 [R, C] row-major, x fp32 [C]) -> fp32 [R]"""
+def gemv_rows(W, x, out=None, beta=0.0, gscale=None):
+    """out[r] = beta * out[r] + gscale * W[r, :] . x  (W fp32 or bf16 [R, C] row-major, x fp32 [C]) -> fp32 [R]"""
     _chk2d(W)
     R, C = W.shape
     assert x.dtype == F32 and x.is_contiguous() and x.numel() == C
@@ -447,7 +449,7 @@ def gemv_rows(W, x, out=None, beta=0.0):
         out = torch.empty(R, device=W.device, dtype=F32)
     assert out.dtype == F32 and out.is_contiguous() and out.numel() == R
     lib().call("pvrl_gemv_rows_f32", _ptr(W), 1 if W.dtype == OP16 else 0, _ld(W), R, C, _ptr(x), float(beta), _ptr(out),
-               _stream())
+               _ptr(gscale), _stream())
     return out
 
 
@@ -547,12 +549,13 @@ def milnce(x, n, C, grad_scale=None):
     return nom, den, dx
 
 
-def rank1_add(out, a, b):
-    """out[r][c] += a[r] * b[c]  (fp32 [R, C] row-major, in place)"""
+def rank1_add(out, a, b, gscale=None):
+    """out[r][c] += gscale * a[r] * b[c]  (fp32 [R, C] row-major, in place)"""
     L = lib()
     _chk2d(out, F32)
     assert a.dtype == F32 and b.dtype == F32 and a.numel() == out.shape[0] and b.numel() == out.shape[1]
-    L.call("pvrl_rank1_add_f32", _ptr(out), _ld(out), _ptr(a.contiguous()), _ptr(b.contiguous()), out.shape[0], out.shape[1], _stream())
+    L.call("pvrl_rank1_add_f32", _ptr(out), _ld(out), _ptr(a.contiguous()), _ptr(b.contiguous()), out.shape[0], out.shape[1], _ptr(gscale),
+           _stream())
     return out
 
 

@@ -36,13 +36,31 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.steps = 0             # optimiser steps taken (informational; the arithmetic uses the per-parameter counts)
         self.param_steps = None    # per parameter of the flat store: updates applied so far (torch.optim's state["step"];
         self.grad_scale = 1.0      # a parameter without a gradient is skipped and its count does not advance)
-        # Device-side `misc.check_nan_losses` (tools/train_net.py:174 raises in front of optimizer.step()): `skip_flag` is a device
-        # scalar the training loop sets to "this iteration's loss is not finite"; the update kernels leave weights and state
-        # untouched when it is non-zero, and the loop raises at its next log point -- the bad step is never applied, no
-        # host sync per iteration.  `check_grads` adds one pass over the flat gradient buffer (inf / nan in any gradient also
-        # raises the flag): default for the fp16-operand flavour, whose scaled backward can overflow where the loss cannot.
-        self.skip_flag = None
+        # Device-side `misc.check_nan_losses` (tools/train_net.py:174 raises in front of optimizer.step()).  The "skip this step" flag
+        # is a slot of the model's flat gradient buffer (GradStore.bad): RAISED on the device by `note_loss()` (a loss of this
+        # iteration is not finite) and by the kernels that write parameter gradients (inf / nan in a value they write, include/pvrl.h
+        # `nonfinite`); summed over ranks with the tail of the gradient all-reduce, so every replica drops the same step; READ by
+        # the update kernels, which leave weights and state untouched when it is set; and CLEARED by step() itself once the update
+        # kernels are queued (pvrl_flag_roll also counts the dropped step in `bad_steps`) -- its life cycle belongs to the step,
+        # whatever loop calls it.  No host sync per iteration: a training loop reads `dropped_steps()` where it reads its statistics.
+        # `check_grads` (default for the fp16-operand flavour, whose scaled backward can overflow where the loss cannot) additionally
+        # scans the gradients of parameters whose producers do not check themselves (GradStore.fused_checked lists the others).
         self.check_grads = os.environ.get("PVRL_CHECK_GRADS", "1" if OPERAND == "f16" else "0") == "1"
+        self.bad_steps = None      # device counter of dropped steps
+
+    @property
+    def skip_flag(self):
+        """the device flag (1-element view of the flat gradient buffer); non-zero = the next step() is dropped"""
+        return self.vt.grad_store().bad
+
+    def note_loss(self, loss):
+        """raise the skip flag when `loss` (device scalar) is not finite -- misc.check_nan_losses without a host sync"""
+        bad = self.skip_flag
+        bad.copy_(torch.maximum(bad, (~loss.detach().isfinite()).to(bad.dtype).reshape(1)))
+
+    def dropped_steps(self):
+        """number of optimiser steps dropped so far because of a non-finite loss / gradient (host sync)"""
+        return 0 if self.bad_steps is None else int(self.bad_steps.item())
 
     # -- flat storage -----------------------------------------------------------------------
     def _ensure_flat(self):
@@ -68,10 +86,10 @@ class FusedOptimizer(torch.optim.Optimizer):
             self.param_steps = [0] * len(gs.params)
         return self.param_steps
 
-    def _runs(self, gs, params, had_grad):
+    def _runs(self, gs, params, had_grad, by_step=True):
         """-> [[a, b, step]]: maximal contiguous ranges of the flat buffers whose parameters all have a gradient and have
         all been updated `step` times before (one kernel launch each; normally ONE range per parameter group)"""
-        ps = self._steps(gs)
+        ps = self._steps(gs) if by_step else [0] * len(gs.params)
         idx = sorted(gs.index[id(p)] for p in params if id(p) in gs.index and had_grad[gs.index[id(p)]])
         runs = []
         for i in idx:
@@ -96,13 +114,13 @@ class FusedOptimizer(torch.optim.Optimizer):
         base_2 = self.buf2.data_ptr() if self.buf2 is not None else 0
         vp = ctypes.c_void_p
         ps = self._steps(gs)
-        skip = None
-        if self.check_grads:
-            if self.skip_flag is None:
-                self.skip_flag = torch.zeros((), device=gs.flat.device)
-            L.call("pvrl_nonfinite_flag_f32", vp(base_g), gs.end, vp(self.skip_flag.data_ptr()), stream)
-        if self.skip_flag is not None:
-            skip = vp(self.skip_flag.data_ptr())
+        if self.bad_steps is None or self.bad_steps.device != gs.flat.device:
+            self.bad_steps = torch.zeros(1, device=gs.flat.device)
+        skip = vp(gs.bad.data_ptr())
+        if self.check_grads:       # gradients written by kernels that do not raise the flag themselves (head, glue, MViT engine)
+            rest = [p for i, p in enumerate(gs.params) if i not in gs.fused_checked]
+            for a, b, _ in self._runs(gs, rest, had_grad, by_step=False):
+                L.call("pvrl_nonfinite_flag_f32", vp(base_g + 4 * a), b - a, skip, stream)
         for g in self.param_groups:
             for a, b, done in self._runs(gs, g["params"], had_grad):
                 n, o = b - a, 4 * a
@@ -119,6 +137,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 i = gs.index.get(id(p))
                 if i is not None and had_grad[i]:
                     ps[i] += 1
+        L.call("pvrl_flag_roll", skip, vp(self.bad_steps.data_ptr()), stream)      # count a dropped step, re-arm the flag
         self._bump(gs)
         return None
 

@@ -26,10 +26,14 @@ class StackEngine:
     """Runs a list of residual attention blocks (objects with ln_1, attn.in_proj_weight/bias,
     attn.out_proj, ln_2, mlp.c_fc, mlp.c_proj).  Shares the weight-copy cache of `enc` (EncoderEngine)."""
 
-    def __init__(self, resblocks, weight_cache, grad_target=None, heads=8):
+    def __init__(self, resblocks, weight_cache, grad_target=None, heads=8, grad_store=None):
+        """`grad_store` (optional callable -> engine.GradStore): parameter gradients are then written in "fused" form -- the kernels
+        take the fp16 flavour's backward scale out themselves and raise the optimiser's skip flag on a non-finite value
+        (GradStore.target(..., fused=True)); without it `grad_target(p)` -> (tensor, beta) as before."""
         self.blocks = list(resblocks)
         self._weight = weight_cache
         self._target = grad_target
+        self._gs = grad_store
         self.H = heads
 
     def forward(self, x, nseq, S, causal=False, kpm=None, save=True):
@@ -62,15 +66,18 @@ class StackEngine:
         scale = (Wd // self.H) ** -0.5
         P = lambda t: t.detach()
         dx = dy.contiguous().clone()
-        tgt = self._target
+        gs = self._gs() if self._gs is not None else None
+        tgt = self._target if gs is None else (lambda p: gs.target(p, fused=True))
+        gsc, bad = (gs.inv, gs.bad) if gs is not None else (None, None)
 
         def wgrad(d, xin, w, b):
             (dw, bw), (db, _) = tgt(w), tgt(b)
-            ops.gemm_tn(d, xin, dw, db, beta=bw)
+            ops.gemm_tn(d, xin, dw, db, beta=bw, gscale=gsc, nonfinite=bad)
 
         def lnbwd(dh, x, st, ln):
             (dg, bg), (db, _) = tgt(ln.weight), tgt(ln.bias)
-            ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx, dx_out=dx, beta_acc=bg)
+            ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx, dx_out=dx, beta_acc=bg, gscale=gsc,
+                              nonfinite=bad)
 
         for blk, s in zip(reversed(self.blocks), reversed(saved["blocks"])):
             d2 = ops.cast_scale(dx, None)

@@ -92,6 +92,12 @@ def log_json_stats(stats):
 def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_iters=None):
     model.train()
     vt = model.model
+    if cfg.TRAIN.LINEAR:                                       # train_net.py:72-85: the frozen encoder runs in eval mode (DropPath off)
+        if hasattr(vt, "pos_drop"):
+            vt.pos_drop.eval()
+            vt.blocks.eval()
+        elif hasattr(vt, "video_encoder"):                     # MViTv2
+            vt.video_encoder.eval()
     if hasattr(vt, "text_model"):
         vt.text_model.eval()                                   # train_net.py:89-95: no gradients on the text model
     data_size = len(train_loader)
@@ -102,7 +108,7 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
     optimizer.grad_scale = 1.0 / (world * (num_iters if accumulate else 1))
     dev = next(model.parameters()).device
     window = []
-    skipped = []
+    dropped_before = float(optimizer.dropped_steps()) if hasattr(optimizer, "dropped_steps") else 0.0
     last_line = None
     pretrain = is_pretraining(cfg)
     t_last = time.perf_counter()
@@ -127,19 +133,16 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
             optimizer.zero_grad(set_to_none=True)
         last_micro = not accumulate or (cur_iter + 1) % num_iters == 0
         # misc.check_nan_losses(loss) (train_net.py:174) raises BEFORE the step of a bad iteration.  Here the test stays on the
-        # device: the optimiser's skip flag = "a loss of this (accumulated) iteration is not finite" (+ any non-finite gradient when
-        # optimizer.check_grads), its update kernels do nothing when it is set, and the host raises at the next log point.
-        bad = (~loss.detach().isfinite()).float().reshape(())
-        if hasattr(optimizer, "skip_flag"):
-            if optimizer.skip_flag is None or optimizer.skip_flag.device != bad.device:
-                optimizer.skip_flag = torch.zeros((), device=bad.device)
-            optimizer.skip_flag.copy_(bad if first_micro else torch.maximum(optimizer.skip_flag, bad))
+        # device: a non-finite loss raises the optimiser's skip flag (as does a non-finite gradient, where it is written), the flag
+        # is summed over ranks with the gradients, the update kernels do nothing when it is set, and the host raises at the next
+        # log point, where it reads its statistics anyway.
+        if hasattr(optimizer, "note_loss"):
+            optimizer.note_loss(loss)
         reducer.sync = last_micro          # DDP no_sync() on the other micro-iterations: accumulate locally, reduce once
         loss.backward()
         if last_micro:
             reducer.finish()
             optimizer.step()
-        skipped.append(optimizer.skip_flag.clone() if getattr(optimizer, "skip_flag", None) is not None else bad)
         with torch.no_grad():
             if task_losses is not None:                        # EPIC-Kitchens (train_net.py:195-222): verb / noun / action accuracies
                 v1, v5 = topk_accuracies(pred[0], labels["verb"], (1, 5))
@@ -159,8 +162,9 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
         if (cur_iter + 1) % cfg.LOG_PERIOD == 0 or cur_iter + 1 == data_size:
             w = torch.stack(window)
             # one host sync per LOG_PERIOD: the medians, "every loss of the window is finite", "no step of the window was skipped"
+            drops = optimizer.bad_steps if getattr(optimizer, "bad_steps", None) is not None else torch.zeros(1, device=w.device)
             vals = torch.cat([w.median(0).values, w[:, 0].isfinite().all().float().view(1),
-                              torch.stack(skipped).max().view(1).to(w.device)]).tolist()
+                              (drops.to(w.device) - dropped_before).view(1)]).tolist()
             finite, dropped = vals[-2], vals[-1]
             vals = vals[:-2]
             if finite == 0.0 or dropped != 0.0 or any(math.isnan(v) or math.isinf(v) for v in vals):
@@ -179,7 +183,6 @@ def train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_ite
             log_json_stats(line)
             last_line = line
             window = []
-            skipped = []
     return last_line
 
 

@@ -99,6 +99,10 @@ class VisionTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         self.time_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        # vit.py:209,214: identity at p = 0 (asserted above); kept as attributes because the linear-probing loop reaches for them
+        # (`model.model.pos_drop.eval()`, tools/train_net.py:72-85)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.time_drop = nn.Dropout(p=drop_rate)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # vit.py:220
         self.drop_path_rates = dpr
         self.blocks = nn.ModuleList([
@@ -284,8 +288,29 @@ class VisionTransformer(nn.Module):
         teacher_x = torch.cat((teacher_x.index_select(0, rand_inds), intermediate_teacher_x), dim=0)
         return x, teacher_x, mse
 
-    def _pretrain_forward(self, feat, text, rng, batch_size):
-        teacher_x = self.get_pseudo_labels(feat.device, text)                 # frozen text tower: its own HIP graph
+    _text_side = None      # HIP stream of the frozen text tower
+
+    def _teacher_begin(self, text, dev):
+        """The frozen CLIP-text teacher (vit.py:425-433) depends on the narrations only, not on the encoder: its ~110 small launches
+        (one HIP-graph replay) are issued on a side stream BEFORE the encoder forward and run under it; the main stream joins
+        where the teacher logits are consumed (`_teacher_end`).  Serially they sat between the encoder and the head on one queue
+        (~1 ms per step with the GPU nearly idle).  PVRL_TEXT_OVERLAP=0: A/B runs."""
+        if dev.type != "cuda" or os.environ.get("PVRL_TEXT_OVERLAP", "1") != "1":
+            return None
+        if self._text_side is None or self._text_side.device != dev:
+            self._text_side = torch.cuda.Stream(device=dev)
+        side = self._text_side
+        side.wait_stream(torch.cuda.current_stream())       # the ids are ready -- and everything that read last step's teacher logits
+        with torch.cuda.stream(side):                        # is done before their memory (this stream's pool) is written again
+            teacher_x = self.get_pseudo_labels(dev, text)
+        return teacher_x, side.record_event()
+
+    def _pretrain_forward(self, feat, text, rng, batch_size, teacher=None):
+        if teacher is not None:
+            teacher_x, ev = teacher
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            teacher_x = self.get_pseudo_labels(feat.device, text)            # frozen text tower: its own HIP graph
         if os.environ.get("PVRL_HEAD_ENGINE", "1") != "1":
             return self._pretrain_head(feat, teacher_x, rng, batch_size)     # the same head wired through torch.autograd (eager)
         # One autograd node with a hand-written backward (head_engine.PretrainHeadEngine): its ~1,000 small launches are
@@ -310,13 +335,15 @@ class VisionTransformer(nn.Module):
             b, c, mt, h, w = x.shape
             t = mt // self.num_seg
             x = x.view(b, c, self.num_seg, t, h, w).permute(0, 2, 1, 3, 4, 5).reshape(b * self.num_seg, c, t, h, w)
+        pretrain = isinstance(self.label_emb, torch.Tensor) and len(self.text) > 0 and self.training
+        if pretrain and (not self.cfg.DEV.MATCH_LANG_EMB or (hasattr(self, "num_seg") and self.num_seg > 0)):
+            raise NotImplementedError("pre-training forward (vit.py:325-352) is built for DEV.MATCH_LANG_EMB True and "
+                                      "MODEL.NUM_SEG 0, the setting of every shipped pre-training config")
+        teacher = self._teacher_begin(text, x.device) if pretrain and isinstance(x, torch.Tensor) else None
         x = feat = self.forward_features(x.contiguous(), droppath=(rng or {}).get("droppath"))
         dev = x.device
-        if isinstance(self.label_emb, torch.Tensor) and len(self.text) > 0 and self.training:
-            if not self.cfg.DEV.MATCH_LANG_EMB or (hasattr(self, "num_seg") and self.num_seg > 0):
-                raise NotImplementedError("pre-training forward (vit.py:325-352) is built for DEV.MATCH_LANG_EMB True and "
-                                          "MODEL.NUM_SEG 0, the setting of every shipped pre-training config")
-            return self._pretrain_forward(feat, text, rng, batch_size)
+        if pretrain:
+            return self._pretrain_forward(feat, text, rng, batch_size, teacher)
 
         if self.cfg.DEV.MATCH_LANG_EMB:
             le, le_t = self._labels(dev)

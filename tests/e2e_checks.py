@@ -14,15 +14,19 @@ from oracle import rounded_oracle as rorc
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 from procedurevrl_amd._lib import OPERAND
 
-# Tolerances per library flavour (relative L2 unless stated), set to ~1.5x the largest value observed on MI355X so that a
-# regression that doubles an error fails.  north star: step logits and loss values within 1e-3 -- that is the fp16-operand
-# flavour's bar (PVRL_OPERAND=f16, tests/test_f16_flavour_gpu.py); the bf16 flavour's error is operand rounding (8x larger
-# unit roundoff), demonstrated by the oracle with the datapath's rounding points (oracle/rounded_oracle.py).
+# Tolerances per library flavour (relative L2 unless stated).  north star: step logits and loss values within 1e-3 of the fp32
+# reference -- that is the DEFAULT (fp16-operand) flavour's bar, asserted here as TOL_ACT = TOL_LOSS = 1e-3 on every end-to-end
+# check; the full-size checks additionally hold the logits to TOL_LOGITS_FULL (observed 2.9e-4 since the cls rows' chain runs in
+# fp32, csrc/cls_chain.hip).  The bf16 flavour (PVRL_OPERAND=bf16, tests/test_bf16_flavour_gpu.py) has an 8x larger unit
+# roundoff; that its error is operand rounding and nothing else is shown by the oracle with the datapath's rounding points
+# (oracle/rounded_oracle.py).  Gradient tolerances: ~1.5x the largest value observed on MI355X.
 if OPERAND == "bf16":
     TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-2, 2e-2, 2.5e-3       # observed maxima (32-clip timed config): 6.4e-3, 1.26e-2, 1.45e-3
+    TOL_LOGITS_FULL = 4e-3                                 # 12 blocks, cls chain in fp32: observed 2.1e-3
     OPERAND_DTYPE = torch.bfloat16
 else:
     TOL_ACT, TOL_GRAD, TOL_LOSS = 1e-3, 2.5e-3, 1e-3       # observed maxima: 7.9e-4, 1.34e-3, 2.7e-4
+    TOL_LOGITS_FULL = 5e-4                                 # 12 blocks, cls chain in fp32: observed 2.9e-4
     OPERAND_DTYPE = torch.float16
 TOL_GSUM = 2 * TOL_GRAD      # worst relative error of a parameter's sum |grad| over ALL parameters
 TOL_RATIO = 1.3              # HIP logits error / error of the oracle with the datapath's rounding points (observed 0.93-1.08)
@@ -214,9 +218,11 @@ def check_pretrain_head_engine():
         e = rel(eager["grads"][k], g) if k in eager["grads"] else float("inf")
         if e > worst:
             worst, wk = e, k
-    # same kernels on the same operands; only fp32 summation orders of the small glue differ (16-bit operand rounding of the
-    # stack's backward GEMMs can flip on a last-bit difference, hence not 1e-6)
-    out.append((f"head engine vs autograd head: all gradients (worst: {wk})", worst, 2e-3 if OPERAND == "bf16" else 3e-4))
+    # same kernels; the engine back-propagates the four denoise levels as ONE stack pass (round 5) where the autograd-wired head runs
+    # four: fp32 summation orders differ and, in the fp16 flavour, the pass has one gradient scale S instead of one per level, so
+    # the 16-bit operands of the stack's backward GEMMs round differently (observed 6.6e-4 fp16; both sit inside TOL_GRAD of the
+    # reference's golden gradients, checked below)
+    out.append((f"head engine vs autograd head: all gradients (worst: {wk})", worst, 2e-3 if OPERAND == "bf16" else 1.2e-3))
     _e2e_step(model, cfg, f)                              # warm-up call 2
     rep = [_e2e_step(model, cfg, f) for _ in range(3)]    # capture + replay, replay, replay
     he = vt.head_engine
@@ -374,13 +380,15 @@ def check_timed_config_train_step():
     """The benchmark's OWN configuration -- 32 clips of 8x224^2, 12 blocks, K = 9871 (BASELINE configs[1]) -- one training
     step (forward, step logits, top-5 KL loss, backward) against the oracle run in micro-batches on the host cores:
     every kernel launch of the timed step at its timed shape (M = 50,208 rows, grouped weight gradients, 256x256 tiles)."""
-    return _hip_vs_oracle(12, 224, 9871, 32, seed=17, tag="32 clips (timed config): ", rounding_model=False, micro=4)
+    res = _hip_vs_oracle(12, 224, 9871, 32, seed=17, tag="32 clips (timed config): ", rounding_model=False, micro=4)
+    return [(l, e, TOL_LOGITS_FULL if "logits vs oracle" in l else t) for l, e, t in res]
 
 
 def check_bench_config_two_clips():
     """bench.py --parity-probe: the benchmark's model (12 blocks, 8 x 224^2, K = 9871) on 2 clips, one training step vs the
     oracle -- cheap enough (a few seconds of CPU) to ride along with a timed run of either library flavour"""
-    return _hip_vs_oracle(12, 224, 9871, 2, seed=19, tag="2 clips (bench model): ", rounding_model=False)
+    res = _hip_vs_oracle(12, 224, 9871, 2, seed=19, tag="2 clips (bench model): ", rounding_model=False)
+    return [(l, e, TOL_LOGITS_FULL if "logits vs oracle" in l else t) for l, e, t in res]
 
 
 def check_text_tower_full_size():
@@ -618,4 +626,4 @@ def check_hip_graph_replay():
 
 ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
               check_train_step_t4, check_train_step_t32, check_train_step_crop256, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
-              check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step]
+              check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step, check_bench_config_two_clips]

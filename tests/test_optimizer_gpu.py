@@ -175,22 +175,42 @@ def test_non_finite_step_is_dropped_on_the_device(method):
     before = snap()
     fill()
     gs.views[5].view(-1)[3] = float("inf")
-    opt.skip_flag = torch.zeros((), device=gs.flat.device)
     opt.step()
     after = snap()
-    assert float(opt.skip_flag) == 1.0
+    assert opt.dropped_steps() == 1
+    assert float(opt.skip_flag) == 0.0, "step() re-arms the flag it consumed"
     assert all(b is None or torch.equal(a, b) for a, b in zip(after, before)), "a step with an inf gradient changed weights or state"
-    # (b) the loop's loss flag alone
+    # (b) the loop's loss flag alone (optimizer.note_loss), gradients finite
     opt.check_grads = False
     fill()
-    opt.skip_flag.fill_(1.0)
+    opt.note_loss(torch.tensor(float("nan"), device=gs.flat.device))
+    assert float(opt.skip_flag) == 1.0
+    opt.note_loss(torch.tensor(1.0, device=gs.flat.device))      # a finite loss of a later micro-iteration does not lower it
+    assert float(opt.skip_flag) == 1.0
     opt.step()
     assert all(b is None or torch.equal(a, b) for a, b in zip(snap(), before))
-    # (c) clean again: the step is applied
-    opt.skip_flag.zero_()
+    assert opt.dropped_steps() == 2
+    # (c) the NEXT step of a loop that never touches the flag is applied (the flag's life cycle belongs to step())
     fill()
     opt.step()
     assert not torch.equal(snap()[0], before[0])
+    assert opt.dropped_steps() == 2
+    # (d) a kernel that writes a parameter gradient raises the flag itself: the weight-gradient reduce (and takes a scale out)
+    from procedurevrl_amd import ops
+    P = torch.randn(512, 256, device=gs.flat.device).to(ops.OP16)
+    Q = torch.randn(512, 256, device=gs.flat.device).to(ops.OP16)
+    dW = torch.zeros(256, 256, device=gs.flat.device)
+    db = torch.zeros(256, device=gs.flat.device)
+    flag = torch.zeros(1, device=gs.flat.device)
+    half = torch.full((1,), 0.5, device=gs.flat.device)
+    ops.gemm_tn(P, Q, dW, db, gscale=half, nonfinite=flag)
+    ref = 0.5 * (P.float().t() @ Q.float())
+    assert float((dW - ref).norm() / ref.norm()) < 1e-5 and float(flag) == 0.0
+    ops.gemm_tn(P, Q, dW, db, beta=1.0, gscale=half, nonfinite=flag)              # what is there (beta) is not scaled again
+    assert float((dW - 2 * ref).norm() / ref.norm()) < 1e-5
+    P[7, 3] = float("inf")
+    ops.gemm_tn(P, Q, dW, db, gscale=half, nonfinite=flag)
+    assert float(flag) == 1.0
     # nan counts as well; finite values never raise the flag
     from procedurevrl_amd._lib import lib
     import ctypes

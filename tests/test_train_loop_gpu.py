@@ -228,3 +228,55 @@ def test_non_finite_loss_never_reaches_the_weights_and_raises_at_the_log_point(t
     now = snaps["model"].state_dict()
     for k, v in snaps["w"].items():
         assert torch.equal(now[k], v), f"{k} was changed by an iteration whose loss was not finite"
+
+
+@pytest.mark.gpu
+def test_linear_probing_runs_the_encoder_in_eval_mode(tmp_path):
+    """tools/train_net.py:72-85 (`TRAIN.LINEAR`, set by three of the four shipped COIN fine-tune configs): the wrapper trains, but
+    `pos_drop` and `blocks` are put in eval mode -- DropPath off in the frozen encoder -- and only head / order parameters are
+    optimised (lib/models/optimizer.py:21-34).  A LINEAR training step's features equal the eval-mode features (with DropPath 0.3
+    they would not), no encoder parameter receives a gradient or moves, the classification head does."""
+    from procedurevrl_amd import train_net as tn
+    from procedurevrl_amd.build import build_model
+    from procedurevrl_amd.datasets import construct_loader
+    from procedurevrl_amd.distributed import GradReducer
+    from procedurevrl_amd.optimizer import construct_optimizer
+    cfg = _finetune_cfg(tmp_path, "kinetics")
+    cfg.TRAIN.LINEAR = True
+    cfg.MODEL.DROP_PATH = 0.3
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    vt = model.model
+    with torch.no_grad():                                        # (the reference zero-initialises temporal_fc: wake that branch up)
+        for blk in vt.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    opt = construct_optimizer(model, cfg)
+    assert not any(p.requires_grad for n, p in model.named_parameters() if "head" not in n and "order" not in n)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    feats = []
+    real = vt.forward_features
+
+    def spy(x, *a, **k):
+        f = real(x, *a, **k)
+        feats.append((x.detach().clone(), f.detach().clone(), vt.training, vt.blocks.training))
+        return f
+
+    vt.forward_features = spy
+    try:
+        loader = construct_loader(cfg, "train")
+        tn.train_epoch(loader, model, opt, GradReducer(vt, enabled=False), 0, cfg, max_iters=2)
+    finally:
+        vt.forward_features = real
+    assert len(feats) == 2 and all(t and not bt for _, _, t, bt in feats), "wrapper in train mode, blocks in eval mode"
+    model.eval()
+    with torch.no_grad():
+        for x, f, _, _ in feats:
+            assert torch.equal(real(x), f), "a LINEAR step's features are the eval-mode features (DropPath off)"
+    model.train()                                                # for contrast: with the blocks in train mode DropPath 0.3 changes them
+    with torch.no_grad():
+        assert not torch.equal(real(feats[0][0]), feats[0][1])
+    for n, p in model.named_parameters():
+        moved = not torch.equal(p.detach(), before[n])
+        if "head" not in n and "order" not in n:
+            assert p.grad is None and not moved, n
+    assert not torch.equal(vt.head_cls.weight.detach(), before["model.head_cls.weight"])
