@@ -65,6 +65,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from procedurevrl_amd.distributed import reserve_comm_cus
+        comm_cus = reserve_comm_cus(world)          # CUs per XCD left to RCCL (before the first launch / init_process_group)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -279,6 +281,8 @@ def main():
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "comm": None if world == 1 else {"backend": backend, "ranks": dist.get_world_size(),
                                              "rccl": rccl_version(torch) if backend == "nccl" else None,
+                                             "cus_per_xcd_left_to_rccl": comm_cus, "compute_cus_per_xcd": os.environ.get("PVRL_COMPUTE_CUS"),
+                                             "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                              "grad_allreduce_mb": round(vt.grad_store().flat.numel() * 4 / 2 ** 20, 1)},
             "loss": float(loss.item()), "hip_graphs": bool(graphs), "hbm_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3), "sustained": sustained, "value_note": value_note,

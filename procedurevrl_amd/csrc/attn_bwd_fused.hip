@@ -515,14 +515,9 @@ bool pvrl_attn_bwd_fused_ok(const AttnArgs& p) {
 }
 
 int pvrl_attn_bwd_fused_launch(const AttnArgs& p, hipStream_t s) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  const int cus = 8 * pvrl_compute_cus_per_xcd();       // one persistent workgroup per CU (common.h: PVRL_COMPUTE_CUS leaves some free)
   const int nvb = 8 * ((p.nseq + 7) / 8) * p.H;
-  const int grid = nvb < cus ? nvb : cus - (cus & 7);      // a multiple of 8: a workgroup's items stay on its XCD
+  const int grid = nvb < cus ? nvb : cus;                   // a multiple of 8: a workgroup's items stay on its XCD
   if (p.mp.S > 192) hipLaunchKernelGGL(attn_bwd_fused_kernel<7>, dim3(grid), dim3(512), 0, s, p, nvb);      // 7 query blocks, loops unrolled
   else hipLaunchKernelGGL(attn_bwd_fused_kernel<0>, dim3(grid), dim3(512), 0, s, p, nvb);
   PVRL_LAUNCH_CHECK();

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 // The 16-bit OPERAND TYPE of the datapath (GEMM / attention operands and the activations stored between kernels; everything
 // else -- accumulators, residual stream, statistics, losses, parameter gradients -- is fp32).  Fixed at build time:
@@ -204,3 +205,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// CUs per XCD that the PERSISTENT / one-round kernels of this library size their grids for (gemm_nt8, gemm_tn8 and its grouped
+// launch, attn_bwd_fused: one 512-thread workgroup owns a whole CU -- 256 VGPRs per lane, 128 KB of LDS).  Default: all of them
+// (MI355X: 256 CUs / 8 XCDs = 32).  PVRL_COMPUTE_CUS=<n> (read once per process, like the PVRL_NT* A/B switches: the one piece
+// of process-wide launch configuration in the library) leaves 32 - n CUs per XCD to kernels of OTHER streams: in a data-parallel job
+// RCCL's channel kernels take CUs at a kernel seam and then hold them for the length of a collective; a persistent grid sized for
+// CUs it cannot get pays a second wave of workgroups -- up to 2x on that launch (distributed.reserve_comm_cus sets both this and
+// RCCL's channel count before the first launch; measured cost of the reservation on one GPU: DESIGN.md section 6).
+static inline int pvrl_compute_cus_per_xcd() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    int c = n / 8;
+    const char* e = getenv("PVRL_COMPUTE_CUS");
+    if (e && atoi(e) > 0 && atoi(e) < c) c = atoi(e);
+    cus = c;
+  }
+  return cus;
+}

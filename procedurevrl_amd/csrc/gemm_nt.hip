@@ -118,11 +118,8 @@ static int f32_small_plan(int64_t M, int64_t N, int64_t K, int* kchunk_out) {
 int nt_cus_per_xcd() {
   static int cus = 0;
   if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    cus = n / 8;
-    const char* e = getenv("PVRL_NT_CUS");      // probe runs: fewer persistent workgroups per XCD
+    cus = pvrl_compute_cus_per_xcd();           // (common.h: all CUs of an XCD, or PVRL_COMPUTE_CUS of them)
+    const char* e = getenv("PVRL_NT_CUS");      // probe runs: fewer persistent workgroups per XCD for this kernel family only
     if (e && atoi(e) > 0 && atoi(e) < cus) cus = atoi(e);
   }
   return cus;

@@ -31,7 +31,7 @@ extern "C" int64_t pvrl_gemm_tn_plan_splits(int64_t M, int64_t N, int64_t K) {
   if (tn_use_rt(N, K)) {
     // one workgroup per CU and ONE round: as many (slice, tile) pairs as fit the 256 CUs, slices of >= 64 rows
     const int64_t tiles = cdiv(N, 256) * cdiv(K, 256);
-    int64_t s = 256 / tiles;
+    int64_t s = 8 * pvrl_compute_cus_per_xcd() / tiles;
     if (tiles == 1) s = 128;          // a single 256x256 tile: 128 slices measured ahead of 256 (200,736 x 256 x 256: 89 vs 109 us)
     const int64_t smax = M / 64;
     if (s > smax) s = smax;
@@ -156,12 +156,13 @@ extern "C" int64_t pvrl_gemm_tn_grouped_plan_splits(int nprob, const pvrl_tn_pro
   const int64_t T = tn_group_tiles(nprob, problems);
   int64_t smax = 32;
   for (int i = 0; i < nprob; ++i) smax = std::min<int64_t>(smax, std::max<int64_t>(1, problems[i].M / 64));
-  // the smallest slice count whose T*s equal work items fill whole rounds of the 256 CUs to >= 97 %, else the best one
+  // the smallest slice count whose T*s equal work items fill whole rounds of the (256) CUs to >= 97 %, else the best one
   int64_t best = 1;
   double best_eff = 0.0;
+  const int64_t ncu = 8 * pvrl_compute_cus_per_xcd();
   for (int64_t s = 1; s <= smax; ++s) {
     const int64_t items = T * s;
-    const double eff = (double)items / (double)(256 * cdiv(items, 256));
+    const double eff = (double)items / (double)(ncu * cdiv(items, ncu));
     if (eff >= 0.97) return s;
     if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
   }

@@ -86,6 +86,8 @@ def init_process_group(local_rank, local_world_size, shard_id, num_shards, init_
     """distributed.py:72-110"""
     proc_rank = local_rank + shard_id * local_world_size
     world_size = local_world_size * num_shards
+    if dist_backend == "nccl":
+        reserve_comm_cus(world_size)       # CUs for RCCL's channel kernels, before the first launch of this process
     dist.init_process_group(backend=dist_backend, init_method=init_method, world_size=world_size, rank=proc_rank)
     if dist_backend == "nccl":
         torch.cuda.set_device(local_rank)
@@ -122,6 +124,30 @@ def init_distributed_training(cfg):
         pg = dist.new_group(list(range(i * n, (i + 1) * n)))
         if i == cfg.SHARD_ID:
             _LOCAL_PROCESS_GROUP = pg
+
+
+def reserve_comm_cus(world, per_xcd=None):
+    """Optionally keep r CUs per XCD out of this library's persistent grids for RCCL (r = PVRL_COMM_CUS, default 0 = off), BEFORE
+    the first kernel launch and before `init_process_group` (both settings are read once per process):
+    PVRL_COMPUTE_CUS = 32 - r CUs per XCD for `gemm_nt8` / `gemm_tn8` / `attn_bwd_fused` (csrc/common.h: one 512-thread workgroup per
+    CU on a grid sized to the device) and NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = 8 r channel workgroups for RCCL.
+
+    Why it is OFF by default -- measured on one MI355X with a kernel that holds CUs on another stream through the whole backward the
+    way a collective's channel kernels do (tools/probe/comm_cus_ab.py, profiles/r5_comm_cus.txt): the reservation costs 0.6-0.7 ms
+    of a 50.4 ms step (r = 1) and buys nothing at ROCm's default of 4 hardware queues, where the step under a 34 ms CU-holding kernel
+    takes 79.0 ms with r = 0 and 80.1 ms with r = 1: what is exposed is not a second wave of workgroups but HARDWARE-QUEUE sharing
+    -- the foreign kernel shares one of the 4 HSA queues with streams of the step, and everything queued behind it waits for it.
+    (GPU_MAX_HW_QUEUES=8 un-shares the queues -- +6.9 ms under the held CUs instead of +28.6, and there r = 1 is worth 1.3 ms -- but the
+    step ALONE is 20 % slower, 60.2 vs 50.4 ms: its graph branches then truly co-run.)  So an all-reduce costs the step at most
+    its own kernel time (~3-5 ms per step for 0.94 GB per GPU at 8 ranks, if all of it lands on the critical queue).  Values already in the
+    environment win.  -> r"""
+    r = int(os.environ.get("PVRL_COMM_CUS", "0") if per_xcd is None else per_xcd)
+    if world <= 1 or r <= 0:
+        return 0
+    os.environ.setdefault("PVRL_COMPUTE_CUS", str(32 - r))
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(8 * r))
+    os.environ.setdefault("NCCL_MIN_NCHANNELS", str(8 * r))
+    return r
 
 
 class GradReducer:

@@ -129,3 +129,31 @@ def test_bench_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["comm"]["ranks"] == 2
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_the_drivers_command():
+    """The driver's 8-GPU launch -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` -- functionally on ONE GPU: eight processes share the device (PVRL_SINGLE_DEVICE) and reduce
+    over gloo.  Covers the 8-rank rendezvous, per-block gradient hooks between staged HIP-graph replays at world 8, the all-gather of the
+    InfoNCE embeddings, the max-over-ranks clock and the single JSON line; the reservation of CUs for RCCL is a no-op of the gloo
+    backend apart from its bookkeeping fields."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, PVRL_DIST_BACKEND="gloo", PVRL_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PVRL_COMM_CUS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PVRL_COMPUTE_CUS", "NCCL_MAX_NCHANNELS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--steps", "2",
+                        "--warmup", "1", "--classes", "512", "--no-cpu-baseline", "--no-kernel-timing"],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 16 and out["comm"]["ranks"] == 8
+    assert out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak" and out["value"] > 0
+    assert out["comm"]["compute_cus_per_xcd"] == "31" and out["comm"]["nccl_max_nchannels"] == "8"

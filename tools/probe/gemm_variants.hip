@@ -2262,7 +2262,7 @@ extern "C" int pvrl_probe_gemm_tn_bf16(int g_tn_tile, const void* P, int64_t ldp
   const long NK = N * K;
   const long nthreads = (NK >> 2) + (dbias ? N : 0);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, p.part, p.cpart,
-                     (int)splits, NK, (int)N, beta, dW, dbias);
+                     (int)splits, NK, (int)N, beta, dW, dbias, (const float*)nullptr, (float*)nullptr);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
 }
