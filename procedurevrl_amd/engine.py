@@ -352,7 +352,15 @@ class EncoderEngine(GraphReplay):
         self._grads = None
         self.saved = None
         self.grad_hook = None
-        self.overlap_wgrad = True     # weight-gradient GEMMs on a side stream, concurrent with the dgrad chain
+        # ONE STREAM since round 5.  Until round 4 the weight-gradient GEMMs ran on a side stream next to the dgrad chain and the
+        # fused temporal maps W_e were built on it at the start of the forward (PVRL_WGRAD_OVERLAP=1 / PVRL_PREFETCH_FUSED=1 bring
+        # both back).  Measured (profiles/r5_hw_queues.txt, two passes): single stream 636.5 clips/s, W_e prefetch only 632.3, both
+        # 622.7 -- and only the single-stream step is independent of how HIP maps streams to hardware queues: with the side
+        # stream it is 58 ms instead of 51 at GPU_MAX_HW_QUEUES=6 (the branches of its graph truly co-run), the capture segfaults
+        # inside ROCm 7 at 1-2 queues, and under a foreign stream's long kernel (RCCL) it stalls behind whatever shares its queue
+        # (tools/probe/comm_cus_ab.py).  Grouped weight-gradient launches fill the chip on their own; there is nothing to overlap.
+        self.overlap_wgrad = os.environ.get("PVRL_WGRAD_OVERLAP", "0") == "1"
+        self.prefetch_fused = os.environ.get("PVRL_PREFETCH_FUSED", "0") == "1"
         self._side = None
         self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
         # the B cls rows' projection + MLP in fp32 on the master weights (csrc/cls_chain.hip; PVRL_CLS_FP32=0: A/B runs)
@@ -450,8 +458,8 @@ class EncoderEngine(GraphReplay):
         path.  They are built for all blocks on the side stream at the start of the forward, under the patch embedding and
         the first block's LayerNorm / QKV / attention; each block waits for its own event."""
         self._fe_events = {}
-        side = self.side_stream(device)
-        if side is None or not device.type == "cuda":
+        side = self.side_stream(device, force=True) if self.prefetch_fused and device.type == "cuda" else None
+        if side is None:
             return
         stale = [blk for blk in self.m.blocks if self._fused_temporal_stale(blk)]
         if not stale:
@@ -499,12 +507,12 @@ class EncoderEngine(GraphReplay):
         return self.m.grad_store()
 
     # ------------------------------------------------------------------ side stream for weight gradients
-    def side_stream(self, device):
+    def side_stream(self, device, force=False):
         """Nothing in backward depends on a weight gradient until the optimiser step, while the data-gradient chain
-        (dgrad GEMM -> LayerNorm bwd -> attention bwd ...) is strictly serial.  Weight-gradient GEMMs are therefore
+        (dgrad GEMM -> LayerNorm bwd -> attention bwd ...) is strictly serial.  With `overlap_wgrad` the weight-gradient GEMMs are
         issued on a second HIP stream: they fill CUs left idle by the ragged last wave of the big-tile dgrad GEMMs
-        and overlap the HBM-bound LayerNorm / cast kernels."""
-        if not self.overlap_wgrad:
+        and overlap the HBM-bound LayerNorm / cast kernels.  (`force`: the stream itself, for the forward's W_e prefetch.)"""
+        if not self.overlap_wgrad and not force:
             return None
         if self._side is None or self._side.device != device:
             self._side = torch.cuda.Stream(device=device)
