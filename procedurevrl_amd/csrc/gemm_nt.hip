@@ -156,6 +156,16 @@ int nt8_enabled() {
   return on;
 }
 
+// rows from which the mid-sized shapes take 256 x 128 tiles instead of 128 x 128 (PVRL_NT_MID_M: A/B runs; read once)
+int nt_mid_m() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("PVRL_NT_MID_M");
+    m = e && atoi(e) > 0 ? atoi(e) : 2048;
+  }
+  return m;
+}
+
 // PVRL_NT_TILE=22|42|44|26|25 forces a tile shape where it is legal for the problem (shape sweeps: tools/probe/mvit_gemm_times.py); read once
 int nt_forced_tile() {
   static int t = -1;
@@ -190,7 +200,7 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
     if (p.N % 384 == 0 && p.M >= 100000) return launch_tile<EPI, 2, 6>(p, s);
     if (p.N % 320 == 0) return launch_tile<EPI, 2, 5>(p, s);
   }
-  if (p.M >= 2048 && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
+  if (p.M >= nt_mid_m() && (p.N % 256 == 0 || two_out)) return launch_tile<EPI, 4, 2>(p, s);
   return launch_tile<EPI, 2, 2>(p, s);
 }
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--videos", type=int, default=4)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=6)   # graphs are captured on the 3rd step; the next one is slow once
+    ap.add_argument("--host-profile", action="store_true", help="cProfile the host side of the timed steps (stderr)")
     args = ap.parse_args()
     import torch
     from procedurevrl_amd.build import build_model
@@ -74,11 +75,21 @@ def main():
         step()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     evs[0].record()
     for k in range(args.steps):
         loss = step()
         evs[k + 1].record()
+    t_enq = (time.perf_counter() - t0) / args.steps
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     per_step = [round(evs[k].elapsed_time(evs[k + 1]), 1) for k in range(args.steps)]
@@ -92,7 +103,7 @@ def main():
                                              f"{frames}x224^2, frozen CLIP-text teacher (12 layers, ctx 77) + order / diffusion "
                                              "transformer + top-5 KL + MSE, fwd+bwd+AdamW (SURVEY 8d's separate 36-clip run)",
                                  "clips_per_gpu": clips, "global_batch": clips, "parallelism": "dp1"},
-                      "per_step_ms": per_step, "loss": float(loss)}))
+                      "per_step_ms": per_step, "host_enqueue_ms_per_step": round(1e3 * t_enq, 3), "loss": float(loss)}))
 
 
 if __name__ == "__main__":

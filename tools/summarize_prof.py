@@ -13,8 +13,8 @@ def short(name):
         k = int(m.group(1))
         ident = m.group(2)[:k]
         rest = m.group(2)[k:]
-        t = re.match(r"ILi(\d+)E(DF16b|f)?", rest)
-        return ident + (f"<{t.group(1)},{'bf16' if t.group(2) == 'DF16b' else 'f32'}>" if t else "")
+        t = re.match(r"ILi(\d+)E(DF16b|DF16_|f)?", rest)
+        return ident + (f"<{t.group(1)},{ {'DF16b': 'bf16', 'DF16_': 'f16'}.get(t.group(2), 'f32') }>" if t else "")
     n = n.split("(")[0]
     n = re.sub(r"at::native::", "aten::", n)
     return n[:90]
