@@ -509,6 +509,7 @@ bool pvrl_attn_bwd_fused_ok(const AttnArgs& p) {
   if (p.causal || p.kpm) return false;
   if (p.mp.S <= 96 || p.mp.S > FB_ROWS) return false;      // at least four query blocks (the tail slots of an item are finished during its first two)
   if ((long)p.nseq * p.mp.S >= (1L << 31)) return false;      // row indices are formed in 32 bits
+  if ((p.ldd % 8) || (p.ldo % 8)) return false;               // dQ / dK / dV rows leave as 16-byte stores, Q / dO / O rows arrive by 16-byte LDS-DMA
   int e = 0;
   const float m = frexpf(p.scale, &e);
   return m == 0.5f;      // power of two

@@ -165,8 +165,8 @@ class GradReducer:
 
     `grad_coll` (env PVRL_GRAD_COLL = "allreduce" | "rsag"): the collective per chunk.  "rsag" = reduce-scatter + all-gather of
     the reduced shards, both in place: on a fully-connected xGMI node every rank exchanges 1/W of the chunk with each of its
-    W - 1 peers directly (all 7 links busy in both phases) instead of walking a ring (~0.9 vs ~6 ms for the 538 MB
-    of ViT-B at W = 8); chunks whose length W does not divide fall back to the all-reduce.
+    W - 1 peers directly (all 7 links busy in both phases) instead of walking a ring (SURVEY 5 / 8e ESTIMATE, never measured -- no multi-GPU node was available: ~0.9 vs ~6 ms for the 538 MB
+    of ViT-B at W = 8; keep the default "allreduce" until tests/test_rccl_multi_gpu.py[rsag] has run on real RCCL); chunks whose length W does not divide fall back to the all-reduce.
 
     `find_unused` (the reference builds DDP with find_unused_parameters=True, lib/models/build.py:51): a parameter
     that received no gradient on ANY rank keeps `.grad is None`, so the optimiser skips it exactly as torch.optim
@@ -352,6 +352,25 @@ class GradReducer:
         if assumed is not None and tuple(v > 0 for v in vals[:-1]) != assumed:
             self._want_resync = True       # rides in the next step's tail: all ranks re-synchronise together LAG steps after it
         return True
+
+    def flush(self):
+        """"cached" mode checks a step's reduced flags LAG steps later: before a checkpoint / an evaluation / the end of the run, check
+        what is still queued NOW (blocking) and let a requested re-synchronisation happen -- a used-pattern change in the last LAG steps
+        must not reach a checkpoint unnoticed.  Collective when a re-synchronisation is due: every rank calls it at the same point."""
+        if not self.enabled or self.find_unused != "cached":
+            return
+        while self._queue and self.find_unused == "cached":
+            self._check_one(block=True)
+        if self._want_resync:       # this rank saw a changed pattern in the steps just checked: the request must reach the others
+            flag = torch.tensor([1.0], device=self.vt.grad_store().flat.device)
+        else:
+            flag = torch.tensor([0.0], device=self.vt.grad_store().flat.device)
+        dist.all_reduce(flag)
+        if float(flag.item()) > 0 and self.find_unused == "cached":
+            import warnings
+            warnings.warn("GradReducer.flush: a rank saw the set of used parameters change in the last steps; re-synchronising parameters "
+                          "and optimiser state from rank 0 and falling back to find_unused='sync'.")
+            self._resync()
 
     def finish(self):
         if not self.enabled:

@@ -340,6 +340,7 @@ def train(cfg, max_iters=None):
     for cur_epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
         shuffle_dataset(train_loader, cur_epoch)               # train_net.py:503
         train_epoch(train_loader, model, optimizer, reducer, cur_epoch, cfg, max_iters)
+        reducer.flush()       # "cached" used-parameter decisions are checked LAG steps late: settle them before a checkpoint / evaluation
         if cu.is_checkpoint_epoch(cfg, cur_epoch):
             cu.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch, cfg)
         if is_eval_epoch(cfg, cur_epoch):                      # train_net.py:516-518

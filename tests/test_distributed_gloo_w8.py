@@ -103,6 +103,27 @@ def _worker(rank, world, port, results):
     out["cached_mode_after"] = red.find_unused
     out["cached_syncs"] = red.host_syncs
     out["weights_after"] = weights.tolist()
+    # --- flush(): a pattern change in the LAST step of a run (nothing would check it LAG steps later) is settled before a checkpoint
+    red = du.GradReducer(vt, find_unused="cached")
+    weights2 = torch.full((4,), float(rank))
+    ev2 = []
+
+    def resync2():
+        dist.broadcast(weights2, 0)
+        ev2.append(1)
+    red.on_resync = resync2
+    for step in range(3):
+        skip = (i_none, i_half) if (step < 2 or rank != 1) else (i_none,)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _fill(gs, vt, red, float(rank + 1), skip=skip)
+    out["flush_before"] = len(ev2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        red.flush()
+    out["flush_after"] = len(ev2)
+    out["flush_weights"] = weights2.tolist()
+    out["flush_mode"] = red.find_unused
     results[rank] = out
     dist.destroy_process_group()
 
@@ -131,4 +152,5 @@ def test_n_rank_gloo(world):
         assert r["cached_mode_after"] == "sync"
         assert all(r["cached_seen"][steps[0]:]) and not any(r["cached_seen"][:4]), r["cached_seen"]
         assert r["weights_after"] == [0.0] * 4                        # rank 0's copy everywhere
+        assert r["flush_before"] == 0 and r["flush_after"] == 1 and r["flush_weights"] == [0.0] * 4 and r["flush_mode"] == "sync", r
     assert results[1]["cached_seen"][4]                               # the rank that changed reads the new flags at once
