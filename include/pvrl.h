@@ -50,6 +50,21 @@ int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, in
                       int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, const float* bias2,
                       void* stream);
 
+/* Several SMALL problems of pvrl_gemm_nt_bf16 in one launch (128 x 128 tiles; epilogue PVRL_EPI_BF16, PVRL_EPI_F32 or PVRL_EPI_RESID_F32,
+ * the same for all): the 768^3 products of the temporal branch's two back-to-back linear maps (vit.py:131-134) -- W_fc W_proj of every
+ * block, and in backward dW_e W_proj^T / W_fc^T dW_e -- are 36 tiles each on a 256-CU chip; a dozen per launch fill it.  Per problem:
+ * out0 = [aux +] rowscale * (A W^T + bias), N % 128 == 0, K % 64 == 0, leading dimensions multiples of 8.  Any nprob (12 per launch). */
+typedef struct pvrl_nt_problem {
+  const void* A; int64_t lda;     /* bf16 [M, K] */
+  const void* W; int64_t ldw;     /* bf16 [N, K] */
+  int64_t M, N, K;
+  const float* bias;              /* fp32 [N] or null */
+  const float* rowscale;          /* fp32 [M] or null */
+  const void* aux; int64_t aux_ld; /* fp32 [M, aux_ld] (PVRL_EPI_RESID_F32) or null */
+  void* out0; int64_t ld0;
+} pvrl_nt_problem;
+int pvrl_gemm_nt_batched_bf16(int nprob, const pvrl_nt_problem* problems, int epilogue, void* stream);
+
 /* C[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias, all fp32 (projection head vit.py:299, step logits
  * `x @ label_emb.t() / temp` vit.py:307,334,340,432).  Long reductions with few output tiles are split over K into fp32
  * partials (workspace >= pvrl_gemm_nt_f32_small_workspace_bytes, may be 0 / null when that returns 0) summed in a fixed

@@ -30,7 +30,7 @@ def operand_torch_dtype():
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "void**": ctypes.c_void_p,
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
-    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p,
+    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -66,6 +66,14 @@ class TnProblem(ctypes.Structure):
     _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_int64), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
                 ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("beta", ctypes.c_float),
                 ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("gscale", ctypes.c_void_p), ("nonfinite", ctypes.c_void_p)]
+
+
+class NtProblem(ctypes.Structure):
+    """`pvrl_nt_problem` of include/pvrl.h"""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+                ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("bias", ctypes.c_void_p),
+                ("rowscale", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("aux_ld", ctypes.c_int64), ("out0", ctypes.c_void_p),
+                ("ld0", ctypes.c_int64)]
 
 
 class CastProblem(ctypes.Structure):

@@ -237,6 +237,40 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
   }
 }
 
+extern "C" int pvrl_gemm_nt_batched_bf16(int nprob, const pvrl_nt_problem* problems, int epilogue, void* stream) {
+  if (nprob <= 0) return PVRL_OK;
+  if (!problems || (epilogue != PVRL_EPI_BF16 && epilogue != PVRL_EPI_F32 && epilogue != PVRL_EPI_RESID_F32)) return PVRL_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i0 = 0; i0 < nprob; i0 += NT_BATCH_MAX) {
+    GemmNTBatch g = {};
+    g.n = nprob - i0 < NT_BATCH_MAX ? nprob - i0 : NT_BATCH_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const pvrl_nt_problem& q = problems[i0 + i];
+      if (!q.A || !q.W || !q.out0 || q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.N % 128) || (q.K % BK)) return PVRL_EINVAL;
+      if ((q.lda % 8) || (q.ldw % 8) || (q.ld0 % 8) || (epilogue == PVRL_EPI_RESID_F32 && (!q.aux || (q.aux_ld % 8)))) return PVRL_EINVAL;
+      GemmNT& p = g.prob[i];
+      p.A = (const op_t*)q.A; p.lda = q.lda; p.W = (const op_t*)q.W; p.ldw = q.ldw;
+      p.M = (int)q.M; p.N = (int)q.N; p.K = (int)q.K;
+      p.bias = q.bias; p.bias2 = nullptr; p.rowscale = q.rowscale; p.aux = q.aux; p.aux_ld = q.aux_ld; p.aux_rowmod = 0;
+      p.out0 = q.out0; p.ld0 = q.ld0; p.out1 = nullptr; p.ld1 = 0; p.m_off = 0;
+      p.cus = nt_cus_per_xcd(); p.tails = 0;
+      p.tiles_n = p.N / 128; p.tiles_m = cdiv(p.M, 128); p.gm = nt_gm_for(p.tiles_n);
+      p.nwg = 8 * cdiv(p.tiles_m, 8) * p.tiles_n;
+      g.first[i] = blocks;
+      blocks += p.nwg;
+    }
+    g.first[g.n] = blocks;
+    switch (epilogue) {
+      case PVRL_EPI_BF16: hipLaunchKernelGGL(gemm_nt_batched_kernel<PVRL_EPI_BF16>, dim3(blocks), dim3(256), 0, s, g); break;
+      case PVRL_EPI_F32: hipLaunchKernelGGL(gemm_nt_batched_kernel<PVRL_EPI_F32>, dim3(blocks), dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL(gemm_nt_batched_kernel<PVRL_EPI_RESID_F32>, dim3(blocks), dim3(256), 0, s, g); break;
+    }
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
+
 extern "C" int64_t pvrl_gemm_nt_f32_small_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int splits = f32_small_plan(M, N, K, nullptr);

@@ -303,8 +303,10 @@ __host__ __device__ inline NtTail nt_tail_plan(int cm, int tiles_n, int cus, int
 //   <2,2>: 128x128, 4 waves, 64 KiB LDS, 2 workgroups / CU   (small M: order transformer, CLIP text)
 //   <4,4>: 256x256, 16 waves, 128 KiB LDS, 1 workgroup / CU  (the encoder's 50k-row GEMMs: half the L2->LDS
 //          bytes per FLOP of the 128x128 tile, which is what bounds the small tile at ~0.7-0.9 PFLOP/s)
+// (the body is a device function of the problem and the workgroup's index inside it, so that one launch can carry several small
+//  problems: gemm_nt_batched_kernel below)
 template <int EPI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
+__device__ __forceinline__ void gemm_nt_body(const GemmNT& p, const int bid) {
   constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
   constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
   constexpr bool TAILS = WM == 4 && WN == 4;      // sub-tiles of the last round: 256x256 tiles only
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   int tm, tn;
   int f = 1, sub = 0;    // this workgroup computes rows [sub * BM / f, (sub + 1) * BM / f) of its tile
   {
-    const int xcd = blockIdx.x & 7;
-    int j = blockIdx.x >> 3;
+    const int xcd = bid & 7;
+    int j = bid >> 3;
     const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
     const int cm = qm + (xcd < rm ? 1 : 0);                 // panels owned by this XCD
     const int mbase = xcd * qm + (xcd < rm ? xcd : rm);
@@ -482,6 +484,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   }
 
   if (!TAILS || active) nt_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
+  gemm_nt_body<EPI, WM, WN>(p, (int)blockIdx.x);
+}
+
+// Several SMALL problems in one launch (128 x 128 tiles): the 768^3 products of the fused temporal branch -- W_e = W_fc W_proj of every block
+// at the start of a forward, dW_fc = dW_e W_proj^T and dW_proj = W_fc^T dW_e of every block at the end of a backward -- are 36 tiles each
+// on a 256-CU chip, 16.6 us apiece whatever they carry; twelve of them in one launch fill it (432 tiles).  A problem's workgroups keep
+// their XCD mapping: every first[] is a multiple of 8.
+constexpr int NT_BATCH_MAX = 12;
+struct GemmNTBatch { int n; int first[NT_BATCH_MAX + 1]; GemmNT prob[NT_BATCH_MAX]; };
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_batched_kernel(GemmNTBatch g) {
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < NT_BATCH_MAX; ++t)
+    if (t < g.n && (int)blockIdx.x >= g.first[t]) q = t;
+  gemm_nt_body<EPI, 2, 2>(g.prob[q], (int)blockIdx.x - g.first[q]);
 }
 
 

@@ -359,6 +359,11 @@ class EncoderEngine(GraphReplay):
         # stream it is 58 ms instead of 51 at GPU_MAX_HW_QUEUES=6 (the branches of its graph truly co-run), the capture segfaults
         # inside ROCm 7 at 1-2 queues, and under a foreign stream's long kernel (RCCL) it stalls behind whatever shares its queue
         # (tools/probe/comm_cus_ab.py).  Grouped weight-gradient launches fill the chip on their own; there is nothing to overlap.
+        # the 768^3 GEMMs of the fused temporal branch (W_e per block in forward; dW_fc, dW_proj per block in backward) batched into
+        # one launch per dozen (ops.gemm_nt_batched): 36 tiles apiece cannot fill 256 CUs (PVRL_BATCH_FUSED=0: one launch each, A/B runs)
+        self.batch_fused = os.environ.get("PVRL_BATCH_FUSED", "1") == "1"
+        self._fused_fresh = set()
+        self._chain = []
         self.overlap_wgrad = os.environ.get("PVRL_WGRAD_OVERLAP", "0") == "1"
         self.prefetch_fused = os.environ.get("PVRL_PREFETCH_FUSED", "0") == "1"
         self._side = None
@@ -442,8 +447,8 @@ class EncoderEngine(GraphReplay):
             self._w[("fused_t", id(wf))] = e
         ef, ep = self._weight(wf), self._weight(wp)
         ver = (ef.ver, ep.ver, blk.temporal_attn.proj.bias._version)
-        if self._capturing == "bwd" or id(blk) in self._fe_events:     # (built a moment ago by _prefetch_fused_temporal)
-            return e
+        if self._capturing == "bwd" or id(blk) in self._fe_events or id(blk) in self._fused_fresh:     # (built a moment ago by
+            return e                                                     #  _prefetch_fused_temporal / _build_fused_all)
         if self._capturing == "fwd" or e.ver != ver or e.w is None:
             L = lib()
             we = ops.gemm_nt(ef.w, ep.t, L.PVRL_EPI_F32)                    # [out, in] = W_fc [out, mid] . W_proj [mid, in]
@@ -502,6 +507,71 @@ class EncoderEngine(GraphReplay):
         ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
         gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
         ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)            # [mid] = W_fc^T db_e (bf16 operand copy)
+
+    def _build_fused_all(self):
+        """W_e = W_fc W_proj (and b_e) of every block whose weights changed, at the start of a forward: ONE batched launch of the twelve
+        768^3 GEMMs and one of the twelve casts instead of a 16.6-us GEMM + a cast in front of every block's temporal GEMM."""
+        self._fused_fresh = set()
+        if not self.batch_fused or self.prefetch_fused:
+            return
+        stale = [blk for blk in self.m.blocks if self._fused_temporal_stale(blk)]
+        if len(stale) < 2:
+            return
+        L = lib()
+        ents, probs = [], []
+        for blk in stale:
+            wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
+            e = self._w.get(("fused_t", id(wf)))
+            if e is None:
+                e = _W()
+                self._w[("fused_t", id(wf))] = e
+            ef, ep = self._weight(wf), self._weight(wp)
+            ents.append((blk, e, ef, ep))
+            probs.append(dict(A=ef.w, W=ep.t))                              # [out, in] = W_fc [out, mid] . W_proj [mid, in]
+        wes = ops.gemm_nt_batched(probs, L.PVRL_EPI_F32)
+        items = []
+        for we, (blk, e, ef, ep) in zip(wes, ents):
+            if e.w is None or e.w.device != we.device:
+                e.w = torch.empty(we.shape, device=we.device, dtype=OP16)
+                e.t = torch.empty((we.shape[1], we.shape[0]), device=we.device, dtype=OP16)
+            items.append((we, e.w, e.t))
+        ops.cast_weights_multi(items)
+        for blk, e, ef, ep in ents:
+            e.be = ops.gemv_rows(blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.bias.detach(), out=e.be)
+            e.ver = (ef.ver, ep.ver, blk.temporal_attn.proj.bias._version)
+            self._fused_fresh.add(id(blk))
+
+    def _temporal_chain_all(self, gs):
+        """`_temporal_chain` for every block queued by the backward (no gradient hook installed: nobody needs a block's gradients
+        before the end): the 2 x 12 GEMMs dW_fc = dW_e W_proj^T, dW_proj = W_fc^T dW_e as batched launches, the twelve casts as one."""
+        chain, self._chain = self._chain, []
+        if not chain:
+            return
+        L = lib()
+        rs = gs.inv_row if gs.inv is not None else None
+        dev = chain[0][1].device
+        C = self.C
+        items = []
+        for blk, dwe, dbe in chain:
+            items.append((dwe, torch.empty((C, C), device=dev, dtype=OP16), torch.empty((C, C), device=dev, dtype=OP16)))
+        ops.cast_weights_multi(items)
+        groups = {0.0: [], 1.0: []}
+        for (blk, dwe, dbe), (_, dwe_b, dwe_t) in zip(chain, items):
+            wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
+            ef, ep = self._weight(wf), self._weight(wp)
+            for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t)):
+                g, beta = gs.target(lin_w, fused=True)
+                groups[beta].append(dict(A=A, W=W, rowscale=rs, out0=g, aux=g if beta else None))
+        if groups[0.0]:
+            ops.gemm_nt_batched(groups[0.0], L.PVRL_EPI_F32)
+        if groups[1.0]:
+            ops.gemm_nt_batched(groups[1.0], L.PVRL_EPI_RESID_F32)
+        for blk, dwe, dbe in chain:
+            wf = blk.temporal_fc.weight
+            ef = self._weight(wf)
+            ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
+            gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
+            ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)
 
     def grad_store(self):
         return self.m.grad_store()
@@ -622,6 +692,7 @@ class EncoderEngine(GraphReplay):
         m = self.m
         self._refresh_weights()
         self._refreshed = True
+        self._build_fused_all()
         self._prefetch_fused_temporal(frames.device)
         B, _, T, HI, WI = frames.shape
         Wp = WI // 16
@@ -743,6 +814,8 @@ class EncoderEngine(GraphReplay):
         self._wpost = []
         self._side_keep = []
         self._fe_events = {}
+        self._chain = []
+        self._fused_fresh = set()
 
     def _enc_params(self):
         """the parameters whose gradients backward() writes"""
@@ -776,6 +849,7 @@ class EncoderEngine(GraphReplay):
         assert sv is not None, "backward() without a saved forward()"
         gs = self.grad_store()
         R, M = sv["R"], sv["M"]
+        self._chain = []
         if SCALED_GRADS:
             dfeat = gs.begin_scaled(dfeat)
         dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
@@ -820,6 +894,7 @@ class EncoderEngine(GraphReplay):
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
         self.flush_wgrads()
+        self._temporal_chain_all(gs)
         self.join_side_stream()
         if gs.scale is not None:
             gs.end_scaled()
@@ -885,7 +960,11 @@ class EncoderEngine(GraphReplay):
         fe = self._fused_temporal(blk)
         dwe = torch.empty((C, C), device=dev, dtype=F32)
         dbe = torch.empty(C, device=dev, dtype=F32)
-        self._wgrad(dz, s["o_t"], dwe, dbe, 0.0, post=lambda b=blk, w=dwe, v=dbe: self._temporal_chain(b, gs, w, v))
+        if self.batch_fused and self.grad_hook is None:       # nobody needs this block's gradients before the end of the backward:
+            self._wgrad(dz, s["o_t"], dwe, dbe, 0.0)           # the chain of all blocks runs batched in _bwd_end
+            self._chain.append((blk, dwe, dbe))
+        else:
+            self._wgrad(dz, s["o_t"], dwe, dbe, 0.0, post=lambda b=blk, w=dwe, v=dbe: self._temporal_chain(b, gs, w, v))
         dot = ops.gemm_nt(dz, fe.t, L.PVRL_EPI_BF16)
         if T == 8:
             dqkv_t = ops.attn_t8_bwd(s["qkv_t"], dot, B * N, H, self.scale)

@@ -106,6 +106,37 @@ def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=No
     return (out0, out1) if two else out0
 
 
+def gemm_nt_batched(problems, epi):
+    """problems: list of dicts (A, W[, bias, rowscale, aux, out0]) -> list of out0; one launch per 12 problems (pvrl_gemm_nt_batched_bf16):
+    out0 = [aux +] rowscale * (A W^T + bias) with the 128 x 128-tile kernel.  `epi`: PVRL_EPI_BF16 | PVRL_EPI_F32 | PVRL_EPI_RESID_F32."""
+    from ._lib import NtProblem
+    L = lib()
+    if not problems:
+        return []
+    f32_out = epi in (L.PVRL_EPI_RESID_F32, L.PVRL_EPI_F32)
+    arr = (NtProblem * len(problems))()
+    outs, flops = [], 0.0
+    for a, pr in zip(arr, problems):
+        A, W = _chk2d(pr["A"], OP16), _chk2d(pr["W"], OP16)
+        M, K = A.shape
+        N = W.shape[0]
+        assert W.shape[1] == K
+        out0 = pr.get("out0")
+        if out0 is None:
+            out0 = torch.empty((M, N), device=A.device, dtype=F32 if f32_out else OP16)
+        aux, bias, rs = pr.get("aux"), pr.get("bias"), pr.get("rowscale")
+        a.A, a.lda, a.W, a.ldw, a.M, a.N, a.K = A.data_ptr(), _ld(A), W.data_ptr(), _ld(W), M, N, K
+        a.bias = None if bias is None else bias.data_ptr()
+        a.rowscale = None if rs is None else rs.data_ptr()
+        a.aux, a.aux_ld = (None, 0) if aux is None else (aux.data_ptr(), _ld(aux))
+        a.out0, a.ld0 = out0.data_ptr(), _ld(out0)
+        outs.append(out0)
+        flops += 2.0 * M * N * K
+    _timed("gemm_nt_batched<" + _EPI_NAMES[epi] + ">", flops, lambda: L.call(
+        "pvrl_gemm_nt_batched_bf16", len(problems), ctypes.addressof(arr), epi, _stream()))
+    return outs
+
+
 def gemm_nt_f32(A, B, bias=None, alpha=1.0, out=None):
     L = lib()
     _chk2d(A, F32); _chk2d(B, F32)

@@ -110,6 +110,33 @@ def check_gemm_nt():
     return out
 
 
+def check_gemm_nt_batched():
+    """pvrl_gemm_nt_batched_bf16: several small NT problems in one launch (the 768^3 products of the fused temporal branch) vs fp32 math
+    on the rounded operands; differing shapes, ragged M, row scale, residual, more problems than one launch carries."""
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(21)
+    out = []
+    shapes = [(768, 768, 768)] * 13 + [(300, 256, 128), (130, 128, 64), (1000, 384, 256)]
+    probs, refs = [], []
+    for (M, N, K) in shapes:
+        A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05
+        rs = torch.rand(M, generator=g) + 0.5
+        aux = torch.randn(M, N, generator=g)
+        probs.append(dict(A=A.to(dev(), BF), W=W.to(dev(), BF), rowscale=rs.to(dev()), aux=aux.to(dev())))
+        refs.append((bf(A) @ bf(W).t(), rs, aux))
+    o = ops.gemm_nt_batched([dict(A=p["A"], W=p["W"]) for p in probs], L.PVRL_EPI_F32)
+    out.append(("gemm_nt_batched f32 (16 problems, worst)", max(rel(x, r[0]) for x, r in zip(o, refs)), 1e-5))
+    o = ops.gemm_nt_batched(probs, L.PVRL_EPI_RESID_F32)
+    out.append(("gemm_nt_batched residual + row scale (worst)", max(rel(x, r[2] + r[1][:, None] * r[0]) for x, r in zip(o, refs)), 1e-5))
+    o = ops.gemm_nt_batched([dict(A=p["A"], W=p["W"]) for p in probs[:3]], L.PVRL_EPI_BF16)
+    out.append(("gemm_nt_batched 16-bit out (worst)", max(rel(x, r[0]) for x, r in zip(o, refs)), TOL_BF16))
+    one = ops.gemm_nt(probs[0]["A"], probs[0]["W"], L.PVRL_EPI_F32)
+    out.append(("gemm_nt_batched == gemm_nt bit for bit", float((one != ops.gemm_nt_batched([dict(A=probs[0]["A"], W=probs[0]["W"])], L.PVRL_EPI_F32)[0]).sum()), 0.0))
+    return out
+
+
 def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -702,5 +729,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
