@@ -358,11 +358,14 @@ int pvrl_cast_weight_pad_bf16(const float* in, void* out, int64_t ldo, void* out
  *                biasscale = the mean DropPath factor over the T frames of vit.py:144-149)
  *   epilogue 1:  u = X[m] . W[n] + bias[n];  out = GELU_erf(u) (nn.GELU, vit.py:45); out16_pre / out16_act (optional, the
  *                library's 16-bit operand type, leading dimension ld16) receive u / GELU(u)
- * X [M, K], W [N, K], out fp32; N % 16 == 0, K % 128 == 0; HBM-bound on W, deterministic (fixed summation order). */
+ * X [M, K], W [N, K], out fp32; N % 16 == 0, K % 128 == 0; HBM-bound on W, deterministic (fixed summation order).
+ * Long reductions with few output columns (fc2: N = 768, K = 3072) are cut into four slices of K over workgroups whose products a
+ * second small kernel sums in slice order: workspace >= pvrl_cls_linear_f32_workspace_bytes (0 / null when that returns 0). */
+int64_t pvrl_cls_linear_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int pvrl_cls_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t M, int64_t N,
                         int64_t K, int epilogue, const float* rowscale, const float* biasscale, const float* aux,
                         int64_t ld_aux, float* out, int64_t ldo, void* out16_pre, void* out16_act, int64_t ld16,
-                        void* stream);
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[r][c] = beta*out[r][c] + in[r][c] for an R x C block (unpadding weight gradients into the parameter's grad). */
 int pvrl_copy2d_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t R, int64_t C, float beta, void* stream);

@@ -29,21 +29,44 @@ struct ClsLin {
   const float* aux; long ld_aux;      // fp32 [M, N] or null: added last (residual)
   float* out; long ldo;
   op_t* o16a; op_t* o16b; long ld16;  // GELU epilogue: 16-bit copies of the pre-activation / the activation (or null)
-  int M, N, K;
+  float* part;               // ksplit > 1: [ksplit][M][N] partial products of the K slices (cls_epilogue_kernel sums them in slice order)
+  int M, N, K, ksplit;
 };
 
-constexpr int CL_MT = 3;      // 16-row tiles of X per pass: 48 rows (more rows: grid.y passes, W is streamed again)
+constexpr int CL_MT = 3;      // at most this many 16-row tiles of X per pass: 48 rows (more rows: grid.y passes, W is streamed again)
 
 // EPI 0: aux + rowscale * acc + biasscale * bias;  1: exact-erf GELU(acc + bias).  KU: 16-wide k steps per unrolled chunk (all of a
 // chunk's loads are in flight before its first MFMA)
-template <int NW, int EPI, int KU>
+__device__ __forceinline__ void cls_store(const ClsLin& p, int epi, int m, int n, float s) {
+  const float b = p.bias ? p.bias[n] : 0.f;
+  if (epi == 0) {
+    float y = (p.rowscale ? p.rowscale[m] * s : s) + (p.biasscale ? p.biasscale[m] * b : b);
+    if (p.aux) y += p.aux[(long)m * p.ld_aux + n];
+    p.out[(long)m * p.ldo + n] = y;
+  } else {
+    const float u = s + b;
+    const float g = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+    p.out[(long)m * p.ldo + n] = g;
+    if (p.o16a) p.o16a[(long)m * p.ld16 + n] = (op_t)u;
+    if (p.o16b) p.o16b[(long)m * p.ld16 + n] = (op_t)g;
+  }
+}
+
+// CL_MT template parameter MT: 16-row tiles actually carried (M <= 16 -> 1, <= 32 -> 2: a third tile of clamped rows is a third more
+// activation loads).  gridDim.z = slices of K (ksplit): with one workgroup per 16 columns the long reduction of fc2 (N = 768, K = 3072)
+// ran on 48 CUs and took 25 us for 9.4 MB -- what ONE CU's vector-memory path moves, not HBM; cut into four slices it runs on 192, the
+// slices' products go to a workspace and cls_epilogue_kernel sums them in slice order (no atomics, no device-scope fences: on this
+// chip an agent-scope release writes an XCD's L2 back -- a last-arriver reduce inside the kernel was measured 3-6x SLOWER than this).
+template <int NW, int EPI, int KU, int MT>
 __global__ __launch_bounds__(NW * 64) void cls_linear_kernel(ClsLin p) {
+  constexpr int CL_MT = MT;
   __shared__ float part[NW][CL_MT][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * CL_MT);
   const int mt_n = min(CL_MT, (p.M - m0 + 15) >> 4);
-  const int kw = p.K / NW, kbeg = wave * kw;
+  const int kslice = p.K / p.ksplit;
+  const int kw = kslice / NW, kbeg = blockIdx.z * kslice + wave * kw;
   const float* wrow = p.W + (long)(n0 + r) * p.ldw + kbeg + q * 4;
   const float* xrow[CL_MT];
 #pragma unroll
@@ -81,43 +104,61 @@ __global__ __launch_bounds__(NW * 64) void cls_linear_kernel(ClsLin p) {
     for (int w = 0; w < NW; ++w) s += part[w][t][i][l];
     const int m = m0 + t * 16 + 4 * (l >> 4) + i, n = n0 + (l & 15);
     if (m >= p.M) continue;
-    const float b = p.bias ? p.bias[n] : 0.f;
-    if (EPI == 0) {
-      float y = (p.rowscale ? p.rowscale[m] * s : s) + (p.biasscale ? p.biasscale[m] * b : b);
-      if (p.aux) y += p.aux[(long)m * p.ld_aux + n];
-      p.out[(long)m * p.ldo + n] = y;
-    } else {
-      const float u = s + b;
-      const float g = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
-      p.out[(long)m * p.ldo + n] = g;
-      if (p.o16a) p.o16a[(long)m * p.ld16 + n] = (op_t)u;
-      if (p.o16b) p.o16b[(long)m * p.ld16 + n] = (op_t)g;
-    }
+    if (p.ksplit > 1) p.part[((long)blockIdx.z * p.M + m) * p.N + n] = s;
+    else cls_store(p, EPI, m, n, s);
   }
 }
 
+__global__ __launch_bounds__(256) void cls_epilogue_kernel(ClsLin p, int epi) {
+  const long MN = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) s += p.part[(long)z * MN + i];
+    cls_store(p, epi, (int)(i / p.N), (int)(i % p.N), s);
+  }
+}
+
+template <int NW, int KU, int MT>
+int launch_cls_mt(const ClsLin& p, int epi, hipStream_t s) {
+  dim3 grid((unsigned)(p.N / 16), (unsigned)cdiv(p.M, 16 * MT), (unsigned)p.ksplit);
+  if (epi == 0) hipLaunchKernelGGL((cls_linear_kernel<NW, 0, KU, MT>), grid, dim3(NW * 64), 0, s, p);
+  else hipLaunchKernelGGL((cls_linear_kernel<NW, 1, KU, MT>), grid, dim3(NW * 64), 0, s, p);
+  PVRL_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    hipLaunchKernelGGL(cls_epilogue_kernel, dim3((unsigned)cdiv((long)p.M * p.N, 256)), dim3(256), 0, s, p, epi);
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
 template <int NW, int KU>
 int launch_cls_ku(const ClsLin& p, int epi, hipStream_t s) {
-  dim3 grid((unsigned)(p.N / 16), (unsigned)cdiv(p.M, 16 * CL_MT));
-  if (epi == 0) hipLaunchKernelGGL((cls_linear_kernel<NW, 0, KU>), grid, dim3(NW * 64), 0, s, p);
-  else hipLaunchKernelGGL((cls_linear_kernel<NW, 1, KU>), grid, dim3(NW * 64), 0, s, p);
-  PVRL_LAUNCH_CHECK();
-  return PVRL_OK;
+  if (p.M <= 16) return launch_cls_mt<NW, KU, 1>(p, epi, s);
+  if (p.M <= 32) return launch_cls_mt<NW, KU, 2>(p, epi, s);
+  return launch_cls_mt<NW, KU, 3>(p, epi, s);
 }
 template <int NW>
 int launch_cls(const ClsLin& p, int epi, hipStream_t s) {
-  const int kw = p.K / NW;
-  if (kw % 96 == 0) return launch_cls_ku<NW, 6>(p, epi, s);      // ViT-B: 768 / 8 and 3072 / 16
+  const int kw = p.K / p.ksplit / NW;
+  if (kw % 96 == 0) return launch_cls_ku<NW, 6>(p, epi, s);      // ViT-B: 768 / 8, and 3072 in four slices
   if (kw % 32 == 0) return launch_cls_ku<NW, 2>(p, epi, s);
   return launch_cls_ku<NW, 1>(p, epi, s);
 }
 
 }  // namespace
 
+// slices of K: the long reductions with few column tiles (fc2: N = 768, K = 3072 -> 4 x 48 workgroups)
+static int cls_ksplit(int64_t N, int64_t K) { return (K >= 2048 && K % 1024 == 0 && N / 16 < 128) ? 4 : 1; }
+
+extern "C" int64_t pvrl_cls_linear_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int64_t ks = cls_ksplit(N, K);
+  return ks > 1 ? ks * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int pvrl_cls_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t M,
                                    int64_t N, int64_t K, int epilogue, const float* rowscale, const float* biasscale,
                                    const float* aux, int64_t ld_aux, float* out, int64_t ldo, void* out16_pre,
-                                   void* out16_act, int64_t ld16, void* stream) {
+                                   void* out16_act, int64_t ld16, void* workspace, int64_t workspace_bytes, void* stream) {
   if (M <= 0) return PVRL_OK;
   if (!X || !W || !out || N <= 0 || K <= 0 || (N % 16) || (K % 128) || (epilogue != 0 && epilogue != 1)) return PVRL_EINVAL;
   if ((ldx % 4) || (ldw % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15)) return PVRL_EINVAL;
@@ -126,9 +167,10 @@ extern "C" int pvrl_cls_linear_f32(const float* X, int64_t ldx, const float* W, 
   p.X = X; p.ldx = ldx; p.W = W; p.ldw = ldw; p.bias = bias; p.rowscale = rowscale; p.biasscale = biasscale;
   p.aux = aux; p.ld_aux = ld_aux; p.out = out; p.ldo = ldo;
   p.o16a = (op_t*)out16_pre; p.o16b = (op_t*)out16_act; p.ld16 = ld16;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksplit = cls_ksplit(N, K);
+  p.part = (float*)workspace;
+  if (p.ksplit > 1 && (!workspace || workspace_bytes < pvrl_cls_linear_f32_workspace_bytes(M, N, K))) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // waves per workgroup = slices of K: 16 for the long reductions (fc2: K = 3072), else 8; K / waves stays a multiple of 16
-  if (K % 256 == 0 && K >= 2048) return launch_cls<16>(p, epilogue, s);
+  // eight waves per workgroup = eight slices of the workgroup's K range; K / ksplit / 8 stays a multiple of 16
   return launch_cls<8>(p, epilogue, s);
 }

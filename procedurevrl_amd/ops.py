@@ -161,8 +161,11 @@ def cls_linear(X, W, bias=None, gelu=False, rowscale=None, biasscale=None, aux=N
     assert W.shape[1] == K
     if out is None:
         out = torch.empty((M, N), device=X.device, dtype=F32)
+    nbytes = L.call("pvrl_cls_linear_f32_workspace_bytes", M, N, K)
+    ws = workspace(nbytes, X.device, "cls_part") if nbytes else None
     L.call("pvrl_cls_linear_f32", _ptr(X), _ld(X), _ptr(W), _ld(W), _ptr(bias), M, N, K, 1 if gelu else 0, _ptr(rowscale),
-           _ptr(biasscale), _ptr(aux), _ld(aux) if aux is not None else 0, _ptr(out), _ld(out), None, None, 0, _stream())
+           _ptr(biasscale), _ptr(aux), _ld(aux) if aux is not None else 0, _ptr(out), _ld(out), None, None, 0, _ptr(ws),
+           ws.numel() if ws is not None else 0, _stream())
     return out
 
 

@@ -156,7 +156,7 @@ def check_cls_linear():
     g = torch.Generator().manual_seed(12)
     out = []
     for (M, N, K) in [(32, 768, 768), (36, 3072, 768), (32, 768, 3072), (2, 768, 768), (50, 3072, 768), (7, 768, 3072), (3, 512, 512),
-                      (5, 256, 128)]:
+                      (5, 256, 128), (100, 256, 2048)]:      # one to three 16-row tiles, several row passes; K >= 2048 with few columns: four K slices
         X = torch.randn(M, K, generator=g)
         W = torch.randn(N, K, generator=g) * 0.05
         bias = torch.randn(N, generator=g)
@@ -175,6 +175,8 @@ def check_cls_linear():
         big = torch.zeros(M + 5, N + 64, device=dev())
         ops.cls_linear(Xd, Wd, None, out=big[5:, :N])
         out.append((f"cls_linear strided out {M}x{N}x{K}", rel(big[5:, :N], acc), TOL_F32))
+        again = ops.cls_linear(Xd, Wd, bd)          # (K slices are summed by a second kernel in slice order)
+        out.append((f"cls_linear repeatable {M}x{N}x{K}", float((again != ops.cls_linear(Xd, Wd, bd)).sum()), 0.0))
     return out
 
 
