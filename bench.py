@@ -39,6 +39,9 @@ def main():
                                                              "(the default run keeps to the headline, the bf16 flavour and the full pre-training step)")
     ap.add_argument("--sustained-steps", type=int, default=None,
                     help="back-to-back steps of the `sustained` leg after the timed region (default: 300 on the default single-GPU run, else 0)")
+    ap.add_argument("--world1-rccl", action="store_true",
+                    help="one GPU, but through the N > 1 machinery: a 1-rank RCCL process group, the per-block gradient hook between staged "
+                         "HIP-graph replays, RCCL's all-reduce / all-gather kernels on its own stream (what the data-parallel path costs a rank)")
     ap.add_argument("--parity-probe", action="store_true",
                     help="after the timed region: 2 clips of the SAME full-size model (12 blocks, 8x224^2, K=9871), one training "
                          "step vs the CPU oracle (checker only) -> `parity` in the JSON line (logits / loss / worst gradient error)")
@@ -62,6 +65,7 @@ def main():
     backend = os.environ.get("PVRL_DIST_BACKEND", "nccl")          # "gloo" = functional test of the N > 1 path on one GPU
     if os.environ.get("PVRL_SINGLE_DEVICE"):
         local_rank = 0
+    comm_cus = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -74,6 +78,13 @@ def main():
             dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    dp_path = world > 1
+    if args.world1_rccl and world == 1:
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        dp_path = True
 
     from procedurevrl_amd import ops
     from procedurevrl_amd._lib import OPERAND            # the loaded library's 16-bit operand type: "bf16" | "f16"
@@ -136,7 +147,7 @@ def main():
     optimizer = construct_optimizer(model, cfg)
     set_lr(optimizer, cfg.SOLVER.BASE_LR)
     optimizer.grad_scale = 1.0 / world
-    reducer = GradReducer(vt, find_unused=False)     # every parameter gets a gradient every step: no per-step host sync
+    reducer = GradReducer(vt, enabled=dp_path, find_unused=False)     # every parameter gets a gradient every step: no per-step host sync
 
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -150,7 +161,7 @@ def main():
         pred = model(frames)
         loss = kl_topk_loss(pred, teacher, 5)                                # step matching (tools/train_net.py:152-160)
         v = vt.last_video_emb                                                # unit-norm clip embeddings [B, 512]
-        v_all, t_all = (AllGather.apply(v), AllGather.apply(text_emb)) if world > 1 else (v, text_emb)
+        v_all, t_all = (AllGather.apply(v), AllGather.apply(text_emb)) if dp_path else (v, text_emb)
         loss = loss + nce(v_all * (1.0 / 0.07 ** 0.5), t_all * (1.0 / 0.07 ** 0.5))   # global InfoNCE over all ranks' clips
         loss.backward()
         reducer.finish()
@@ -158,7 +169,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if dp_path:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -279,7 +290,7 @@ def main():
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "comm": None if world == 1 else {"backend": backend, "ranks": dist.get_world_size(),
+            "comm": None if not dp_path else {"backend": backend, "ranks": dist.get_world_size(),
                                              "rccl": rccl_version(torch) if backend == "nccl" else None,
                                              "cus_per_xcd_left_to_rccl": comm_cus, "compute_cus_per_xcd": os.environ.get("PVRL_COMPUTE_CUS"),
                                              "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
@@ -332,7 +343,7 @@ def main():
         status = 3 if failed else 0
     else:
         status = 0
-    if world > 1:
+    if dp_path:
         dist.barrier()
         dist.destroy_process_group()
     return status

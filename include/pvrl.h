@@ -223,6 +223,10 @@ int pvrl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, do
                   double weight_decay, int nesterov, int first_step, double gscale, const float* skip, void* stream);
 /* *flag = 1 when any of x[0, n) is inf / nan; never cleared here (zero it, then chain the buffers to check).  x 16-byte aligned. */
 int pvrl_nonfinite_flag_f32(const float* x, int64_t n, float* flag, void* stream);
+/* The fp16-operand flavour's per-backward gradient scale (procedurevrl_amd/engine.py GradStore.begin_scaled) in one launch: S = the power of
+ * two that brings max|g| to ~target, chosen on the device (no host sync); out[0, n) = g * S, scale[0] = S, inv[0, ninv) = 1 / S (the `gscale`
+ * of the gradient-writing entry points; repeated so that it can also serve as a GEMM epilogue's per-row scale).  inf / nan in g leave S finite. */
+int pvrl_grad_scale_begin(const float* g, int64_t n, float target, float* out, float* scale, float* inv, int64_t ninv, void* stream);
 /* End of an optimiser step: *total += 1 when *flag != 0 (total may be null), then *flag = 0 -- the flag's life cycle belongs to the
  * step that consumed it, whatever loop calls it. */
 int pvrl_flag_roll(float* flag, float* total, void* stream);

@@ -88,6 +88,43 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
   if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
 }
 
+// The fp16 flavour's gradient scale of one engine backward (engine.GradStore.begin_scaled) in ONE launch: S = 2^floor(log2(target / max|g|))
+// chosen on the device, out = g * S, scale[0] = S, inv[0 .. ninv) = 1 / S (the `gscale` scalar of the gradient-writing kernels, repeated as
+// the per-row scale of a GEMM epilogue).  A non-finite max (inf / nan in g) must not turn S into 0 or 1 / S into inf: S stays a finite
+// power of two and the non-finite values flow on to the loss / gradient checks.  One workgroup: g is an engine's incoming gradient
+// (a few 10^4 elements); torch's abs / max / nan_to_num / clamp / log2 / floor / exp2 / reciprocal / mul chain was 14 launches.
+__global__ __launch_bounds__(1024) void grad_scale_begin_kernel(const float* __restrict__ g, long n, float target, float* __restrict__ out,
+                                                                float* __restrict__ scale, float* __restrict__ inv, int ninv) {
+  __shared__ float red[16];
+  __shared__ float s_scale;
+  float m = 0.f;
+  bool bad = false;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float v = g[i];
+    bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+    m = fmaxf(m, fabsf(v));                         // (fmaxf drops a NaN: tracked separately)
+  }
+  m = wave_max(m);
+  const unsigned long long anybad = __ballot(bad);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = anybad ? __uint_as_float(0x7f800000u) : m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    bool inf = false;
+    for (int w = 0; w < 16; ++w) { inf |= (__float_as_uint(red[w]) & 0x7f800000u) == 0x7f800000u; a = fmaxf(a, red[w]); }
+    if (inf) a = 3e38f;                             // torch path: nan_to_num(nan = 1, posinf = 3e38); either way S stays finite
+    a = fminf(fmaxf(a, 1e-30f), 3e38f);
+    float e = floorf(log2f(target / a));
+    e = fminf(fmaxf(e, -100.f), 100.f);
+    s_scale = exp2f(e);
+  }
+  __syncthreads();
+  const float S = s_scale, iS = 1.0f / S;
+  for (long i = threadIdx.x; i < n; i += 1024) out[i] = g[i] * S;
+  if (threadIdx.x == 0) scale[0] = S;
+  for (int i = threadIdx.x; i < ninv; i += 1024) inv[i] = iS;
+}
+
 // end of an optimiser step: count it when it was dropped and re-arm the flag for the next one
 __global__ void flag_roll_kernel(float* __restrict__ flag, float* __restrict__ total) {
   if (*flag != 0.f && total) *total += 1.f;
@@ -95,6 +132,14 @@ __global__ void flag_roll_kernel(float* __restrict__ flag, float* __restrict__ t
 }
 
 }  // namespace
+
+extern "C" int pvrl_grad_scale_begin(const float* g, int64_t n, float target, float* out, float* scale, float* inv, int64_t ninv,
+                                     void* stream) {
+  if (!g || !out || !scale || !inv || n <= 0 || ninv < 1 || !(target > 0.f)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(grad_scale_begin_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, (long)n, target, out, scale, inv, (int)ninv);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
 
 extern "C" int pvrl_flag_roll(float* flag, float* total, void* stream) {
   if (!flag) return PVRL_EINVAL;

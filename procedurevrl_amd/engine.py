@@ -126,11 +126,20 @@ class GradStore:
         # a non-finite incoming gradient (amax = inf / nan) must not turn S into 0 and 1/S into inf: S stays a finite power
         # of two, so the non-finite values flow through to the loss check (train_epoch) instead of poisoning gradients
         # accumulated by earlier micro-iterations
-        amax = torch.nan_to_num(g.detach().abs().max(), nan=1.0, posinf=3e38).clamp(1e-30, 3e38)
+        self._touched, self._seen_idx, self._seen_ptr = [], set(), set()
+        g = g.detach()
+        if g.is_cuda and g.dtype == F32 and g.is_contiguous() and g.numel() <= (1 << 20):      # one launch (csrc/optim.hip)
+            out = torch.empty_like(g)
+            self.scale = torch.empty(1, device=g.device, dtype=F32)
+            self.inv_row = torch.empty(4096, device=g.device, dtype=F32)       # 1 / S, also as a GEMM epilogue's per-row scale
+            self.inv = self.inv_row[:1]
+            lib().call("pvrl_grad_scale_begin", ops._ptr(g), g.numel(), float(self.SCALE_TARGET), ops._ptr(out), ops._ptr(self.scale),
+                       ops._ptr(self.inv_row), 4096, ops._stream())
+            return out
+        amax = torch.nan_to_num(g.abs().max(), nan=1.0, posinf=3e38).clamp(1e-30, 3e38)
         self.scale = torch.exp2(torch.floor(torch.log2(self.SCALE_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1)
         self.inv = 1.0 / self.scale
         self.inv_row = self.inv.expand(4096).contiguous()      # 1 / S as a GEMM epilogue's per-row scale (EncoderEngine._temporal_chain)
-        self._touched, self._seen_idx, self._seen_ptr = [], set(), set()
         return g * self.scale
 
     def unscale(self):
@@ -194,6 +203,7 @@ class GraphReplay:
     GRAPH_WARMUP = 2      # eager calls of a key before it is captured (lazy workspaces / caches settle)
     GRAPH_MAX_KEYS = 4    # captured (shape, mode) combinations kept; others run eagerly
     _capturing = None     # "fwd" / "bwd" while a HIP graph of that pass is being captured
+    _staged = False       # ... the backward as one graph per block (a gradient hook runs between the replays)
     _refreshed = False    # EncoderEngine: every weight copy was just rebuilt by _refresh_weights()
 
     def _graph_init(self):
@@ -302,6 +312,7 @@ class GraphReplay:
         params = self._enc_params()
         graphs = []
         self._capturing = "bwd"
+        self._staged = staged          # the hook is detached while capturing: a stage must still finish its block's gradients itself
         err = None
         try:
             self.saved = self._saved_copy(g["saved"])
@@ -329,6 +340,7 @@ class GraphReplay:
             err = e
         finally:
             self._capturing = None
+            self._staged = False
             self.grad_hook = hook
         touched = [(p, p.grad) for p in params if p.grad is not None]     # all were None (_grads_fresh)
         for p, _ in touched:            # capture ran no kernel: undo its host-side effect
@@ -960,7 +972,7 @@ class EncoderEngine(GraphReplay):
         fe = self._fused_temporal(blk)
         dwe = torch.empty((C, C), device=dev, dtype=F32)
         dbe = torch.empty(C, device=dev, dtype=F32)
-        if self.batch_fused and self.grad_hook is None:       # nobody needs this block's gradients before the end of the backward:
+        if self.batch_fused and self.grad_hook is None and not self._staged:   # nobody needs this block's gradients before the end of the backward:
             self._wgrad(dz, s["o_t"], dwe, dbe, 0.0)           # the chain of all blocks runs batched in _bwd_end
             self._chain.append((blk, dwe, dbe))
         else:

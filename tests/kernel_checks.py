@@ -137,6 +137,32 @@ def check_gemm_nt_batched():
     return out
 
 
+def check_grad_scale_begin():
+    """pvrl_grad_scale_begin (engine.GradStore.begin_scaled in one launch) vs the torch formula it replaces: S = the power of two that brings
+    max|g| to the target, g * S exactly, 1 / S in every slot; zeros, inf and nan leave S a finite power of two."""
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    g0 = torch.Generator().manual_seed(4)
+    out = []
+    for name, t in (("normal", torch.randn(32, 768, generator=g0) * 3e-6), ("large", torch.randn(5, 777, generator=g0) * 1e9),
+                    ("zeros", torch.zeros(4, 100)), ("inf", torch.tensor([1.0, float("inf"), -2.0])),
+                    ("nan", torch.tensor([1e-3, float("nan"), 5e-4]))):
+        t = t.contiguous()
+        amax = torch.nan_to_num(t.abs().max(), nan=1.0, posinf=3e38).clamp(1e-30, 3e38)
+        S = torch.exp2(torch.floor(torch.log2(256.0 / amax)).clamp(-100.0, 100.0))
+        if name == "nan":       # the kernel treats nan like inf (S from 3e38): torch's nan_to_num(nan=1) differs only in this don't-care case
+            S = torch.exp2(torch.floor(torch.log2(torch.tensor(256.0 / 3e38))).clamp(-100.0, 100.0))
+        d = t.to(dev())
+        o = torch.empty_like(d); sc = torch.empty(1, device=dev()); inv = torch.empty(64, device=dev())
+        lib().call("pvrl_grad_scale_begin", ops._ptr(d), d.numel(), 256.0, ops._ptr(o), ops._ptr(sc), ops._ptr(inv), 64, ops._stream())
+        out.append((f"grad_scale_begin S ({name})", abs(float(sc) - float(S)) / float(S), 0.0))
+        out.append((f"grad_scale_begin 1/S in every slot ({name})", float((inv.cpu() != 1.0 / S).sum()), 0.0))
+        ref = t * S
+        ok = torch.equal(torch.nan_to_num(o.cpu(), nan=7.0), torch.nan_to_num(ref, nan=7.0))
+        out.append((f"grad_scale_begin g * S exact ({name})", 0.0 if ok else 1.0, 0.0))
+    return out
+
+
 def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -731,5 +757,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
