@@ -138,6 +138,18 @@ int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float*
                        int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16, int64_t ldxs, const float* dxs_scale,
                        int64_t dxs_rows, float* dxsum, const float* gscale, float* nonfinite, void* stream);
 
+/* pvrl_layernorm_bwd with dgamma = dbeta = null leaves its per-workgroup partial sums in `workspace` (the caller keeps that workspace
+ * to itself) instead of reducing them; this entry point then reduces the partials of MANY LayerNorms in one launch -- an encoder backward
+ * has 37, each otherwise followed by its own 7-us reduce: dgamma = beta * dgamma + gscale * sum, dbeta likewise, dxsum with beta_sum. */
+typedef struct pvrl_ln_reduce {
+  const float* part;         /* the workspace a deferred pvrl_layernorm_bwd(M, C, dxsum != null ? 1 : 0) wrote */
+  int64_t M, C;
+  int want_sum;              /* that call had a dxsum target */
+  float beta, beta_sum;
+  float* dgamma; float* dbeta; float* dxsum;
+} pvrl_ln_reduce;
+int pvrl_layernorm_bwd_reduce_batched(int n, const pvrl_ln_reduce* items, const float* gscale, float* nonfinite, void* stream);
+
 /* Temporal attention for T = 8 (Block.forward temporal branch, vit.py:129-135 via Attention.forward
  * vit.py:75-92): sequences are 8 consecutive rows of the packed qkv [rows][3*H*64]. */
 int pvrl_attn_t8_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t H, float scale, void* o, int64_t ldo,

@@ -30,7 +30,7 @@ def operand_torch_dtype():
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "void**": ctypes.c_void_p,
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int*": ctypes.c_void_p,
-    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p,
+    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p, "const pvrl_ln_reduce*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -74,6 +74,13 @@ class NtProblem(ctypes.Structure):
                 ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("bias", ctypes.c_void_p),
                 ("rowscale", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("aux_ld", ctypes.c_int64), ("out0", ctypes.c_void_p),
                 ("ld0", ctypes.c_int64)]
+
+
+class LnReduce(ctypes.Structure):
+    """`pvrl_ln_reduce` of include/pvrl.h"""
+    _fields_ = [("part", ctypes.c_void_p), ("M", ctypes.c_int64), ("C", ctypes.c_int64), ("want_sum", ctypes.c_int),
+                ("beta", ctypes.c_float), ("beta_sum", ctypes.c_float), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("dxsum", ctypes.c_void_p)]
 
 
 class CastProblem(ctypes.Structure):

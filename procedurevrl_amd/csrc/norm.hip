@@ -191,6 +191,42 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
   }
 }
 
+// The same for MANY LayerNorms in one launch: a backward of the encoder has 37 of them, each followed by this 7-us reduce of its
+// per-workgroup partials (dgamma | dbeta | optional column sums) -- 49 launches of a few microseconds on an otherwise idle chip.
+// When nobody needs a block's gradients before the end of the backward, pvrl_layernorm_bwd leaves the partials in their own
+// workspaces (dgamma = null) and ONE launch reduces them all.
+constexpr int LN_RED_MAX = 40;
+struct LnReduceItem { const float* part; int nblk, n, C, pstride; float beta, beta_sum; float* dgamma; float* dbeta; float* dxsum; int first; };
+struct LnReduceBatch { int n; LnReduceItem it[LN_RED_MAX]; const float* gscale; float* nonfinite; };
+__global__ __launch_bounds__(256) void colpart_reduce_batched_kernel(LnReduceBatch g) {
+  __shared__ float red[16][17];
+  int q = 0;
+  for (int t = 1; t < g.n; ++t)
+    if ((int)blockIdx.x >= g.it[t].first) q = t;
+  const LnReduceItem w = g.it[q];
+  const int c = threadIdx.x & 15, gr = threadIdx.x >> 4;
+  const int j = ((int)blockIdx.x - w.first) * 16 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (j < w.n) {
+    int b = gr;
+    for (; b + 16 < w.nblk; b += 32) { a0 += w.part[(long)b * w.pstride + j]; a1 += w.part[(long)(b + 16) * w.pstride + j]; }
+    if (b < w.nblk) a0 += w.part[(long)b * w.pstride + j];
+  }
+  red[gr][c] = a0 + a1;
+  __syncthreads();
+  if (gr == 0 && j < w.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    float* o = j < w.C ? w.dgamma + j : (j < 2 * w.C ? w.dbeta + (j - w.C) : w.dxsum + (j - 2 * w.C));
+    const float beta = j < 2 * w.C ? w.beta : w.beta_sum;
+    if (g.gscale) t *= *g.gscale;
+    const float v = (beta != 0.f ? beta * *o : 0.f) + t;
+    *o = v;
+    if (g.nonfinite && (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u) *g.nonfinite = 1.f;
+  }
+}
+
 // measured on MI355X (M = 50,208): alone, 256 workgroups are fastest (94 us; 512: 99, 1024: 111, 2048: 117 -- fewer partial
 // sums to write and reduce); inside the training step, next to the weight-gradient GEMMs of the side stream, 512 win (572 vs
 // 561 clips/s): one workgroup per CU is starved by the co-running kernel.
@@ -230,7 +266,7 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
                                   int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, float* dxsum, const float* gscale,
                                   float* nonfinite, void* stream) {
   if (M <= 0) return PVRL_OK;
-  if (!dy || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta || !workspace) return PVRL_EINVAL;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx_out || (!dgamma != !dbeta) || !workspace) return PVRL_EINVAL;
   if ((ldx % 4) || (lddy % 4) || (ldo % 4) || (dx_in && (ldi % 4))) return PVRL_EINVAL;
   if (workspace_bytes < pvrl_layernorm_bwd_workspace_bytes(M, C)) return PVRL_EINVAL;
   if (dxs_bf16 && (ldxs % 4)) return PVRL_EINVAL;
@@ -251,12 +287,40 @@ extern "C" int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, c
   if (C == 768) { LN_BWD(768) } else if (C == 512) { LN_BWD(512) } else return PVRL_EINVAL;
 #undef LN_BWD
   PVRL_LAUNCH_CHECK();
+  if (!dgamma) return PVRL_OK;       // deferred: the partials stay in `workspace` for pvrl_layernorm_bwd_reduce_batched
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, s, part, nblk,
                      (int)(2 * C), beta_acc, dgamma, dbeta, (int)C, pstride, gscale, nonfinite);
   PVRL_LAUNCH_CHECK();
   if (dxsum) {
     hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, part + 2 * C, nblk, (int)C,
                        beta_acc, dxsum, dxsum, (int)C, pstride, gscale, nonfinite);
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_layernorm_bwd_reduce_batched(int n, const pvrl_ln_reduce* items, const float* gscale, float* nonfinite,
+                                                 void* stream) {
+  if (n <= 0) return PVRL_OK;
+  if (!items) return PVRL_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += LN_RED_MAX) {
+    LnReduceBatch g = {};
+    g.n = n - i0 < LN_RED_MAX ? n - i0 : LN_RED_MAX;
+    g.gscale = gscale; g.nonfinite = nonfinite;
+    int blocks = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const pvrl_ln_reduce& q = items[i0 + i];
+      if (!q.part || !q.dgamma || !q.dbeta || q.M <= 0 || (q.C != 768 && q.C != 512) || (q.want_sum && !q.dxsum)) return PVRL_EINVAL;
+      LnReduceItem& w = g.it[i];
+      w.part = q.part; w.C = (int)q.C;
+      w.nblk = cdiv(q.M, 4) < LN_BWD_MAX_BLOCKS ? cdiv(q.M, 4) : LN_BWD_MAX_BLOCKS;
+      w.pstride = (2 + (q.want_sum ? 1 : 0)) * (int)q.C;
+      w.n = w.pstride;
+      w.beta = q.beta; w.beta_sum = q.beta_sum; w.dgamma = q.dgamma; w.dbeta = q.dbeta; w.dxsum = q.dxsum;
+      w.first = blocks;
+      blocks += cdiv(w.n, 16);
+    }
+    hipLaunchKernelGGL(colpart_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     PVRL_LAUNCH_CHECK();
   }
   return PVRL_OK;

@@ -376,6 +376,7 @@ class EncoderEngine(GraphReplay):
         self.batch_fused = os.environ.get("PVRL_BATCH_FUSED", "1") == "1"
         self._fused_fresh = set()
         self._chain = []
+        self._ln_defer = []
         self.overlap_wgrad = os.environ.get("PVRL_WGRAD_OVERLAP", "0") == "1"
         self.prefetch_fused = os.environ.get("PVRL_PREFETCH_FUSED", "0") == "1"
         self._side = None
@@ -589,6 +590,12 @@ class EncoderEngine(GraphReplay):
             ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
             gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
             ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)
+
+    def _finish_deferred(self, gs):
+        """what the blocks' backward left for the end (no gradient hook): the fused temporal chains and the LayerNorm partial reduces"""
+        self._temporal_chain_all(gs)
+        items, self._ln_defer = self._ln_defer, []
+        ops.layernorm_bwd_reduce_batched(items, gscale=gs.inv, nonfinite=gs.bad)
 
     def grad_store(self):
         return self.m.grad_store()
@@ -832,6 +839,7 @@ class EncoderEngine(GraphReplay):
         self._side_keep = []
         self._fe_events = {}
         self._chain = []
+        self._ln_defer = []
         self._fused_fresh = set()
 
     def _enc_params(self):
@@ -867,6 +875,7 @@ class EncoderEngine(GraphReplay):
         gs = self.grad_store()
         R, M = sv["R"], sv["M"]
         self._chain = []
+        self._ln_defer = []
         if SCALED_GRADS:
             dfeat = gs.begin_scaled(dfeat)
         dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
@@ -911,7 +920,7 @@ class EncoderEngine(GraphReplay):
         self._acc(gs, pos_p, dpos.unsqueeze(0))
         self._acc(gs, tim_p, dtime.unsqueeze(0))
         self.flush_wgrads()
-        self._temporal_chain_all(gs)
+        self._finish_deferred(gs)
         self.join_side_stream()
         if gs.scale is not None:
             gs.end_scaled()
@@ -943,10 +952,14 @@ class EncoderEngine(GraphReplay):
             (dw, bw), (dbias, _) = gs.target(lin.weight, fused=True), gs.target(lin.bias, fused=True)
             self._wgrad(dy, xin, dw, dbias, bw, gscale=gs.inv, nonfinite=gs.bad)
 
+        # (no gradient hook: the 7-us reduces of the LayerNorm partials are deferred and done for the whole backward in one launch)
+        defer = self._ln_defer if (self.batch_fused and self.grad_hook is None and not self._staged) else None
+
         def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None, dxsum=None, dxsum_beta=None):
             (dg, bg), (db, _) = gs.target(ln.weight, fused=True), gs.target(ln.bias, fused=True)
             ops.layernorm_bwd(dh, x, st[0], st[1], P(ln.weight), dg, db, dx_in=dx_in, dx_out=dx_out, beta_acc=bg,
-                              dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta, gscale=gs.inv, nonfinite=gs.bad)
+                              dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta, gscale=gs.inv, nonfinite=gs.bad,
+                              defer=defer)
 
         # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
         wgrad(dy, s["g"], blk.mlp.fc2)

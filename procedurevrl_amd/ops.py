@@ -282,15 +282,27 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=None, beta_acc=0.0, dxs=None, dxs_scale=None,
-                  dxsum=None, dxsum_beta=None, gscale=None, nonfinite=None):
+                  dxsum=None, dxsum_beta=None, gscale=None, nonfinite=None, defer=None):
     """`dxs` (optional bf16 [rows <= M, C]) additionally receives bf16(dxs_scale[m] * dx_out[m]); `dxsum` (optional fp32
-    [C]) the unscaled column sums of those rows of dx_out (dxsum = dxsum_beta * dxsum + sums)."""
+    [C]) the unscaled column sums of those rows of dx_out (dxsum = dxsum_beta * dxsum + sums).
+    `defer` (a list): the per-workgroup partial sums of dgamma / dbeta / dxsum stay in a private workspace and an entry is appended
+    for `layernorm_bwd_reduce_batched`, which reduces many LayerNorms' partials in one launch."""
     L = lib()
     _chk2d(dy); _chk2d(x, F32)
     M, C = x.shape
     if dx_out is None:
         dx_out = torch.empty((M, C), device=x.device, dtype=F32)
     nbytes = L.call("pvrl_layernorm_bwd_workspace_bytes", M, C)
+    if defer is not None:
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        assert dxsum is None or dxs is not None
+        L.call("pvrl_layernorm_bwd", _ptr(dy), _ld(dy), 1 if dy.dtype == F32 else 0, _ptr(x), _ld(x), _ptr(mean),
+               _ptr(rstd), _ptr(gamma), _ptr(dx_in), _ld(dx_in) if dx_in is not None else 0, _ptr(dx_out), _ld(dx_out),
+               float(beta_acc), None, None, _ptr(ws), ws.numel(), M, C, _ptr(dxs), _ld(dxs) if dxs is not None else 0,
+               _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _ptr(dxsum), None, None, _stream())
+        defer.append(dict(part=ws, M=M, C=C, beta=float(beta_acc), beta_sum=float(beta_acc if dxsum_beta is None else dxsum_beta),
+                          dgamma=dgamma, dbeta=dbeta, dxsum=dxsum))
+        return dx_out
     ws = workspace(nbytes, x.device, "ln")
     tgt = dxsum
     if dxsum is not None:
@@ -307,6 +319,21 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
             raise PvrlError("layernorm_bwd: dxsum_beta = 0 with beta_acc != 0 is not supported")
         dxsum.mul_(float(dxsum_beta)).add_(tgt)
     return dx_out
+
+
+def layernorm_bwd_reduce_batched(items, gscale=None, nonfinite=None):
+    """items: the entries `layernorm_bwd(..., defer=items)` appended -> dgamma / dbeta / dxsum of all of them in one launch"""
+    from ._lib import LnReduce
+    if not items:
+        return
+    arr = (LnReduce * len(items))()
+    for a, it in zip(arr, items):
+        a.part, a.M, a.C = it["part"].data_ptr(), it["M"], it["C"]
+        a.want_sum = 0 if it["dxsum"] is None else 1
+        a.beta, a.beta_sum = it["beta"], it["beta_sum"]
+        a.dgamma, a.dbeta = it["dgamma"].data_ptr(), it["dbeta"].data_ptr()
+        a.dxsum = None if it["dxsum"] is None else it["dxsum"].data_ptr()
+    lib().call("pvrl_layernorm_bwd_reduce_batched", len(items), ctypes.addressof(arr), _ptr(gscale), _ptr(nonfinite), _stream())
 
 
 # ----------------------------------------------------------------------------------------

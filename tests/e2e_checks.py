@@ -110,7 +110,7 @@ def check_block_golden():
     from procedurevrl_amd import ops
     dx = to_rows(f["dy"]).to(DEV).clone()
     eng._block_bwd(vt.blocks[0], sv["blocks"][0], sv, dx, gs, ops.cast_scale(dx, None), False, None)
-    eng._temporal_chain_all(gs)        # (the fused temporal branch's parameter gradients are formed for all blocks at the end of a backward)
+    eng._finish_deferred(gs)           # (the fused temporal chains and the LayerNorm partial reduces of all blocks run at the end of a backward)
     eng.join_side_stream()
     out.append(("block bwd dx vs reference", rel(from_rows(dx, B), f["dx"]), TOL_GRAD))
     named = dict(vt.blocks[0].named_parameters())

@@ -438,6 +438,20 @@ def check_layernorm():
         dxs = torch.zeros(rows, C, device=dev(), dtype=BF)
         dx2 = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg, db, dxs=dxs, dxs_scale=sc.to(dev()))
         out.append((f"ln_bwd fused bf16 scaled copy {M}x{C}", rel(dxs, (sc[:, None] * dx2.cpu())[:rows]), 5e-3))
+        # deferred reduces: the partials of several LayerNorms summed by ONE launch -- bit-equal to the immediate form, accumulate + scale incl.
+        items = []
+        want = []
+        for rep, (beta, bsum) in enumerate(((0.0, 0.0), (1.0, 1.0), (0.0, 1.0))):
+            a_g, a_b, a_s = (torch.full((C,), 0.5 + rep, device=dev()) for _ in range(3))
+            d_g, d_b, d_s = a_g.clone(), a_b.clone(), a_s.clone()
+            ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), a_g, a_b, dxs=dxs, dxs_scale=sc.to(dev()),
+                              beta_acc=beta, dxsum=a_s, dxsum_beta=bsum)
+            ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), d_g, d_b, dxs=dxs, dxs_scale=sc.to(dev()),
+                              beta_acc=beta, dxsum=d_s, dxsum_beta=bsum, defer=items)
+            want.append(((a_g, a_b, a_s), (d_g, d_b, d_s)))
+        ops.layernorm_bwd_reduce_batched(items)
+        diff = sum(float((a != d).sum()) for imm, dfr in want for a, d in zip(imm, dfr))
+        out.append((f"ln_bwd deferred + batched reduce == immediate {M}x{C}", diff, 0.0))
         cs = torch.full((C,), 2.0, device=dev())
         dg2, db2 = torch.ones(C, device=dev()), torch.ones(C, device=dev())
         dx3 = ops.layernorm_bwd(dy.to(dev(), BF), x.to(dev()), mean, rstd, gam.to(dev()), dg2, db2, dxs=dxs, dxs_scale=sc.to(dev()),
