@@ -353,6 +353,14 @@ int pvrl_gemv_rows_f32(const void* W, int w_is_bf16, int64_t ld, int64_t R, int6
 int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const float* b, int64_t R, int64_t C, const float* gscale,
                        void* stream);
 
+/* pvrl_gemv_rows_f32 / pvrl_rank1_add_f32 for many equally-shaped problems in one launch each (HOST arrays of n device pointers; 16 per
+ * launch): b_e = W_fc b_proj of every block at the start of a forward, db_proj = W_fc^T db_e and dW_fc += db_e b_proj^T of every block at
+ * the end of a backward (vit.py:131-134). */
+int pvrl_gemv_rows_batched_f32(int n, const void** W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float** x,
+                               const float* beta, float** y, const float* gscale, void* stream);
+int pvrl_rank1_add_batched_f32(int n, float** out, int64_t ld, const float** a, const float** b, int64_t R, int64_t C,
+                               const float* gscale, void* stream);
+
 /* pvrl_cast_weight_bf16 for many weight matrices in one launch (the bf16 operand copies of every nn.Linear of the
  * encoder after an optimiser step): out [R][C] and, when out_t is not null, out_t [C][R], both dense. */
 typedef struct pvrl_cast_problem {

@@ -29,7 +29,7 @@ def operand_torch_dtype():
 
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "void**": ctypes.c_void_p,
-    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int*": ctypes.c_void_p,
+    "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int*": ctypes.c_void_p, "const void**": ctypes.c_void_p, "const float**": ctypes.c_void_p, "float**": ctypes.c_void_p,
     "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p, "const pvrl_ln_reduce*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
 }

@@ -497,4 +497,75 @@ extern "C" int pvrl_rank1_add_f32(float* out, int64_t ld, const float* a, const 
   return PVRL_OK;
 }
 
+// The bias products of the fused temporal branch for MANY blocks in one launch each (twelve 5-7 us launches of each kind per pass otherwise):
+//   gemv:  y_i[r] = beta_i * y_i[r] + gscale * W_i[r, :] . x_i      rank-1:  out_i[r][c] += gscale * a_i[r] * b_i[c]
+namespace {
+constexpr int SMALL_BATCH_MAX = 16;
+struct GemvBatch { int n, R, C, w16; long ld; const void* W[SMALL_BATCH_MAX]; const float* x[SMALL_BATCH_MAX]; float* y[SMALL_BATCH_MAX]; float beta[SMALL_BATCH_MAX]; const float* gscale; };
+__global__ __launch_bounds__(256) void gemv_rows_batched_kernel(GemvBatch g) {
+  const int q = blockIdx.y, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= g.R) return;
+  const float* x = g.x[q];
+  float a = 0.f;
+  if (g.w16) {
+    const op_t* W = (const op_t*)g.W[q];
+    for (int c = lane; c < g.C; c += 64) a += (float)W[(long)r * g.ld + c] * x[c];
+  } else {
+    const float* W = (const float*)g.W[q];
+    for (int c = lane; c < g.C; c += 64) a += W[(long)r * g.ld + c] * x[c];
+  }
+  a = wave_sum(a);
+  if (g.gscale) a *= *g.gscale;
+  if (lane == 0) g.y[q][r] = (g.beta[q] != 0.f ? g.beta[q] * g.y[q][r] : 0.f) + a;
+}
+struct Rank1Batch { int n, R, C4; long ld; float* out[SMALL_BATCH_MAX]; const float* a[SMALL_BATCH_MAX]; const float* b[SMALL_BATCH_MAX]; const float* gscale; };
+__global__ __launch_bounds__(256) void rank1_add_batched_kernel(Rank1Batch g) {
+  const int q = blockIdx.y;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)g.R * g.C4) return;
+  const int r = (int)(idx / g.C4), c = (int)(idx - (long)r * g.C4) * 4;
+  const float av = g.gscale ? g.a[q][r] * *g.gscale : g.a[q][r];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b[q] + c);
+  f32x4* o = reinterpret_cast<f32x4*>(g.out[q] + (long)r * g.ld + c);
+  *o = *o + av * bv;
+}
+}  // namespace
+
+extern "C" int pvrl_gemv_rows_batched_f32(int n, const void** W, int w_is_bf16, int64_t ld, int64_t R, int64_t C, const float** x,
+                                          const float* beta, float** y, const float* gscale, void* stream) {
+  if (n <= 0 || R <= 0) return PVRL_OK;
+  if (!W || !x || !y || !beta || C <= 0 || ld < C) return PVRL_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += SMALL_BATCH_MAX) {
+    GemvBatch g = {};
+    g.n = n - i0 < SMALL_BATCH_MAX ? n - i0 : SMALL_BATCH_MAX;
+    g.R = (int)R; g.C = (int)C; g.w16 = w_is_bf16; g.ld = ld; g.gscale = gscale;
+    for (int i = 0; i < g.n; ++i) {
+      if (!W[i0 + i] || !x[i0 + i] || !y[i0 + i]) return PVRL_EINVAL;
+      g.W[i] = W[i0 + i]; g.x[i] = x[i0 + i]; g.y[i] = y[i0 + i]; g.beta[i] = beta[i0 + i];
+    }
+    hipLaunchKernelGGL(gemv_rows_batched_kernel, dim3((unsigned)cdiv(R, 4), (unsigned)g.n), dim3(256), 0, (hipStream_t)stream, g);
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_rank1_add_batched_f32(int n, float** out, int64_t ld, const float** a, const float** b, int64_t R, int64_t C,
+                                          const float* gscale, void* stream) {
+  if (n <= 0 || R <= 0 || C <= 0) return PVRL_OK;
+  if (!out || !a || !b || (C % 4) || (ld % 4)) return PVRL_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += SMALL_BATCH_MAX) {
+    Rank1Batch g = {};
+    g.n = n - i0 < SMALL_BATCH_MAX ? n - i0 : SMALL_BATCH_MAX;
+    g.R = (int)R; g.C4 = (int)(C / 4); g.ld = ld; g.gscale = gscale;
+    for (int i = 0; i < g.n; ++i) {
+      if (!out[i0 + i] || !a[i0 + i] || !b[i0 + i]) return PVRL_EINVAL;
+      g.out[i] = out[i0 + i]; g.a[i] = a[i0 + i]; g.b[i] = b[i0 + i];
+    }
+    hipLaunchKernelGGL(rank1_add_batched_kernel, dim3((unsigned)cdiv((long)R * g.C4, 256), (unsigned)g.n), dim3(256), 0, (hipStream_t)stream, g);
+    PVRL_LAUNCH_CHECK();
+  }
+  return PVRL_OK;
+}
+
 extern "C" int pvrl_operand_dtype(void) { return PVRL_OPERAND_CODE; }

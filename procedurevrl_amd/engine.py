@@ -555,7 +555,12 @@ class EncoderEngine(GraphReplay):
             items.append((we, e.w, e.t))
         ops.cast_weights_multi(items)
         for blk, e, ef, ep in ents:
-            e.be = ops.gemv_rows(blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.bias.detach(), out=e.be)
+            if e.be is None or e.be.device != wes[0].device:
+                e.be = torch.empty(self.C, device=wes[0].device, dtype=F32)
+        ops.gemv_rows_batched([blk.temporal_fc.weight.detach() for blk, _, _, _ in ents],
+                              [blk.temporal_attn.proj.bias.detach() for blk, _, _, _ in ents], [e.be for _, e, _, _ in ents],
+                              [0.0] * len(ents))                               # b_e = W_fc b_proj
+        for blk, e, ef, ep in ents:
             e.ver = (ef.ver, ep.ver, blk.temporal_attn.proj.bias._version)
             self._fused_fresh.add(id(blk))
 
@@ -584,12 +589,11 @@ class EncoderEngine(GraphReplay):
             ops.gemm_nt_batched(groups[0.0], L.PVRL_EPI_F32)
         if groups[1.0]:
             ops.gemm_nt_batched(groups[1.0], L.PVRL_EPI_RESID_F32)
-        for blk, dwe, dbe in chain:
-            wf = blk.temporal_fc.weight
-            ef = self._weight(wf)
-            ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
-            gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
-            ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)
+        ops.rank1_add_batched([gs.target(blk.temporal_fc.weight, fused=True)[0] for blk, _, _ in chain], [dbe for _, _, dbe in chain],
+                              [blk.temporal_attn.proj.bias.detach() for blk, _, _ in chain], gscale=gs.inv)
+        tb = [gs.target(blk.temporal_attn.proj.bias, fused=True) for blk, _, _ in chain]
+        ops.gemv_rows_batched([self._weight(blk.temporal_fc.weight).t for blk, _, _ in chain], [dbe for _, _, dbe in chain],
+                              [t for t, _ in tb], [b for _, b in tb], gscale=gs.inv)
 
     def _finish_deferred(self, gs):
         """what the blocks' backward left for the end (no gradient hook): the fused temporal chains and the LayerNorm partial reduces"""

@@ -514,6 +514,39 @@ def gemv_rows(W, x, out=None, beta=0.0, gscale=None):
     return out
 
 
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def gemv_rows_batched(Ws, xs, outs, betas, gscale=None):
+    """out_i = beta_i * out_i + gscale * W_i x_i for equally-shaped W_i [R, C] (all fp32 or all 16-bit), one launch per 16"""
+    W0 = _chk2d(Ws[0])
+    R, C = W0.shape
+    for W, x, o in zip(Ws, xs, outs):
+        assert W.shape == (R, C) and W.dtype == W0.dtype and _ld(W) == _ld(W0) and x.dtype == F32 and x.is_contiguous() and x.numel() == C
+        assert o.dtype == F32 and o.is_contiguous() and o.numel() == R
+    aw, ax, ao = _ptr_array(Ws), _ptr_array(xs), _ptr_array(outs)
+    ab = (ctypes.c_float * len(Ws))(*[float(b) for b in betas])
+    lib().call("pvrl_gemv_rows_batched_f32", len(Ws), ctypes.addressof(aw), 1 if W0.dtype == OP16 else 0, _ld(W0), R, C,
+               ctypes.addressof(ax), ctypes.addressof(ab), ctypes.addressof(ao), _ptr(gscale), _stream())
+    return outs
+
+
+def rank1_add_batched(outs, As, Bs, gscale=None):
+    """out_i[r][c] += gscale * a_i[r] * b_i[c] for equally-shaped fp32 out_i [R, C], one launch per 16"""
+    o0 = _chk2d(outs[0], F32)
+    R, C = o0.shape
+    As = [a.contiguous() for a in As]
+    Bs = [b.contiguous() for b in Bs]
+    for o, a, b in zip(outs, As, Bs):
+        assert o.shape == (R, C) and _ld(o) == _ld(o0) and a.dtype == F32 and b.dtype == F32 and a.numel() == R and b.numel() == C
+    ao, aa, ab = _ptr_array(outs), _ptr_array(As), _ptr_array(Bs)
+    lib().call("pvrl_rank1_add_batched_f32", len(outs), ctypes.addressof(ao), _ld(o0), ctypes.addressof(aa), ctypes.addressof(ab), R, C,
+               _ptr(gscale), _stream())
+    return outs
+
+
 def cast_weights_multi(items):
     """items: list of (w fp32 [R, C] contiguous, out bf16 [R, C], out_t bf16 [C, R] or None) -- one launch for all."""
     from ._lib import CastProblem

@@ -163,6 +163,37 @@ def check_grad_scale_begin():
     return out
 
 
+def check_small_batched():
+    """pvrl_gemv_rows_batched_f32 / pvrl_rank1_add_batched_f32: many problems per launch, bit-equal to the one-problem entry points"""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(31)
+    n, R, C = 19, 768, 768
+    out = []
+    for wdt in (torch.float32, BF):
+        Ws = [(torch.randn(R, C, generator=g) * 0.05).to(dev(), wdt) for _ in range(n)]
+        xs = [torch.randn(C, generator=g).to(dev()) for _ in range(n)]
+        y0 = [torch.randn(R, generator=g).to(dev()) for _ in range(n)]
+        betas = [float(i % 2) for i in range(n)]
+        half = torch.full((1,), 0.5, device=dev())
+        ya = [y.clone() for y in y0]
+        yb = [y.clone() for y in y0]
+        ops.gemv_rows_batched(Ws, xs, ya, betas, gscale=half)
+        for W, x, y, b in zip(Ws, xs, yb, betas):
+            ops.gemv_rows(W, x, out=y, beta=b, gscale=half)
+        out.append((f"gemv_rows_batched == gemv_rows ({wdt})", float(sum((a != b).sum() for a, b in zip(ya, yb))), 0.0))
+    outs = [torch.randn(R, C, generator=g).to(dev()) for _ in range(n)]
+    As = [torch.randn(R, generator=g).to(dev()) for _ in range(n)]
+    Bs = [torch.randn(C, generator=g).to(dev()) for _ in range(n)]
+    oa = [o.clone() for o in outs]
+    ob = [o.clone() for o in outs]
+    ops.rank1_add_batched(oa, As, Bs)
+    for o, a, b in zip(ob, As, Bs):
+        ops.rank1_add(o, a, b)
+    out.append(("rank1_add_batched == rank1_add", float(sum((a != b).sum() for a, b in zip(oa, ob))), 0.0))
+    out.append(("rank1_add_batched vs torch", rel(oa[3], outs[3].cpu() + torch.outer(As[3].cpu(), Bs[3].cpu())), TOL_F32))
+    return out
+
+
 def check_gemm_f32_small():
     from procedurevrl_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -771,5 +802,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_small_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
