@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r5_lndefer.txt; : > $O
+O=gpurun_out/r5_ab_batch.txt; : > $O
 timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py tests/test_two_rank_gloo_gpu.py -m gpu -q -x -k "small_batched or layernorm or block_golden or train_step_small or hip_graph_replay or bit_reproducible or e2e_golden or droppath or two_rank" 2>&1 | grep "passed\|failed\|Error" | tail -5 >> $O
 for i in 1 2 3; do for b in 1 0; do
   echo -n "PVRL_BATCH_FUSED=$b : " >> $O

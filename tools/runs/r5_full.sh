@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: whole `-m gpu` suite, smoke, default bench (the driver's sequence)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r5_suite3.txt; : > $O
+O=gpurun_out/r5_full.txt; : > $O
 timeout 3300 python -X faulthandler -m pytest tests -m gpu -v 2>&1 | grep -v Warning > gpurun_out/r5_suite_v.txt
 grep -n "FAILED\|ERROR" gpurun_out/r5_suite_v.txt | head -20 >> $O
 grep -n -B2 -A12 "Fatal Python\|Segmentation" gpurun_out/r5_suite_v.txt | head -40 >> $O
@@ -20,3 +20,14 @@ print("runner_up", d["roofline"].get("runner_up"))
 for s in d.get("side",[]): print("side", s.get("config","")[:60], s.get("value"), s.get("dtype"), s.get("parity"), s.get("error"))
 PY
 cat $O
+# the two side configurations the default run leaves to --all-sides (configs[3], configs[4]) and the N > 1 machinery on one GPU
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --all-sides 2>/dev/null | grep "^{" | tail -1 > gpurun_out/r5_bench_allsides.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-side --world1-rccl 2>/dev/null | grep "^{" | tail -1 > gpurun_out/r5_bench_world1.json
+python - <<'PY' | tee -a gpurun_out/r5_suite3.txt
+import json
+d=json.loads(open('gpurun_out/r5_bench_allsides.json').read())
+print("allsides headline", d["value"], d["ms_per_step"])
+for s in d.get("side",[]): print("side", s.get("config","")[:60], s.get("value"), s.get("ms_per_step"), s.get("error"))
+w=json.loads(open('gpurun_out/r5_bench_world1.json').read())
+print("world1-rccl", w["value"], w["ms_per_step"])
+PY
