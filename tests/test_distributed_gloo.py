@@ -147,6 +147,19 @@ def _worker(rank, world, port, results):
     for epoch in range(2):
         ds.shuffle_dataset(loader, epoch)
         seen.append([int(i) for _, _, idx, _ in loader for i in idx])
+    # --- the optimiser's "skip this step" flag (GradStore.bad) rides in the reduced tail: raised on ONE rank (a non-finite loss or
+    #     gradient there), every rank sees it after finish() and drops the same step (tools/train_net.py:174 raises on that rank's loss;
+    #     the all-reduced NaN gradients must not be applied by the others)
+    red_b = du.GradReducer(vt, find_unused=False)
+    for p, view in zip(gs.params, gs.views):
+        p.grad = view
+    gs.flat[:gs.end].fill_(1.0)
+    gs.bad.fill_(1.0 if rank == 1 else 0.0)
+    for i in reversed(range(len(vt.blocks))):
+        vt.engine.grad_hook(i)
+    red_b.finish()
+    out["bad_after"] = float(gs.bad)
+    gs.bad.zero_()
     out["seen"] = seen
     out["batch"] = loader.batch_size
     results[rank] = out
@@ -170,6 +183,7 @@ def test_two_rank_gloo():
         assert r["blk_half_used"] == [1.0] and r["blk_others_3"], r
         assert r["cached_syncs"] == 1 and r["cached_none"], r
         assert r["bf16_comm"] == [1.125], r
+        assert r["bad_after"] == 1.0, r["bad_after"]                  # both ranks drop the step that was bad on rank 1
         assert r["batch"] == 2
     for epoch in range(2):      # the two ranks see disjoint videos that together cover the dataset; epochs are shuffled differently
         a, b = results[0]["seen"][epoch], results[1]["seen"][epoch]
