@@ -217,6 +217,9 @@ class GraphReplay:
     def _graph_reset_host_state(self):
         pass
 
+    def _bwd_group_end(self, state):
+        """staged backward: a group of blocks is done -- an engine that defers work of its blocks finishes it here (default: nothing)"""
+
     @staticmethod
     def _saved_copy(saved):
         """backward() consumes its `saved` dict (frees block entries as it goes): replays hand it a shallow copy"""
@@ -294,12 +297,10 @@ class GraphReplay:
         gb["dfeat"].copy_(dfeat)
         for p, v in gb["touched"]:      # before the hooks run: the reducer treats a parameter without .grad as unused
             p.grad = v
-        if not staged:
-            gb["graphs"][0].replay()
-        else:
-            for k, graph in enumerate(gb["graphs"]):
-                graph.replay()
-                self.grad_hook(nb - 1 - k)
+        for graph, blocks in gb["graphs"]:
+            graph.replay()
+            for j in blocks:            # (staged: the blocks this graph finished, last block first)
+                self.grad_hook(j)
         self.saved = None
         self._gkey = None
 
@@ -320,22 +321,29 @@ class GraphReplay:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
                     self._eager_backward(st_in)
-                graphs.append(graph)
+                graphs.append((graph, []))
             else:
-                # one graph per block (the first also holds the final-norm stage, the last the embedding stage); a
-                # capture cannot end with side-stream work in flight, so each stage joins its weight gradients
+                # one graph per GROUP of `hook_group` blocks (the first also holds the final-norm stage, the last the embedding stage):
+                # the hook runs for a group's blocks after its replay.  A capture cannot end with side-stream work in flight, so each
+                # stage joins its weight gradients
+                grp = max(1, int(getattr(self, "hook_group", 1)))
                 state = None
-                for i in range(nb - 1, -1, -1):
+                i = nb - 1
+                while i >= 0:
+                    lo = (i // grp) * grp
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
                         if state is None:
                             state = self._bwd_begin(st_in)
-                        self._bwd_block(state, i)
-                        if i == 0:
+                        for j in range(i, lo - 1, -1):
+                            self._bwd_block(state, j)
+                        self._bwd_group_end(state)
+                        if lo == 0:
                             self._bwd_end(state)
                         else:
                             self.join_side_stream()
-                    graphs.append(graph)
+                    graphs.append((graph, list(range(i, lo - 1, -1))))
+                    i = lo - 1
         except Exception as e:          # never fatal: the eager launch sequence is the same kernels
             err = e
         finally:
@@ -374,6 +382,9 @@ class EncoderEngine(GraphReplay):
         # the 768^3 GEMMs of the fused temporal branch (W_e per block in forward; dW_fc, dW_proj per block in backward) batched into
         # one launch per dozen (ops.gemm_nt_batched): 36 tiles apiece cannot fill 256 CUs (PVRL_BATCH_FUSED=0: one launch each, A/B runs)
         self.batch_fused = os.environ.get("PVRL_BATCH_FUSED", "1") == "1"
+        # with a gradient hook (data parallel): blocks per group -- the hook runs (and the deferred launches go out, batched) once per
+        # group of this many blocks instead of per block: four all-reduce rounds of ~135 MB per backward instead of twelve of 45
+        self.hook_group = max(1, int(os.environ.get("PVRL_HOOK_GROUP", "3")))
         self._fused_fresh = set()
         self._chain = []
         self._ln_defer = []
@@ -864,11 +875,17 @@ class EncoderEngine(GraphReplay):
 
     def _backward(self, dfeat):
         st = self._bwd_begin(dfeat)
-        for i in range(len(self.m.blocks) - 1, -1, -1):
+        nb, grp = len(self.m.blocks), self.hook_group
+        for i in range(nb - 1, -1, -1):
             self._bwd_block(st, i)
-            if self.grad_hook is not None:
-                self.grad_hook(i)   # block i's parameter gradients are final: the reducer may start its all-reduce
+            if self.grad_hook is not None and i % grp == 0:
+                self._bwd_group_end(st)      # the group's deferred chains / reduces: its blocks' parameter gradients are final now,
+                for j in range(min(i + grp, nb) - 1, i - 1, -1):
+                    self.grad_hook(j)        # the reducer may start their all-reduce
         self._bwd_end(st)
+
+    def _bwd_group_end(self, st):
+        self._finish_deferred(st["gs"])
 
     # the three stages of backward(); a stage boundary is where the gradient hook may run (and where a staged HIP-graph
     # capture is cut, see _graph_backward)
@@ -956,8 +973,8 @@ class EncoderEngine(GraphReplay):
             (dw, bw), (dbias, _) = gs.target(lin.weight, fused=True), gs.target(lin.bias, fused=True)
             self._wgrad(dy, xin, dw, dbias, bw, gscale=gs.inv, nonfinite=gs.bad)
 
-        # (no gradient hook: the 7-us reduces of the LayerNorm partials are deferred and done for the whole backward in one launch)
-        defer = self._ln_defer if (self.batch_fused and self.grad_hook is None and not self._staged) else None
+        # (the 7-us reduces of the LayerNorm partials are deferred: one launch for the whole backward, or per group of blocks under a gradient hook)
+        defer = self._ln_defer if self.batch_fused else None
 
         def lnbwd(dh, x, st, ln, dx_in, dx_out, dxs=None, dxs_scale=None, dxsum=None, dxsum_beta=None):
             (dg, bg), (db, _) = gs.target(ln.weight, fused=True), gs.target(ln.bias, fused=True)
@@ -994,8 +1011,8 @@ class EncoderEngine(GraphReplay):
         fe = self._fused_temporal(blk)
         dwe = torch.empty((C, C), device=dev, dtype=F32)
         dbe = torch.empty(C, device=dev, dtype=F32)
-        if self.batch_fused and self.grad_hook is None and not self._staged:   # nobody needs this block's gradients before the end of the backward:
-            self._wgrad(dz, s["o_t"], dwe, dbe, 0.0)           # the chain of all blocks runs batched in _bwd_end
+        if self.batch_fused:                                   # nobody needs this block's gradients before the end of the backward (of its
+            self._wgrad(dz, s["o_t"], dwe, dbe, 0.0)           # group, under a gradient hook): the chains run batched in _finish_deferred
             self._chain.append((blk, dwe, dbe))
         else:
             self._wgrad(dz, s["o_t"], dwe, dbe, 0.0, post=lambda b=blk, w=dwe, v=dbe: self._temporal_chain(b, gs, w, v))
