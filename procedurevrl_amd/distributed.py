@@ -214,6 +214,7 @@ class GradReducer:
         self.host_syncs = 0      # flag read-backs that blocked the host (tests / diagnostics)
         self.resyncs = 0
         vt.engine.grad_hook = self._hook if self.enabled else None
+        vt.engine.grad_hook_group = self._hook_group if self.enabled else None      # (engines that run the hook per group of blocks)
 
     # ---- layout of the flat buffer: computed once per gradient store ----------------------------------------------------
     def _layout(self):
@@ -320,6 +321,25 @@ class GradReducer:
             self._settle(gs, k)
         self._reduce(*spans[i])
         self.done.append(i)
+
+    def _hook_group(self, blocks):
+        """the hook for several blocks at once (engine.EncoderEngine.hook_group): their slices of the flat buffer are adjacent, so ONE
+        collective covers them (a ~135 MB all-reduce per group of three ViT-B blocks instead of three of 45 MB)"""
+        if not self.sync:
+            return
+        gs, blk, spans, _ = self._layout()
+        for i in blocks:
+            for k in blk[i]:
+                self._settle(gs, k)
+        runs = []
+        for a, b in sorted(spans[i] for i in blocks):
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        for a, b in runs:
+            self._reduce(a, b)
+        self.done.extend(blocks)
 
     # ---- "cached": late check of every step's reduced flags -------------------------------------------------------------
     def _resync(self):

@@ -217,6 +217,17 @@ class GraphReplay:
     def _graph_reset_host_state(self):
         pass
 
+    grad_hook_group = None      # optional: the hook for a list of blocks at once (distributed.GradReducer merges their all-reduces)
+
+    def _run_hooks(self, blocks):
+        if not blocks or self.grad_hook is None:
+            return
+        if self.grad_hook_group is not None and len(blocks) > 1:
+            self.grad_hook_group(list(blocks))
+        else:
+            for j in blocks:
+                self.grad_hook(j)
+
     def _bwd_group_end(self, state):
         """staged backward: a group of blocks is done -- an engine that defers work of its blocks finishes it here (default: nothing)"""
 
@@ -299,8 +310,7 @@ class GraphReplay:
             p.grad = v
         for graph, blocks in gb["graphs"]:
             graph.replay()
-            for j in blocks:            # (staged: the blocks this graph finished, last block first)
-                self.grad_hook(j)
+            self._run_hooks(blocks)     # (staged: the blocks this graph finished, last block first)
         self.saved = None
         self._gkey = None
 
@@ -880,8 +890,7 @@ class EncoderEngine(GraphReplay):
             self._bwd_block(st, i)
             if self.grad_hook is not None and i % grp == 0:
                 self._bwd_group_end(st)      # the group's deferred chains / reduces: its blocks' parameter gradients are final now,
-                for j in range(min(i + grp, nb) - 1, i - 1, -1):
-                    self.grad_hook(j)        # the reducer may start their all-reduce
+                self._run_hooks(range(min(i + grp, nb) - 1, i - 1, -1))      # the reducer may start their all-reduce
         self._bwd_end(st)
 
     def _bwd_group_end(self, st):
