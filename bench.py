@@ -449,7 +449,7 @@ def pmc_traffic(kernel):
         pmc_traffic.note = f"profiles/{cands[0]} was taken from other kernel sources (csrc sha {meta.get('csrc_sha16')}, now {csrc_sha16()}): re-profile"
         return None
     pmc_traffic.note = f"profiles/{cands[0]}"
-    epi = {"bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
+    epi = {"op16": 0, "bf16": 0, "gelu": 1, "qgelu": 2, "resid_f32": 3, "f32": 4, "dgelu": 5, "dqgelu": 6}
     if kernel.startswith("gemm_tn"):
         cands = ([k for k in t if k.startswith("gemm_tn") and k.endswith("grouped_kernel")] if "grouped" in kernel else
                  [k for k in t if k.startswith("gemm_tn") and not k.endswith("grouped_kernel")])

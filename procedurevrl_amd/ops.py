@@ -15,7 +15,7 @@ F32 = torch.float32
 
 # When set to a list, gemm launches are bracketed with events on the launch stream (bench.py roofline leg).
 KERNEL_TIMING = None
-_EPI_NAMES = {0: "bf16", 1: "gelu", 2: "qgelu", 3: "resid_f32", 4: "f32", 5: "dgelu", 6: "dqgelu"}
+_EPI_NAMES = {0: "op16", 1: "gelu", 2: "qgelu", 3: "resid_f32", 4: "f32", 5: "dgelu", 6: "dqgelu"}
 
 
 def _timed(name, flops, fn):
