@@ -43,6 +43,9 @@ class FusedOptimizer(torch.optim.Optimizer):
         # the update kernels, which leave weights and state untouched when it is set; and CLEARED by step() itself once the update
         # kernels are queued (pvrl_flag_roll also counts the dropped step in `bad_steps`) -- its life cycle belongs to the step,
         # whatever loop calls it.  No host sync per iteration: a training loop reads `dropped_steps()` where it reads its statistics.
+        # The HOST's per-parameter step counts (`param_steps`, Adam's bias correction) advance for a dropped step too: the host does not
+        # know it was dropped.  The reference raises at that iteration and so does `train_epoch` at its next log point; a loop that chooses
+        # to continue after `dropped_steps()` > 0 runs with a bias correction that is one step ahead per dropped step.
         # `check_grads` (default for the fp16-operand flavour, whose scaled backward can overflow where the loss cannot) additionally
         # scans the gradients of parameters whose producers do not check themselves (GradStore.fused_checked lists the others).
         self.check_grads = os.environ.get("PVRL_CHECK_GRADS", "1" if OPERAND == "f16" else "0") == "1"
