@@ -271,6 +271,42 @@ __global__ __launch_bounds__(256) void cast_weight_multi_kernel(CastMulti g) {
   }
 }
 
+// The same with 64 x 64 tiles and 16-byte loads / 8-byte stores, for matrices whose sides are multiples of 64 (every Linear of the encoder):
+// the 32 x 32 form above reads 4 bytes and writes 2 bytes per thread and instruction and sat at 3.4 TB/s for its 1.45 GB.
+__global__ __launch_bounds__(256) void cast_weight_multi64_kernel(CastMulti g) {
+  __shared__ op_t tile[64][68];
+  int lo = 0, hi = g.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= g.it[mid].first) lo = mid; else hi = mid - 1;
+  }
+  const CastItem w = g.it[lo];
+  const int b = (int)blockIdx.x - w.first;
+  const int c0 = (b % w.tiles_c) * 64, r0 = (b / w.tiles_c) * 64;
+  const int q = threadIdx.x & 15, y = threadIdx.x >> 4;
+  f32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(w.in + (long)(r0 + y + 16 * k) * w.C + c0 + 4 * q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    opx4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (op_t)v[k][e];
+    *reinterpret_cast<opx4*>(w.out + (long)(r0 + y + 16 * k) * w.C + c0 + 4 * q) = o;
+    *reinterpret_cast<opx4*>(&tile[y + 16 * k][4 * q]) = o;
+  }
+  if (!w.out_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = y + 16 * k;
+    opx4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = tile[4 * q + e][c];
+    *reinterpret_cast<opx4*>(w.out_t + (long)(c0 + c) * w.R + r0 + 4 * q) = o;
+  }
+}
+
 // out[g][c] = resid[g][c] + alpha * sum_t scale[g*G + t] * in[g*G + t][c]
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict__ in, long ldi, int groups, int G, int C,
@@ -419,15 +455,23 @@ extern "C" int pvrl_cast_weights_multi_bf16(int n, const pvrl_cast_problem* prob
     CastMulti g = {};
     g.n = n - i0 < CAST_MULTI_MAX ? n - i0 : CAST_MULTI_MAX;
     int blocks = 0;
+    bool all64 = true;      // sides multiples of 64, 16-byte aligned: the 64 x 64-tile kernel
     for (int i = 0; i < g.n; ++i) {
       const pvrl_cast_problem& q = problems[i0 + i];
       if (!q.in || !q.out || q.R <= 0 || q.C <= 0) return PVRL_EINVAL;
+      all64 = all64 && (q.R % 64 == 0) && (q.C % 64 == 0) && ((uintptr_t)q.in % 16 == 0) && ((uintptr_t)q.out % 8 == 0) &&
+              (!q.out_t || (uintptr_t)q.out_t % 8 == 0);
+    }
+    const int ts = all64 ? 64 : 32;
+    for (int i = 0; i < g.n; ++i) {
+      const pvrl_cast_problem& q = problems[i0 + i];
       CastItem& w = g.it[i];
       w.in = q.in; w.out = (op_t*)q.out; w.out_t = (op_t*)q.out_t; w.R = (int)q.R; w.C = (int)q.C;
-      w.first = blocks; w.tiles_c = (int)cdiv(q.C, 32);
-      blocks += w.tiles_c * (int)cdiv(q.R, 32);
+      w.first = blocks; w.tiles_c = (int)cdiv(q.C, ts);
+      blocks += w.tiles_c * (int)cdiv(q.R, ts);
     }
-    hipLaunchKernelGGL(cast_weight_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (all64) hipLaunchKernelGGL(cast_weight_multi64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(cast_weight_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     PVRL_LAUNCH_CHECK();
   }
   return PVRL_OK;
