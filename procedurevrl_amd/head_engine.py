@@ -4,8 +4,9 @@ forward and backward are two HIP graphs instead of ~1,000 eager launches wired t
 
     feat [9b, 768] --head--> x --l2norm--> v [9b, 512] --step logits--> logits [9b, K]
     v --order / diffusion transformer (mask one clip per video, pad a tail, 4 denoise levels of a 4-layer stack)--> inter [4b, 512]
-    inter --l2norm, step logits--> inter_pred [4b, K];  pred = cat(logits[perm], inter_pred), teacher likewise,
-    mse = [x0 repeated per level, inter]
+    inter --l2norm, step logits--> inter_pred [4b, K];  pred = cat(logits[perm], inter_pred), mse = [x0 repeated per level, inter]
+    teacher = cat(teacher[perm], teacher[masked rows] per level): `assemble_teacher`, OUTSIDE the graphs -- nothing above reads the
+    teacher logits, so the frozen text tower that produces them runs on its side stream UNDER this head's forward (vit._teacher_begin)
 
 Round 2 left this part eager: capturing it needed torch.autograd INSIDE a stream capture, which crashes on ROCm 7.x
 (an AccumulateGrad node is bound to the default stream).  Here autograd sees ONE Function (`PretrainHeadFn`): its forward and
@@ -76,7 +77,7 @@ class PretrainHeadEngine:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def _forward(self, feat, teacher_x, dr, save=True):
+    def _forward(self, feat, dr, save=True):
         o, ot = self.o, self.o.order_tfm
         L, C, lv = ot.max_len, ot.hidden_size, ot.tfm_layers
         dev = feat.device
@@ -123,16 +124,22 @@ class PretrainHeadEngine:
         x0_rep = x0.unsqueeze(0).expand(lv, -1, -1).reshape(-1, C)
         inter_n, inter_inv = ops.l2norm_fwd(inter)
         inter_pred = ops.gemm_nt_f32(inter_n, le, alpha=it)
-        masked_teacher = teacher_x.index_select(0, rows)                                     # get_mask_samples, vit.py:360-363
-        inter_teacher = masked_teacher.unsqueeze(0).expand(lv, -1, -1).reshape(-1, teacher_x.shape[1])
         n_keep = b * o.order_recog_batch
-        ri = rand_inds[:n_keep]
+        ri = rand_inds[:n_keep].contiguous()
         pred = torch.cat((logits.index_select(0, ri), inter_pred), dim=0)
-        teacher_out = torch.cat((teacher_x.index_select(0, ri), inter_teacher), dim=0)
         if save:
             self.saved = dict(feat=feat, v=v, vinv=vinv, rows=rows, pad_mask=pad_mask, is_mask=is_mask, ri=ri, n_keep=n_keep,
                               inter_n=inter_n, inter_inv=inter_inv, E=E, h1=h1, g1=g1, levels=levels, eng=eng, b=b, n=n)
-        return pred, teacher_out, x0_rep, inter
+        return pred, x0_rep, inter, rows, ri
+
+    def assemble_teacher(self, teacher_x, rows, ri):
+        """the teacher half of the output assembly (vit.py:336-350): rows [0, n_keep) are teacher[perm], then the masked clips'
+        teacher rows (get_mask_samples, vit.py:360-363) once per denoise level.  Four launches outside the head's graphs: the first
+        point of the step that reads the text tower's result."""
+        lv = self.o.order_tfm.tfm_layers
+        masked_teacher = teacher_x.index_select(0, rows)
+        inter_teacher = masked_teacher.unsqueeze(0).expand(lv, -1, -1).reshape(-1, teacher_x.shape[1])
+        return torch.cat((teacher_x.index_select(0, ri), inter_teacher), dim=0)
 
     # ------------------------------------------------------------------ backward
     @torch.no_grad()
@@ -224,31 +231,31 @@ class PretrainHeadEngine:
                     kpm=None if kpm is None else kpm.repeat(len(levels), 1))
 
     # ------------------------------------------------------------------ HIP graphs
-    def _key(self, feat, teacher_x):
+    def _key(self, feat):
         o = self.o
-        return (tuple(feat.shape), tuple(teacher_x.shape), feat.device.index, o.head.weight.data_ptr(),
+        return (tuple(feat.shape), feat.device.index, o.head.weight.data_ptr(),
                 o.order_tfm.time_mlp[1].weight.data_ptr(), o.grad_store().flat.data_ptr(), o._labels(feat.device)[0].data_ptr())
 
-    def forward(self, feat, teacher_x, dr, save=True):
+    def forward(self, feat, dr, save=True):
+        """-> (pred, mse target, mse prediction, rows of the masked clips, kept permutation) -- the last two for `assemble_teacher`"""
         if not (self.use_graphs and feat.is_cuda and save):
             self._gkey = None
-            return self._forward(feat, teacher_x, dr, save)
-        key = self._key(feat, teacher_x)
+            return self._forward(feat, dr, save)
+        key = self._key(feat)
         g = self._graphs.get(key)
         if g is None:
             k = self._gseen.get(key, 0)
             self._gseen[key] = k + 1
             if k < self.GRAPH_WARMUP or len(self._graphs) >= self.GRAPH_MAX_KEYS:
                 self._gkey = None
-                return self._forward(feat, teacher_x, dr, save)
+                return self._forward(feat, dr, save)
             try:
-                g = self._capture_forward(key, feat, teacher_x, dr)
+                g = self._capture_forward(key, feat, dr)
             except Exception as e:          # never fatal: the eager launch sequence is the same kernels
                 self._failed("forward", e)
                 self._gkey = None
-                return self._forward(feat, teacher_x, dr, save)
+                return self._forward(feat, dr, save)
         g["feat"].copy_(feat)
-        g["teacher"].copy_(teacher_x)
         for k in ("mask_inds", "pad_start", "noises", "rand_inds"):
             g["dr"][k].copy_(dr[k])
         g["fwd"].replay()
@@ -266,20 +273,20 @@ class PretrainHeadEngine:
         self._graphs = {}
         torch.cuda.synchronize()
 
-    def _capture_forward(self, key, feat, teacher_x, dr):
+    def _capture_forward(self, key, feat, dr):
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        sf, st = feat.clone(), teacher_x.clone()
+        sf = feat.clone()
         sd = {k: v.clone() for k, v in dr.items()}
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self._cap, self._cap_seen = "fwd", set()
         try:
             with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-                out = self._forward(sf, st, sd, True)
+                out = self._forward(sf, sd, True)
         finally:
             self._cap = None
-        g = dict(fwd=graph, feat=sf, teacher=st, dr=sd, out=out, saved=self.saved, bwd=None)
+        g = dict(fwd=graph, feat=sf, dr=sd, out=out, saved=self.saved, bwd=None)
         self._graphs[key] = g
         return g
 
@@ -291,7 +298,7 @@ class PretrainHeadEngine:
         params = self.params()
         if any(p.grad is not None for p in params):     # accumulation into existing gradients (beta = 1 launches): eager
             return self._backward(d_pred, d_x0rep, d_inter)
-        lvC = g["out"][2].shape
+        lvC = g["out"][1].shape
         z = lambda t: torch.zeros(lvC, device=d_pred.device, dtype=F32) if t is None else t
         d_x0rep, d_inter = z(d_x0rep), z(d_inter)
         if g["bwd"] is None:
@@ -330,18 +337,19 @@ class PretrainHeadEngine:
 
 
 class PretrainHeadFn(torch.autograd.Function):
-    """(feat, teacher logits, draws) -> (pred, teacher, mse target, mse prediction): vit.py:298-352 as ONE autograd node"""
+    """(feat, draws) -> (pred, mse target, mse prediction, masked rows, kept permutation): vit.py:298-352 as ONE autograd node (the
+    teacher half of the output assembly follows outside, PretrainHeadEngine.assemble_teacher)"""
 
     @staticmethod
-    def forward(ctx, anchor, feat, teacher_x, owner, dr):
+    def forward(ctx, anchor, feat, owner, dr):
         need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        pred, teacher_out, x0_rep, inter = owner.head_engine.forward(feat.contiguous(), teacher_x.contiguous(), dr, save=need)
+        pred, x0_rep, inter, rows, ri = owner.head_engine.forward(feat.contiguous(), dr, save=need)
         ctx.owner = owner
-        ctx.mark_non_differentiable(teacher_out)
-        return pred, teacher_out, x0_rep, inter
+        ctx.mark_non_differentiable(rows, ri)
+        return pred, x0_rep, inter, rows, ri
 
     @staticmethod
-    def backward(ctx, d_pred, _d_teacher, d_x0rep, d_inter):
+    def backward(ctx, d_pred, d_x0rep, d_inter, _d_rows, _d_ri):
         eng = ctx.owner.head_engine
         if d_pred is None:
             sv = eng.saved
@@ -349,4 +357,4 @@ class PretrainHeadFn(torch.autograd.Function):
                                  device=sv["v"].device, dtype=F32)
         d_feat = eng.backward(d_pred.contiguous(), None if d_x0rep is None else d_x0rep.contiguous(),
                               None if d_inter is None else d_inter.contiguous())
-        return None, d_feat, None, None, None
+        return None, d_feat, None, None

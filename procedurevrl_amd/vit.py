@@ -290,12 +290,20 @@ class VisionTransformer(nn.Module):
 
     _text_side = None      # HIP stream of the frozen text tower
 
+    @staticmethod
+    def _text_overlap():
+        v = os.environ.get("PVRL_TEXT_OVERLAP", "head")
+        return "head" if v == "1" else v
+
     def _teacher_begin(self, text, dev):
-        """The frozen CLIP-text teacher (vit.py:425-433) depends on the narrations only, not on the encoder: its ~110 small launches
-        (one HIP-graph replay) are issued on a side stream BEFORE the encoder forward and run under it; the main stream joins
-        where the teacher logits are consumed (`_teacher_end`).  Serially they sat between the encoder and the head on one queue
-        (~1 ms per step with the GPU nearly idle).  PVRL_TEXT_OVERLAP=0: A/B runs."""
-        if dev.type != "cuda" or os.environ.get("PVRL_TEXT_OVERLAP", "1") != "1":
+        """The frozen CLIP-text teacher (vit.py:425-433) depends on the narrations only: its ~110 small launches (one HIP-graph replay)
+        are issued on a side stream and the main stream joins where the teacher logits are first read (the output assembly behind the
+        head, `_pretrain_forward`).  Serially they sat between the encoder and the head on one queue (~1 ms per step with the GPU
+        nearly idle).  Where the side stream starts (PVRL_TEXT_OVERLAP): "head" (default) = behind the encoder forward, so the tower
+        runs under the pre-training head's ~300 launch-sized kernels, which leave the chip almost empty; "encoder" = before the
+        encoder forward (round 5's first form: the tower then shares the chip with the persistent GEMMs for 4.9 ms and stretches
+        them by ~14 %, profiles/r5_timeline_full.txt); "0": no side stream."""
+        if dev.type != "cuda" or self._text_overlap() == "0":
             return None
         if self._text_side is None or self._text_side.device != dev:
             self._text_side = torch.cuda.Stream(device=dev)
@@ -306,20 +314,26 @@ class VisionTransformer(nn.Module):
         return teacher_x, side.record_event()
 
     def _pretrain_forward(self, feat, text, rng, batch_size, teacher=None):
-        if teacher is not None:
-            teacher_x, ev = teacher
-            torch.cuda.current_stream().wait_event(ev)
-        else:
-            teacher_x = self.get_pseudo_labels(feat.device, text)            # frozen text tower: its own HIP graph
-        if os.environ.get("PVRL_HEAD_ENGINE", "1") != "1":
-            return self._pretrain_head(feat, teacher_x, rng, batch_size)     # the same head wired through torch.autograd (eager)
+        engine = os.environ.get("PVRL_HEAD_ENGINE", "1") == "1"
+        if teacher is None and feat.is_cuda and self._text_overlap() == "head" and engine:
+            teacher = self._teacher_begin(text, feat.device)                 # side stream, from here: under the head's forward
+
+        def teacher_logits():
+            if teacher is not None:
+                teacher_x, ev = teacher
+                torch.cuda.current_stream().wait_event(ev)
+                return teacher_x
+            return self.get_pseudo_labels(feat.device, text)                 # frozen text tower: its own HIP graph
+        if not engine:
+            return self._pretrain_head(feat, teacher_logits(), rng, batch_size)     # the same head wired through torch.autograd (eager)
         # One autograd node with a hand-written backward (head_engine.PretrainHeadEngine): its ~1,000 small launches are
         # replayed from two HIP graphs.  (Capturing the autograd-wired head crashes hipStreamEndCapture on ROCm 7.x: an
         # AccumulateGrad node is bound to the default stream -- round 2)
         if self.head_engine is None:
             self.head_engine = PretrainHeadEngine(self)
         dr = self.head_engine.draws(rng, batch_size, feat.shape[0], feat.device)
-        pred, teacher_out, x0_rep, inter = PretrainHeadFn.apply(self.anchor(), feat, teacher_x, self, dr)
+        pred, x0_rep, inter, rows, ri = PretrainHeadFn.apply(self.anchor(), feat, self, dr)
+        teacher_out = self.head_engine.assemble_teacher(teacher_logits(), rows, ri)
         return pred, teacher_out, [x0_rep, inter]
 
     def forward(self, x, rng=None):
@@ -339,7 +353,9 @@ class VisionTransformer(nn.Module):
         if pretrain and (not self.cfg.DEV.MATCH_LANG_EMB or (hasattr(self, "num_seg") and self.num_seg > 0)):
             raise NotImplementedError("pre-training forward (vit.py:325-352) is built for DEV.MATCH_LANG_EMB True and "
                                       "MODEL.NUM_SEG 0, the setting of every shipped pre-training config")
-        teacher = self._teacher_begin(text, x.device) if pretrain and isinstance(x, torch.Tensor) else None
+        teacher = None
+        if pretrain and isinstance(x, torch.Tensor) and (self._text_overlap() == "encoder" or os.environ.get("PVRL_HEAD_ENGINE", "1") != "1"):
+            teacher = self._teacher_begin(text, x.device)
         x = feat = self.forward_features(x.contiguous(), droppath=(rng or {}).get("droppath"))
         dev = x.device
         if pretrain:
