@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "gemm_nt_core.h"
 #include "gemm_nt8_core.h"
+#include "gemm_nt_skinny.h"
 
 namespace {
 
@@ -176,9 +177,20 @@ int nt_forced_tile() {
   return t;
 }
 
+// PVRL_NT_SKINNY=0 sends the few-row problems (M <= 192: the pre-training head's stack) back to the 128 x 128 tile (A/B runs; read once)
+int nt_skinny_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_NT_SKINNY");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
+  }
+  return on;
+}
+
 template <int EPI>
 int launch_nt(const GemmNT& p, hipStream_t s) {
   constexpr bool two_out = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
+  if (nt_skinny_ok(p) && nt_forced_tile() == 0 && nt_skinny_enabled()) return launch_nt_skinny<EPI>(p, s);
   switch (nt_forced_tile()) {
     case 22: return launch_tile<EPI, 2, 2>(p, s);
     case 42: return launch_tile<EPI, 4, 2>(p, s);

@@ -438,13 +438,18 @@ class EncoderEngine(GraphReplay):
         """Bring the bf16 operand copies of every encoder weight up to date in ONE launch (pvrl_cast_weights_multi_bf16)
         instead of one 6-us launch per matrix on first use; afterwards _weight() finds every version current."""
         m = self.m
-        todo = []
         plist = [(m.patch_embed.proj.weight, False)]
         for blk in m.blocks:
             plist += [(blk.temporal_attn.qkv.weight, True), (blk.temporal_attn.proj.weight, True),
                       (blk.temporal_fc.weight, True), (blk.attn.qkv.weight, True), (blk.attn.proj.weight, True),
                       (blk.mlp.fc1.weight, True), (blk.mlp.fc2.weight, True)]
-        epoch = getattr(m, "weights_epoch", 0)
+        self.refresh_params(plist, force=self._capturing == "fwd")
+
+    def refresh_params(self, plist, force=False):
+        """operand copies of the (parameter, transposed copy wanted) pairs of `plist` in ONE launch; `force`: re-cast the current ones
+        as well (inside a forward capture: a replay must refresh the copies after an optimiser step)"""
+        todo = []
+        epoch = getattr(self.m, "weights_epoch", 0)
         for p, need_t in plist:
             e = self._w.get(id(p))
             if e is None:
@@ -452,7 +457,7 @@ class EncoderEngine(GraphReplay):
                 self._w[id(p)] = e
             ver = (p._version, epoch if p.requires_grad else 0, p.data_ptr())
             fresh = e.ver == ver and e.w is not None and e.w.device == p.device and (e.t is not None or not need_t)
-            if fresh and self._capturing != "fwd":
+            if fresh and not force:
                 continue
             w2 = p.detach().reshape(p.shape[0], -1)
             if not w2.is_contiguous():

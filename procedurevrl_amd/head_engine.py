@@ -108,19 +108,24 @@ class PretrainHeadEngine:
         g1 = ops.gelu_f32(h1)
         tm = ops.gemm_nt_f32(g1, m3.weight.detach().contiguous(), m3.bias.detach())           # [levels, C]
         eng = StackEngine(ot.temporalModelling.resblocks, self._wc, o.grad_target, heads=ot.tfm_heads, grad_store=o.grad_store)
-        inter, levels = [], []
+        self._refresh_stack_weights()
+        # the levels' saved activations go straight into level-major buffers: the batched backward reads them as one row-wise
+        # concatenation without the ~45 torch.cat launches that used to build it; the levels' outputs likewise (`inter`)
+        bufs = eng.level_buffers(lv, b, L, C, dev) if save else None
+        inter = torch.empty((lv, b, C), device=dev, dtype=F32)
         denoised = None
         for i in range(lv):
             t_index = ot.total_levels - 1 - i
             src = x0 if i == 0 else denoised
             noisy = float(ot.sqrt_alphas_cumprod[t_index]) * src + float(ot.sqrt_one_minus_alphas_cumprod[t_index]) * noises[i]
             cur = torch.where(is_mask, noisy[:, None, :], feats)
-            cur = cur + type_emb + temb + tm[i][None, None, :]
-            out, sv = eng.forward(cur.reshape(b * L, C).contiguous(), b, L, causal=False, kpm=kpm, save=save)
-            denoised = out.index_select(0, rows)
-            inter.append(denoised)
-            levels.append(sv)
-        inter = torch.cat(inter)                                                             # [levels * b, C]
+            xin = bufs[0]["x0"][i] if save else torch.empty((b * L, C), device=dev, dtype=F32)
+            torch.add(cur + type_emb + temb, tm[i][None, None, :], out=xin.view(b, L, C))
+            out, _ = eng.forward(xin, b, L, causal=False, kpm=kpm, save=save, into=(bufs, i) if save else None)
+            denoised = inter[i]
+            torch.index_select(out, 0, rows, out=denoised)
+        levels = (bufs, lv, b, L, kpm)
+        inter = inter.view(lv * b, C)                                                        # [levels * b, C]
         x0_rep = x0.unsqueeze(0).expand(lv, -1, -1).reshape(-1, C)
         inter_n, inter_inv = ops.l2norm_fwd(inter)
         inter_pred = ops.gemm_nt_f32(inter_n, le, alpha=it)
@@ -170,7 +175,8 @@ class PretrainHeadEngine:
         d_out = torch.zeros((lv, b * L, C), device=dev, dtype=F32)
         d_out.index_copy_(1, sv["rows"], d_inter.view(lv, b, C))
         d_out = d_out.view(lv * b * L, C)
-        allsv = self._merge_levels(sv["levels"])
+        bufs, lvn, nb, Ln, kpm = sv["levels"]
+        allsv = eng.merged(bufs, lvn, nb, Ln, False, kpm)
         if SCALED_GRADS:                         # fp16-operand flavour: the stack's backward runs in S-scaled units
             d_cur = eng.backward(gs.begin_scaled(d_out), allsv)
             d_cur = d_cur * gs.end_scaled()
@@ -211,24 +217,17 @@ class PretrainHeadEngine:
         self.saved = None
         return d_feat
 
-    @staticmethod
-    def _merge_levels(levels):
-        """saved activations of the denoise levels (StackEngine.forward, one dict per level) -> one dict over levels x b sequences"""
-        first = levels[0]
-        cat = lambda ts: torch.cat(ts, 0)
-        blocks = []
-        for j in range(len(first["blocks"])):
-            per = [lvl["blocks"][j] for lvl in levels]
-            blk = {}
-            for k, v in per[0].items():
-                if isinstance(v, tuple):
-                    blk[k] = tuple(cat([p[k][e] for p in per]) for e in range(len(v)))
-                else:
-                    blk[k] = cat([p[k] for p in per])
-            blocks.append(blk)
-        kpm = first["kpm"]
-        return dict(blocks=blocks, nseq=first["nseq"] * len(levels), S=first["S"], causal=first["causal"],
-                    kpm=None if kpm is None else kpm.repeat(len(levels), 1))
+    def _refresh_stack_weights(self):
+        """16-bit operand copies of the stack's 16 weight matrices in ONE launch (engine.refresh_params) instead of one per matrix on
+        first use; inside the forward capture every copy is re-cast (a replay must refresh them after an optimiser step)"""
+        ot = self.o.order_tfm
+        plist = []
+        for blk in ot.temporalModelling.resblocks:
+            plist += [(blk.attn.in_proj_weight, True), (blk.attn.out_proj.weight, True), (blk.mlp.c_fc.weight, True),
+                      (blk.mlp.c_proj.weight, True)]
+        self.o.engine.refresh_params(plist, force=self._cap == "fwd")
+        if self._cap == "fwd":
+            self._cap_seen.update(id(p) for p, _ in plist)
 
     # ------------------------------------------------------------------ HIP graphs
     def _key(self, feat):
@@ -260,7 +259,6 @@ class PretrainHeadEngine:
             g["dr"][k].copy_(dr[k])
         g["fwd"].replay()
         self.saved = dict(g["saved"])
-        self.saved["levels"] = list(g["saved"]["levels"])
         self._gkey = key
         return tuple(t.clone() for t in g["out"])       # the graph's own output buffers are overwritten by the next replay
 
@@ -323,7 +321,6 @@ class PretrainHeadEngine:
                 for p in params:
                     p.grad = None
                 self.saved = dict(g["saved"])
-                self.saved["levels"] = list(g["saved"]["levels"])
                 return self._backward(d_pred, d_x0rep, d_inter)
         gb = g["bwd"]
         gb["d_pred"].copy_(d_pred)

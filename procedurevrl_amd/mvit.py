@@ -221,6 +221,7 @@ class MViTEngine(GraphReplay):
     installed the backward is one graph per block, the hook running between them)."""
 
     _weight = EncoderEngine._weight      # un-padded bf16 copies for the width-512 stacks (order transformer, text tower)
+    refresh_params = EncoderEngine.refresh_params
 
     def __init__(self, owner, enc):
         self.m = owner                   # the wrapper (weights_epoch, grad_target)

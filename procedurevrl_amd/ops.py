@@ -268,14 +268,19 @@ def gemm_tn_grouped(problems, ws_tag="tn_group"):
 # ----------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True, stats=None):
+    """`stats` (optional): (mean, rstd) fp32 [M] tensors to write the row statistics into"""
     L = lib()
     _chk2d(x, F32)
     M, C = x.shape
     if out is None:
         out = torch.empty((M, C), device=x.device, dtype=out_dtype)
-    mean = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
-    rstd = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+    if stats is not None:
+        mean, rstd = stats
+        assert mean.dtype == F32 and rstd.dtype == F32 and mean.is_contiguous() and rstd.is_contiguous() and mean.numel() == M == rstd.numel()
+    else:
+        mean = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+        rstd = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
     L.call("pvrl_layernorm_fwd", _ptr(x), _ld(x), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ld(out),
            1 if out.dtype == F32 else 0, _ptr(mean), _ptr(rstd), M, C, _stream())
     return out, mean, rstd

@@ -36,26 +36,59 @@ class StackEngine:
         self._gs = grad_store
         self.H = heads
 
-    def forward(self, x, nseq, S, causal=False, kpm=None, save=True):
-        """x fp32 [nseq*S, W] (batch-first rows).  Returns (y fp32 [nseq*S, W], saved)."""
+    def level_buffers(self, levels, nseq, S, Wd, dev):
+        """Saved-activation storage of `levels` independent passes over the SAME stack (the denoise levels of the pre-training head,
+        tfm_model.py:165-204), level-major: pass i of forward(..., into=(bufs, i)) writes slice i, and the passes' saved tensors are
+        then ONE row-wise concatenation without a copy (`merged`) -- what the batched backward over levels x nseq sequences reads."""
+        rows = nseq * S
+        e = lambda *shape, dtype=OP16: torch.empty((levels,) + shape, device=dev, dtype=dtype)
+        return [dict(x0=e(rows, Wd, dtype=F32), h1=e(rows, Wd), st1=(e(rows, dtype=F32), e(rows, dtype=F32)), qkv=e(rows, 3 * Wd),
+                     o=e(rows, Wd), lse=e(nseq, self.H, S, dtype=F32), x1=e(rows, Wd, dtype=F32), h2=e(rows, Wd),
+                     st2=(e(rows, dtype=F32), e(rows, dtype=F32)), u=e(rows, 4 * Wd), g=e(rows, 4 * Wd))
+                for _ in self.blocks]
+
+    @staticmethod
+    def merged(bufs, levels, nseq, S, causal, kpm):
+        """the level buffers as the `saved` of one pass over levels x nseq sequences (views: flatten(0, 1) of contiguous tensors)"""
+        fl = lambda t: t.flatten(0, 1)
+        blocks = [{k: (tuple(fl(t) for t in v) if isinstance(v, tuple) else fl(v)) for k, v in b.items()} for b in bufs]
+        return dict(blocks=blocks, nseq=nseq * levels, S=S, causal=causal, kpm=None if kpm is None else kpm.repeat(levels, 1))
+
+    def forward(self, x, nseq, S, causal=False, kpm=None, save=True, into=None):
+        """x fp32 [nseq*S, W] (batch-first rows).  Returns (y fp32 [nseq*S, W], saved).
+        `into` = (level_buffers(...), i): the saved activations are written into slice i of the level buffers (x must BE
+        bufs[0]["x0"][i]); `saved` is then None -- use `merged`."""
         L = lib()
         Wd = x.shape[1]
         scale = (Wd // self.H) ** -0.5
         saved = []
         P = lambda t: t.detach()
-        for blk in self.blocks:
-            h1, m1, r1 = ops.layernorm_fwd(x, P(blk.ln_1.weight), P(blk.ln_1.bias), LN_EPS)
-            qkv = ops.gemm_nt(h1, self._weight(blk.attn.in_proj_weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.in_proj_bias))
-            o, _, lse = ops.attn_fwd(qkv, nseq, S, self.H, scale, mode=0, causal=causal, kpm=kpm)
+        nb = len(self.blocks)
+        for j, blk in enumerate(self.blocks):
+            if into is not None:
+                bufs, i = into
+                b = {k: (tuple(t[i] for t in v) if isinstance(v, tuple) else v[i]) for k, v in bufs[j].items()}
+                assert j > 0 or x.data_ptr() == b["x0"].data_ptr()
+                nxt = bufs[j + 1]["x0"][i] if j + 1 < nb else None
+            else:
+                b = dict(h1=None, st1=None, qkv=None, o=None, lse=None, x1=None, h2=None, st2=None, u=None, g=None)
+                nxt = None
+            h1, m1, r1 = ops.layernorm_fwd(x, P(blk.ln_1.weight), P(blk.ln_1.bias), LN_EPS, out=b["h1"], stats=b["st1"])
+            qkv = ops.gemm_nt(h1, self._weight(blk.attn.in_proj_weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.in_proj_bias),
+                              out0=b["qkv"])
+            o, _, lse = ops.attn_fwd(qkv, nseq, S, self.H, scale, mode=0, causal=causal, kpm=kpm, o=b["o"], lse=b["lse"])
             x1 = ops.gemm_nt(o, self._weight(blk.attn.out_proj.weight).w, L.PVRL_EPI_RESID_F32,
-                             bias=P(blk.attn.out_proj.bias), aux=x)
-            h2, m2, r2 = ops.layernorm_fwd(x1, P(blk.ln_2.weight), P(blk.ln_2.bias), LN_EPS)
-            u, g = ops.gemm_nt(h2, self._weight(blk.mlp.c_fc.weight).w, L.PVRL_EPI_QGELU, bias=P(blk.mlp.c_fc.bias))
+                             bias=P(blk.attn.out_proj.bias), aux=x, out0=b["x1"])
+            h2, m2, r2 = ops.layernorm_fwd(x1, P(blk.ln_2.weight), P(blk.ln_2.bias), LN_EPS, out=b["h2"], stats=b["st2"])
+            u, g = ops.gemm_nt(h2, self._weight(blk.mlp.c_fc.weight).w, L.PVRL_EPI_QGELU, bias=P(blk.mlp.c_fc.bias),
+                               out0=b["u"], out1=b["g"])
             x2 = ops.gemm_nt(g, self._weight(blk.mlp.c_proj.weight).w, L.PVRL_EPI_RESID_F32,
-                             bias=P(blk.mlp.c_proj.bias), aux=x1)
-            if save:
+                             bias=P(blk.mlp.c_proj.bias), aux=x1, out0=nxt)
+            if save and into is None:
                 saved.append(dict(x0=x, h1=h1, st1=(m1, r1), qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=(m2, r2), u=u, g=g))
             x = x2
+        if into is not None:
+            return x, None
         return x, dict(blocks=saved, nseq=nseq, S=S, causal=causal, kpm=kpm)
 
     def backward(self, dy, saved):
@@ -70,9 +103,19 @@ class StackEngine:
         tgt = self._target if gs is None else (lambda p: gs.target(p, fused=True))
         gsc, bad = (gs.inv, gs.bad) if gs is not None else (None, None)
 
+        # weight gradients: collected and issued as grouped launches of up to TN_GROUP_MAX problems (a four-layer stack: 16 problems
+        # = two launches + two reduces instead of 16 + 16; ops.gemm_tn_grouped falls back to single launches for shapes off the
+        # 256-multiples)
+        wq = []
+
         def wgrad(d, xin, w, b):
             (dw, bw), (db, _) = tgt(w), tgt(b)
-            ops.gemm_tn(d, xin, dw, db, beta=bw, gscale=gsc, nonfinite=bad)
+            wq.append((d, xin, dw, db, bw, gsc, bad))
+
+        def flush():
+            for a in range(0, len(wq), ops.TN_GROUP_MAX):
+                ops.gemm_tn_grouped(wq[a:a + ops.TN_GROUP_MAX], ws_tag="tn_group_stack")
+            del wq[:]
 
         def lnbwd(dh, x, st, ln):
             (dg, bg), (db, _) = tgt(ln.weight), tgt(ln.bias)
@@ -94,4 +137,7 @@ class StackEngine:
             wgrad(dqkv, s["h1"], blk.attn.in_proj_weight, blk.attn.in_proj_bias)
             dh = ops.gemm_nt(dqkv, self._weight(blk.attn.in_proj_weight).t, L.PVRL_EPI_BF16)
             lnbwd(dh, s["x0"], s["st1"], blk.ln_1)
+            if len(wq) >= ops.TN_GROUP_MAX:
+                flush()
+        flush()
         return dx

@@ -45,8 +45,10 @@ def check_gemm_nt():
     out = []
     g = torch.Generator().manual_seed(1)
     # the last three: the 128 x 384 / 128 x 320 tiles of MViTv2-S's N = 384 / 1152 / 640 layers (M >= 4096), ragged last tile
-    for (M, N, K) in [(300, 128, 64), (1000, 768, 768), (257, 2304, 768), (130, 768, 3072), (100100, 384, 128), (4230, 768, 128),
-                      (4500, 640, 256)]:
+    # (M <= 192 with K % 256 == 0 -- (130, 768, 3072) and the three after it, the order / diffusion stack's shapes -- run the few-row kernel
+    # of csrc/gemm_nt_skinny.h: ragged last 16-row tile, one to three 48-row passes)
+    for (M, N, K) in [(300, 128, 64), (1000, 768, 768), (257, 2304, 768), (130, 768, 3072), (36, 512, 2048), (144, 1536, 512),
+                      (37, 2048, 512), (100100, 384, 128), (4230, 768, 128), (4500, 640, 256)]:
         A = torch.randn(M, K, generator=g)
         W = torch.randn(N, K, generator=g) * 0.05
         bias = torch.randn(N, generator=g)
