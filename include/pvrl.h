@@ -44,7 +44,9 @@ int pvrl_operand_dtype(void);
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.
  * Replaces nn.Linear forward (vit.py:54-60,75-92,133; tfm_model.py:35-41) and, with the
  * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M.  bias2 (fp32 [N] or null,
- * PVRL_EPI_RESID_F32 only) is added after the row scale: x + rs * (o W_e^T + b_e) + b_fc of the fused temporal branch. */
+ * PVRL_EPI_RESID_F32 only) is added after the row scale: x + rs * (o W_e^T + b_e) + b_fc of the fused temporal branch.
+ * M <= 192 with K % 256 == 0 (the order / diffusion stack's 36- and 144-row products, tfm_model.py:129-204) runs a few-row kernel whose
+ * workgroups split K over their waves (csrc/gemm_nt_skinny.h): same arithmetic up to the order of the fp32 sums over k. */
 int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
                       int epilogue, const float* bias, const float* rowscale, const void* aux, int64_t aux_ld,
                       int64_t aux_rowmod, void* out0, int64_t ld0, void* out1, int64_t ld1, const float* bias2,
