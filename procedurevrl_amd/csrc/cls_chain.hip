@@ -30,6 +30,7 @@ struct ClsLin {
   float* out; long ldo;
   op_t* o16a; op_t* o16b; long ld16;  // GELU epilogue: 16-bit copies of the pre-activation / the activation (or null)
   float* part;               // ksplit > 1: [ksplit][M][N] partial products of the K slices (cls_epilogue_kernel sums them in slice order)
+  float alpha;               // multiplies the product (1 for the cls chain; 1 / temperature for the step logits)
   int M, N, K, ksplit;
 };
 
@@ -39,6 +40,7 @@ constexpr int CL_MT = 3;      // at most this many 16-row tiles of X per pass: 4
 // chunk's loads are in flight before its first MFMA)
 __device__ __forceinline__ void cls_store(const ClsLin& p, int epi, int m, int n, float s) {
   const float b = p.bias ? p.bias[n] : 0.f;
+  s *= p.alpha;
   if (epi == 0) {
     float y = (p.rowscale ? p.rowscale[m] * s : s) + (p.biasscale ? p.biasscale[m] * b : b);
     if (p.aux) y += p.aux[(long)m * p.ld_aux + n];
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NW * 64) void cls_linear_kernel(ClsLin p) {
   const int mt_n = min(CL_MT, (p.M - m0 + 15) >> 4);
   const int kslice = p.K / p.ksplit;
   const int kw = kslice / NW, kbeg = blockIdx.z * kslice + wave * kw;
-  const float* wrow = p.W + (long)(n0 + r) * p.ldw + kbeg + q * 4;
+  const float* wrow = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + kbeg + q * 4;      // (N need not be a multiple of 16: columns >= N are never stored)
   const float* xrow[CL_MT];
 #pragma unroll
   for (int t = 0; t < CL_MT; ++t) xrow[t] = p.X + (long)min(m0 + t * 16 + r, p.M - 1) * p.ldx + kbeg + q * 4;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void cls_linear_kernel(ClsLin p) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += part[w][t][i][l];
     const int m = m0 + t * 16 + 4 * (l >> 4) + i, n = n0 + (l & 15);
-    if (m >= p.M) continue;
+    if (m >= p.M || n >= p.N) continue;
     if (p.ksplit > 1) p.part[((long)blockIdx.z * p.M + m) * p.N + n] = s;
     else cls_store(p, EPI, m, n, s);
   }
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void cls_epilogue_kernel(ClsLin p, int epi) {
 
 template <int NW, int KU, int MT>
 int launch_cls_mt(const ClsLin& p, int epi, hipStream_t s) {
-  dim3 grid((unsigned)(p.N / 16), (unsigned)cdiv(p.M, 16 * MT), (unsigned)p.ksplit);
+  dim3 grid((unsigned)cdiv(p.N, 16), (unsigned)cdiv(p.M, 16 * MT), (unsigned)p.ksplit);
   if (epi == 0) hipLaunchKernelGGL((cls_linear_kernel<NW, 0, KU, MT>), grid, dim3(NW * 64), 0, s, p);
   else hipLaunchKernelGGL((cls_linear_kernel<NW, 1, KU, MT>), grid, dim3(NW * 64), 0, s, p);
   PVRL_LAUNCH_CHECK();
@@ -167,10 +169,23 @@ extern "C" int pvrl_cls_linear_f32(const float* X, int64_t ldx, const float* W, 
   p.X = X; p.ldx = ldx; p.W = W; p.ldw = ldw; p.bias = bias; p.rowscale = rowscale; p.biasscale = biasscale;
   p.aux = aux; p.ld_aux = ld_aux; p.out = out; p.ldo = ldo;
   p.o16a = (op_t*)out16_pre; p.o16b = (op_t*)out16_act; p.ld16 = ld16;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksplit = cls_ksplit(N, K);
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksplit = cls_ksplit(N, K); p.alpha = 1.f;
   p.part = (float*)workspace;
   if (p.ksplit > 1 && (!workspace || workspace_bytes < pvrl_cls_linear_f32_workspace_bytes(M, N, K))) return PVRL_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   // eight waves per workgroup = eight slices of the workgroup's K range; K / ksplit / 8 stays a multiple of 16
   return launch_cls<8>(p, epilogue, s);
+}
+
+// The same kernel behind pvrl_gemm_nt_f32_small (gemm_nt.hip) for its K % 128 == 0 shapes -- C = alpha * (A B^T) + bias with a few dozen
+// rows: projection head 768 -> 512 and the step logits against the 9871 x 512 fp32 label table (lib/models/vit.py:299-307), where the
+// 64 x 64-tile FMA kernel took 99 us for the 20 MB it streams.  false: not a shape for this kernel (the caller keeps its own).
+bool pvrl_cls_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float alpha, float* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, hipStream_t s, int* status) {
+  if ((K % 128) || (lda % 4) || (ldb % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || cls_ksplit(N, K) != 1) return false;
+  ClsLin p = {};
+  p.X = A; p.ldx = lda; p.W = B; p.ldw = ldb; p.bias = bias; p.out = C; p.ldo = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksplit = 1; p.alpha = alpha;
+  *status = launch_cls<8>(p, 0, s);
+  return true;
 }

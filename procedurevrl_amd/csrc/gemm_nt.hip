@@ -5,6 +5,10 @@
 #include "gemm_nt8_core.h"
 #include "gemm_nt_skinny.h"
 
+// cls_chain.hip: the cls rows' fp32 MFMA kernel, also used for the K % 128 == 0 shapes of pvrl_gemm_nt_f32_small
+bool pvrl_cls_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float alpha, float* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, hipStream_t s, int* status);
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -283,6 +287,16 @@ extern "C" int pvrl_gemm_nt_batched_bf16(int nprob, const pvrl_nt_problem* probl
   return PVRL_OK;
 }
 
+// PVRL_F32_SMALL_MFMA=0 keeps every shape on the 64 x 64-tile FMA kernel (A/B runs; read once)
+static int f32_small_mfma_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PVRL_F32_SMALL_MFMA");
+    on = e ? (e[0] == '0' ? 0 : 1) : 1;
+  }
+  return on;
+}
+
 extern "C" int64_t pvrl_gemm_nt_f32_small_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int splits = f32_small_plan(M, N, K, nullptr);
@@ -294,6 +308,10 @@ extern "C" int pvrl_gemm_nt_f32_small(const float* A, int64_t lda, const float* 
                                       void* workspace, int64_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0) return PVRL_OK;
   if (!A || !B || !C || K <= 0) return PVRL_EINVAL;
+  if (f32_small_mfma_enabled()) {       // K % 128 == 0: one workgroup per 16 columns of B, fp32 MFMA (cls_chain.hip)
+    int st = PVRL_OK;
+    if (pvrl_cls_gemm_f32(A, lda, B, ldb, bias, alpha, C, ldc, M, N, K, (hipStream_t)stream, &st)) return st;
+  }
   int kchunk;
   const int splits = f32_small_plan(M, N, K, &kchunk);
   if (splits > 1 && (!workspace || workspace_bytes < pvrl_gemm_nt_f32_small_workspace_bytes(M, N, K))) return PVRL_EINVAL;
