@@ -404,6 +404,10 @@ class EncoderEngine(GraphReplay):
         self.group_wgrad = True       # one grouped launch for a block's seven weight gradients
         # the B cls rows' projection + MLP in fp32 on the master weights (csrc/cls_chain.hip; PVRL_CLS_FP32=0: A/B runs)
         self.cls_fp32 = os.environ.get("PVRL_CLS_FP32", "1") == "1"
+        # Only the cls row of the LAST block's output is read (final norm + `x[:, 0]`, vit.py:418-421): that block's spatial projection
+        # and MLP touch the cls rows alone, forward and backward -- the reference computes (and back-propagates zeros through) all 1,569
+        # tokens of every clip there.  Same features, loss and gradients; PVRL_PRUNE_LAST=0: A/B runs.
+        self.prune_last = os.environ.get("PVRL_PRUNE_LAST", "1") == "1"
         self._wq = []
         self._wpost = []
         self._side_keep = []
@@ -772,7 +776,7 @@ class EncoderEngine(GraphReplay):
         if droppath is None:
             droppath = self._droppath_all(B, N, T, dev, training)
         for i, blk in enumerate(m.blocks):
-            x = self._block_fwd(blk, x, sv, droppath[i], save)
+            x = self._block_fwd(blk, x, sv, droppath[i], save, last=i == len(m.blocks) - 1)
 
         feat, mean, rstd = ops.layernorm_fwd(x[R:], m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
                                              out_dtype=F32)
@@ -783,7 +787,9 @@ class EncoderEngine(GraphReplay):
             self.saved = sv
         return feat
 
-    def _block_fwd(self, blk, x0, sv, dp, save):
+    def _block_fwd(self, blk, x0, sv, dp, save, last=False):
+        """`last`: the encoder's last block (with prune_last: the patch rows of x2 / x3 are neither computed nor defined)"""
+        prune = last and self.prune_last
         L = lib()
         B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
         C, H = self.C, self.H
@@ -819,8 +825,9 @@ class EncoderEngine(GraphReplay):
         _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
         x2 = torch.empty_like(x0)
         wproj = self._weight(blk.attn.proj.weight).w
-        ops.gemm_nt(o_s[:R], wproj, L.PVRL_EPI_RESID_F32, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1[:R],
-                    out0=x2[:R])
+        if not prune:
+            ops.gemm_nt(o_s[:R], wproj, L.PVRL_EPI_RESID_F32, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1[:R],
+                        out0=x2[:R])
         if self.cls_fp32:
             # the cls rows' own chain in fp32 on the master weights (csrc/cls_chain.hip): the projection is linear, so the mean over
             # the T frames (vit.py:147-149) is taken first -- B rows instead of B * T
@@ -832,22 +839,32 @@ class EncoderEngine(GraphReplay):
             ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1[R:], out=x2[R:])
 
         # ---- MLP (vit.py:155-157) ----
-        h_m, mean_m, rstd_m = ops.layernorm_fwd(x2, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
-        u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
         x3 = torch.empty_like(x0)
-        ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
-                    rowscale=s3_all, aux=x2, out0=x3)
+        s3c = s3_all[R:] if s3_all is not None else None
+        if prune:
+            # the B cls rows only; h_m / st_m / u / g are then [B, .] tensors (what the backward of this block reads, _block_bwd)
+            h_m = mean_m = rstd_m = u = g = None
+            if save or not self.cls_fp32:
+                h_m, mean_m, rstd_m = ops.layernorm_fwd(x2[R:], P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
+                u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
+            if not self.cls_fp32:
+                ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
+                            rowscale=s3c, aux=x2[R:], out0=x3[R:])
+        else:
+            h_m, mean_m, rstd_m = ops.layernorm_fwd(x2, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
+            u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
+            ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
+                        rowscale=s3_all, aux=x2, out0=x3)
         if self.cls_fp32:       # (the 16-bit path's cls rows of h_m / u / g stay what the backward reads; x3's are replaced)
             hc, _, _ = ops.layernorm_fwd(x2[R:], P(blk.norm2.weight), P(blk.norm2.bias), self.eps, out_dtype=F32,
                                          save_stats=False)
             gc = ops.cls_linear(hc, P(blk.mlp.fc1.weight), P(blk.mlp.fc1.bias), gelu=True)
-            s3c = s3_all[R:] if s3_all is not None else None
             ops.cls_linear(gc, P(blk.mlp.fc2.weight), P(blk.mlp.fc2.bias), rowscale=s3c, biasscale=s3c, aux=x2[R:],
                            out=x3[R:])
         if save:
             sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
                                      lse_t=lse_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
-                                     lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp))
+                                     lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp, pruned=prune))
         return x3
 
     # ------------------------------------------------------------------ HIP graphs (GraphReplay)
@@ -922,7 +939,10 @@ class EncoderEngine(GraphReplay):
         # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
         last = len(m.blocks) - 1
         s3 = sv["blocks"][last]["dp"]["s3_all"] if sv["blocks"][last]["dp"] else None
-        dy = ops.cast_scale(dx, s3)
+        if sv["blocks"][last].get("pruned"):      # dx is zero outside the cls rows here: the last block's MLP / projection backward
+            dy = ops.cast_scale(dx[R:], s3[R:] if s3 is not None else None)     # runs on those rows alone (_block_bwd)
+        else:
+            dy = ops.cast_scale(dx, s3)
         return dict(sv=sv, gs=gs, dx=dx, dy=dy)
 
     def _bwd_block(self, st, i):
@@ -996,26 +1016,47 @@ class EncoderEngine(GraphReplay):
                               dxs=dxs, dxs_scale=dxs_scale, dxsum=dxsum, dxsum_beta=dxsum_beta, gscale=gs.inv, nonfinite=gs.bad,
                               defer=defer)
 
-        # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
-        wgrad(dy, s["g"], blk.mlp.fc2)
-        du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
-        wgrad(du, s["h_m"], blk.mlp.fc1)
-        dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
-        del du
-        dps = torch.empty((R + B * T, C), device=dev, dtype=OP16)
-        lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx, dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
+        if s.get("pruned"):
+            # The encoder's last block under prune_last: dx is zero outside the B cls rows (only `x[:, 0]` of the final norm is read,
+            # vit.py:418-421), so the MLP, norm2 and the spatial projection back-propagate those rows alone: dy, h_m, u, g are [B, .]
+            # tensors here, the weight gradients sums over B (B * T for the projection) rows -- their own small grouped launch: in the
+            # block's grouped launch they would force ONE row slice on its 50k-row problems.
+            def wgrad_c(d, xin, lin):
+                (dw, bw), (dbias, _) = gs.target(lin.weight, fused=True), gs.target(lin.bias, fused=True)
+                return (d, xin, dw, dbias, bw, gs.inv, gs.bad)
+            wq = [wgrad_c(dy, s["g"], blk.mlp.fc2)]
+            du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
+            wq.append(wgrad_c(du, s["h_m"], blk.mlp.fc1))
+            dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
+            lnbwd(dh, s["x2"][R:], s["st_m"], blk.norm2, dx[R:], dx[R:])
+            dpc = ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T)
+            wq.append(wgrad_c(dpc, s["o_s"][R:], blk.attn.proj))
+            ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
+            do = torch.zeros((R + B * T, C), device=dev, dtype=OP16)        # no gradient reaches the patch queries' outputs
+            ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16, out0=do[R:])
+            del du, dpc, wq
+        else:
+            # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
+            wgrad(dy, s["g"], blk.mlp.fc2)
+            du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
+            wgrad(du, s["h_m"], blk.mlp.fc1)
+            dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
+            del du
+            dps = torch.empty((R + B * T, C), device=dev, dtype=OP16)
+            lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx, dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
 
-        # ---- spatial ----
-        ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
-        wgrad(dps, s["o_s"], blk.attn.proj)
-        do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
+            # ---- spatial ----
+            ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
+            wgrad(dps, s["o_s"], blk.attn.proj)
+            do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
+            del dps
         dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=OP16)
         ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
                      mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
         ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
         wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
         dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
-        del dqkv, do, dps
+        del dqkv, do
         # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
         dz = torch.empty((R, C), device=dev, dtype=OP16)
         dbf, bbf = gs.target(blk.temporal_fc.bias, fused=True)

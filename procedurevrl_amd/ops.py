@@ -99,7 +99,9 @@ def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=No
     two = epi in (L.PVRL_EPI_GELU, L.PVRL_EPI_QGELU)
     if two and out1 is None:
         out1 = torch.empty((M, N), device=A.device, dtype=OP16)
-    _timed("gemm_nt_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K, lambda: L.call(
+    # (few-row problems run gemm_nt_skinny_kernel, csrc/gemm_nt_skinny.h: their own family in the bench's per-kernel timing)
+    fam = "gemm_nt_skinny<" if (M <= 192 and K % 256 == 0) else "gemm_nt_kernel<"
+    _timed(fam + _EPI_NAMES[epi] + ">", 2.0 * M * N * K, lambda: L.call(
         "pvrl_gemm_nt_bf16", _ptr(A), _ld(A), _ptr(W), _ld(W), M, N, K, epi, _ptr(bias), _ptr(rowscale),
         _ptr(aux), _ld(aux) if aux is not None else 0, aux_rowmod, _ptr(out0), _ld(out0),
         _ptr(out1), _ld(out1) if out1 is not None else 0, _ptr(bias2), _stream()))
