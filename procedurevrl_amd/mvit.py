@@ -11,6 +11,7 @@ Built for the configuration every shipped MViT yaml uses (configs/HowTo100M/proc
 CLS_EMBED_ON, no absolute position embedding, REL_POS_SPATIAL + REL_POS_TEMPORAL, RESIDUAL_POOLING, DIM_MUL_IN_ATT,
 POOL_KVQ_KERNEL (3,3,3), head_dim 96, DROPOUT_RATE 0 (DROPPATH_RATE: any); other settings raise NotImplementedError.
 """
+import os
 from functools import partial
 
 import torch
@@ -231,6 +232,9 @@ class MViTEngine(GraphReplay):
         self._idx = {}
         self.saved = None
         self.grad_hook = None
+        # only the cls row of the last block's output is read (norm + x[:, 0], slowfast_mvit/mvit.py:400-407): its projection and MLP run
+        # on the B cls rows alone, forward and backward (engine.EncoderEngine.prune_last; PVRL_PRUNE_LAST=0: A/B runs)
+        self.prune_last = os.environ.get("PVRL_PRUNE_LAST", "1") == "1"
         self._graph_init()
 
     # -------------------------------------------------------------- HIP graphs (engine.GraphReplay)
@@ -393,16 +397,29 @@ class MViTEngine(GraphReplay):
             rs_a = torch.cat((dp[0].float().repeat_interleave(Lq), dp[0].float())).contiguous()
             rs_m = torch.cat((dp[1].float().repeat_interleave(Lq), dp[1].float())).contiguous()
         wproj = self._wpad(a.proj.weight, a.proj.bias)
-        x1 = ops.gemm_nt(o, wproj.w, L.PVRL_EPI_RESID_F32, bias=wproj.b, rowscale=rs_a, aux=xres)
-        xn2, mean2, rstd2 = om.ln_fwd(x1, dout, P(blk.norm2.weight), P(blk.norm2.bias), eps, Cpad=Cpo)
         w1 = self._wpad(blk.mlp.fc1.weight, blk.mlp.fc1.bias)
-        u, g = ops.gemm_nt(xn2, w1.w, L.PVRL_EPI_GELU, bias=w1.b)
         w2 = self._wpad(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        x2 = ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, rowscale=rs_m, aux=x1)
+        prune = self.prune_last and i == len(self.enc.blocks) - 1
+        if prune:
+            # the last block: x1 / x2 are defined on the cls rows only; xn2 / mean2 / rstd2 / u / g are [B, .] tensors (_block_bwd)
+            Rc = o.shape[0] - B
+            cs = lambda t: None if t is None else t[Rc:]
+            x1 = torch.empty((o.shape[0], Cpo), device=x.device, dtype=F32)
+            ops.gemm_nt(o[Rc:], wproj.w, L.PVRL_EPI_RESID_F32, bias=wproj.b, rowscale=cs(rs_a), aux=xres[Rc:], out0=x1[Rc:])
+            xn2, mean2, rstd2 = om.ln_fwd(x1[Rc:], dout, P(blk.norm2.weight), P(blk.norm2.bias), eps, Cpad=Cpo)
+            u, g = ops.gemm_nt(xn2, w1.w, L.PVRL_EPI_GELU, bias=w1.b)
+            x2 = torch.empty_like(x1)
+            ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, rowscale=cs(rs_m), aux=x1[Rc:], out0=x2[Rc:])
+        else:
+            x1 = ops.gemm_nt(o, wproj.w, L.PVRL_EPI_RESID_F32, bias=wproj.b, rowscale=rs_a, aux=xres)
+            xn2, mean2, rstd2 = om.ln_fwd(x1, dout, P(blk.norm2.weight), P(blk.norm2.bias), eps, Cpad=Cpo)
+            u, g = ops.gemm_nt(xn2, w1.w, L.PVRL_EPI_GELU, bias=w1.b)
+            x2 = ops.gemm_nt(g, w2.w, L.PVRL_EPI_RESID_F32, bias=w2.b, rowscale=rs_m, aux=x1)
         if save:
             sv["blocks"].append(dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, q=q, k=k, v=v, cq=cq, ck=ck, cv=cv,
                                      rel=rel, o=o, lse=lse, xs=xs if pooled else None, amax=amax, x1=x1, xn2=xn2, mean2=mean2,
-                                     rstd2=rstd2, u=u, g=g, q_thw=q_thw, k_thw=k_thw, pooled=pooled, rs_a=rs_a, rs_m=rs_m))
+                                     rstd2=rstd2, u=u, g=g, q_thw=q_thw, k_thw=k_thw, pooled=pooled, rs_a=rs_a, rs_m=rs_m,
+                                     pruned=prune))
         return x2
 
     # -------------------------------------------------------------- backward
@@ -479,17 +496,37 @@ class MViTEngine(GraphReplay):
         # ---- MLP
         w1 = self._wpad(blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         w2 = self._wpad(blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        dyb = dx2_16 if dx2_16 is not None else ops.cast_scale(dx2, rowscale=s["rs_m"])
-        self._wgrad(dyb, s["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias, w2)
-        du = ops.gemm_nt(dyb, w2.t, L.PVRL_EPI_DGELU, aux=s["u"])
-        self._wgrad(du, s["xn2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias, w1)
-        dxn2 = ops.gemm_nt(du, w1.t, L.PVRL_EPI_BF16)
-        dx1, dx1b = om.ln_bwd(dxn2, s["x1"], dout, s["mean2"], s["rstd2"], P(blk.norm2.weight), self._acc_target(blk.norm2.weight),
-                              self._acc_target(blk.norm2.bias), dres=dx2, Cpad=Cpo, want16=True, rowscale16=s["rs_a"])
-        # ---- attention output projection
         wproj = self._wpad(a.proj.weight, a.proj.bias)
-        self._wgrad(dx1b, s["o"], a.proj.weight, a.proj.bias, wproj)
-        d_o = ops.gemm_nt(dx1b, wproj.t, L.PVRL_EPI_BF16)
+        if s.get("pruned"):
+            # the last block under prune_last: dx2 is zero outside the B cls rows, so the MLP, norm2 and the projection back-propagate
+            # those rows alone (the saved xn2 / u / g are [B, .]); no gradient reaches the patch queries' attention outputs
+            assert dx2_16 is None
+            Rc = dx2.shape[0] - B
+            cs = lambda t: None if t is None else t[Rc:]
+            dyb = ops.cast_scale(dx2[Rc:], rowscale=cs(s["rs_m"]))
+            self._wgrad(dyb, s["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias, w2)
+            du = ops.gemm_nt(dyb, w2.t, L.PVRL_EPI_DGELU, aux=s["u"])
+            self._wgrad(du, s["xn2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias, w1)
+            dxn2 = ops.gemm_nt(du, w1.t, L.PVRL_EPI_BF16)
+            dx1c, dx1b = om.ln_bwd(dxn2, s["x1"][Rc:], dout, s["mean2"], s["rstd2"], P(blk.norm2.weight),
+                                   self._acc_target(blk.norm2.weight), self._acc_target(blk.norm2.bias), dres=dx2[Rc:], Cpad=Cpo,
+                                   want16=True, rowscale16=cs(s["rs_a"]))
+            dx1 = dx2                      # zero on the patch rows already
+            dx1[Rc:] = dx1c
+            self._wgrad(dx1b, s["o"][Rc:], a.proj.weight, a.proj.bias, wproj)
+            d_o = torch.zeros_like(s["o"])
+            ops.gemm_nt(dx1b, wproj.t, L.PVRL_EPI_BF16, out0=d_o[Rc:])
+        else:
+            dyb = dx2_16 if dx2_16 is not None else ops.cast_scale(dx2, rowscale=s["rs_m"])
+            self._wgrad(dyb, s["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias, w2)
+            du = ops.gemm_nt(dyb, w2.t, L.PVRL_EPI_DGELU, aux=s["u"])
+            self._wgrad(du, s["xn2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias, w1)
+            dxn2 = ops.gemm_nt(du, w1.t, L.PVRL_EPI_BF16)
+            dx1, dx1b = om.ln_bwd(dxn2, s["x1"], dout, s["mean2"], s["rstd2"], P(blk.norm2.weight), self._acc_target(blk.norm2.weight),
+                                  self._acc_target(blk.norm2.bias), dres=dx2, Cpad=Cpo, want16=True, rowscale16=s["rs_a"])
+            # ---- attention output projection
+            self._wgrad(dx1b, s["o"], a.proj.weight, a.proj.bias, wproj)
+            d_o = ops.gemm_nt(dx1b, wproj.t, L.PVRL_EPI_BF16)
         # ---- pooling attention, rel-pos terms, pooling convs
         q_thw, k_thw = s["q_thw"], s["k_thw"]
         Lq = q_thw[0] * q_thw[1] * q_thw[2]
