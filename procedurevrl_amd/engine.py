@@ -408,6 +408,7 @@ class EncoderEngine(GraphReplay):
         # and MLP touch the cls rows alone, forward and backward -- the reference computes (and back-propagates zeros through) all 1,569
         # tokens of every clip there.  Same features, loss and gradients; PVRL_PRUNE_LAST=0: A/B runs.
         self.prune_last = os.environ.get("PVRL_PRUNE_LAST", "1") == "1"
+        self.prune_attn = os.environ.get("PVRL_PRUNE_ATTN", "1") == "1"     # ... and its spatial attention the cls query only (attn_cls.hip)
         self._wq = []
         self._wpost = []
         self._side_keep = []
@@ -822,7 +823,11 @@ class EncoderEngine(GraphReplay):
         h_s, mean_s, rstd_s = ops.layernorm_fwd(x1, P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
         qkv_s = ops.gemm_nt(h_s, self._weight(blk.attn.qkv.weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
         o_s = torch.empty((R + B * T, C), device=dev, dtype=OP16)
-        _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
+        cls_attn = prune and self.prune_attn
+        if cls_attn:       # the last block: only the cls query's output is read (csrc/attn_cls.hip); o_s[:R] stays undefined
+            _, lse_s = ops.attn_cls_fwd(qkv_s, B * T, N + 1, H, self.scale, T, R, o_cls=o_s[R:])
+        else:
+            _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
         x2 = torch.empty_like(x0)
         wproj = self._weight(blk.attn.proj.weight).w
         if not prune:
@@ -864,7 +869,7 @@ class EncoderEngine(GraphReplay):
         if save:
             sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
                                      lse_t=lse_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
-                                     lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp, pruned=prune))
+                                     lse_s=lse_s, h_m=h_m, st_m=(mean_m, rstd_m), u=u, g=g, dp=dp, pruned=prune, cls_attn=cls_attn))
         return x3
 
     # ------------------------------------------------------------------ HIP graphs (GraphReplay)
@@ -1032,8 +1037,11 @@ class EncoderEngine(GraphReplay):
             dpc = ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T)
             wq.append(wgrad_c(dpc, s["o_s"][R:], blk.attn.proj))
             ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
-            do = torch.zeros((R + B * T, C), device=dev, dtype=OP16)        # no gradient reaches the patch queries' outputs
-            ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16, out0=do[R:])
+            if s.get("cls_attn"):
+                do = ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)      # [B * T, C]: the cls queries' dO
+            else:
+                do = torch.zeros((R + B * T, C), device=dev, dtype=OP16)        # no gradient reaches the patch queries' outputs
+                ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16, out0=do[R:])
             del du, dpc, wq
         else:
             # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
@@ -1051,8 +1059,11 @@ class EncoderEngine(GraphReplay):
             do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
             del dps
         dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=OP16)
-        ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
-                     mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
+        if s.get("cls_attn"):
+            ops.attn_cls_bwd(s["qkv_s"], s["o_s"][R:], do, s["lse_s"], B * T, N + 1, H, self.scale, T, R, dqkv[:M], dqkv[M:])
+        else:
+            ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
+                         mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
         ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
         wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
         dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)

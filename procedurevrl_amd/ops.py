@@ -382,6 +382,28 @@ def attn_fwd(qkv, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=
     return o, o_cls, lse
 
 
+def attn_cls_fwd(qkv, nseq, S, H, scale, T, cls_base, o_cls=None, lse=None):
+    """spatial attention (mode 1 addressing) for the cls query of every sequence only -> (o_cls [nseq, H*64], lse [nseq, H, S] with entry 0
+    of every (sequence, head) valid): the encoder's last block (pvrl_attn_cls_fwd)"""
+    _chk2d(qkv, OP16)
+    if o_cls is None:
+        o_cls = torch.empty((nseq, H * 64), device=qkv.device, dtype=OP16)
+    if lse is None:
+        lse = torch.empty((nseq, H, S), device=qkv.device, dtype=F32)
+    lib().call("pvrl_attn_cls_fwd", _ptr(qkv), _ld(qkv), nseq, S, H, T, cls_base, float(scale), _ptr(o_cls), _ld(o_cls), _ptr(lse),
+               _stream())
+    return o_cls, lse
+
+
+def attn_cls_bwd(qkv, o_cls, d_o_cls, lse, nseq, S, H, scale, T, cls_base, dqkv, dqkv_cls):
+    """backward of attn_cls_fwd: dK / dV of every token, zero dQ for the patch tokens, the cls token's partial rows in dqkv_cls"""
+    _chk2d(qkv, OP16)
+    assert _ld(o_cls) == _ld(d_o_cls) and _ld(dqkv) == _ld(dqkv_cls)
+    lib().call("pvrl_attn_cls_bwd", _ptr(qkv), _ld(qkv), nseq, S, H, T, cls_base, float(scale), _ptr(o_cls), _ptr(d_o_cls), _ld(o_cls),
+               _ptr(lse), _ptr(dqkv), _ptr(dqkv_cls), _ld(dqkv), _stream())
+    return dqkv, dqkv_cls
+
+
 def attn_bwd(qkv, o, o_cls, d_o, d_o_cls, lse, nseq, S, H, scale, mode=0, T=1, cls_base=0, causal=False, kpm=None,
              dqkv=None, dqkv_cls=None):
     L = lib()

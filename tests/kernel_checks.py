@@ -629,6 +629,41 @@ def check_attn_mfma_spatial():
     return out
 
 
+def check_attn_cls():
+    """pvrl_attn_cls_fwd / _bwd (the last block's spatial attention: the cls query only, csrc/attn_cls.hip) against fp32 autograd of
+    vit.py:75-92 on the gathered sequences with the gradient fed to the cls queries' outputs only."""
+    from procedurevrl_amd import ops
+    g = torch.Generator().manual_seed(31)
+    out = []
+    for (B, T, N, H) in [(2, 4, 16, 2), (3, 8, 196, 12), (1, 2, 255, 3)]:
+        HD = H * 64
+        S = N + 1
+        R = B * N * T
+        nseq = B * T
+        qkv = torch.randn(R + B, 3 * HD, generator=g)
+        qkvb = bf(qkv).clone().requires_grad_(True)
+        tok = qkvb[:R].view(B, N, T, 3 * HD).permute(0, 2, 1, 3)
+        cls = qkvb[R:].view(B, 1, 1, 3 * HD).expand(B, T, 1, 3 * HD)
+        seqs = torch.cat([cls, tok], 2).reshape(nseq, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+        o_ref = _ref_attn(seqs[0], seqs[1], seqs[2], 0.125).permute(0, 2, 1, 3).reshape(B, T, S, HD)
+        o_cls_ref = o_ref[:, :, 0].reshape(nseq, HD)
+        qd = qkv.to(dev(), BF)
+        o_cls, lse = ops.attn_cls_fwd(qd, nseq, S, H, 0.125, T, R)
+        tag = f"attn cls-query B={B} T={T} N={N}"
+        out.append((tag + " fwd", rel(o_cls, o_cls_ref), TOL_BF16))
+        do = torch.randn(nseq, HD, generator=g)
+        dob = bf(do)
+        (o_cls_ref * dob).sum().backward()
+        dref = qkvb.grad
+        dbuf = torch.full((R + B + nseq, 3 * HD), float("nan"), device=dev(), dtype=BF)      # every row must be written
+        ops.attn_cls_bwd(qd, o_cls, do.to(dev(), BF), lse, nseq, S, H, 0.125, T, R, dbuf[:R + B], dbuf[R + B:])
+        out.append((tag + " bwd tok", rel(dbuf[:R], dref[:R]), 1.5e-2))
+        out.append((tag + " bwd tok: dQ of the patch tokens (max abs)", float(dbuf[:R, :HD].float().abs().max()), 0.0))
+        dcls_sum = dbuf[R + B:].float().view(B, T, 3 * HD).sum(1)
+        out.append((tag + " bwd cls", rel(dcls_sum, dref[R:]), 1.5e-2))
+    return out
+
+
 def check_attn_bwd_repeatable():
     """The persistent (S = 197, mode 1) and the one-wave (S = 32, mode 0) backward kernels stream their operands with counted waits
     and no workgroup-wide drains: launched repeatedly next to an uneven load on a second stream, every result must be BIT-identical
@@ -821,5 +856,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_small_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_small_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8, check_attn_cls,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]
