@@ -179,13 +179,14 @@ int pvrl_attn_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t 
 /* The same attention (mode 1 addressing) for the cls query of every sequence ONLY -- the spatial attention of the encoder's LAST block,
  * of whose output only x[:, 0] is read (vit.py:418-421; csrc/attn_cls.hip).  Forward: o_cls [nseq][H*64] and lse[(seq*H + h)*S + 0] (the
  * other lse entries are not written).  Backward: dO is taken to be zero for every patch query: dK / dV of all S tokens and zeros for the
- * patch tokens' dQ go to dqkv (token 0's partial row to dqkv_cls[seq], as pvrl_attn_bwd does), dQ of the cls query to dqkv_cls[seq].
+ * patch tokens' dQ (only with zero_patch_dq != 0: a caller that never reads that third of those rows saves the writes) go to dqkv
+ * (token 0's partial row to dqkv_cls[seq], as pvrl_attn_bwd does), dQ of the cls query to dqkv_cls[seq].
  * S >= 2, nseq % T == 0. */
 int pvrl_attn_cls_fwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int64_t T, int64_t cls_base,
                       float scale, void* o_cls, int64_t ldo, float* lse, void* stream);
 int pvrl_attn_cls_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int64_t T, int64_t cls_base,
                       float scale, const void* o_cls, const void* d_o_cls, int64_t ldo, const float* lse, void* dqkv,
-                      void* dqkv_cls, int64_t ldd, void* stream);
+                      void* dqkv_cls, int64_t ldd, int zero_patch_dq, void* stream);
 
 /* PatchEmbed im2col: frames fp32 [B,3,T,HI,WI] -> bf16 rows (b, n, t) x (c, py, px) (vit.py:174-180,396). */
 int pvrl_patchify(const float* frames, int64_t B, int64_t T, int64_t HI, int64_t WI, void* out, int64_t ldo,

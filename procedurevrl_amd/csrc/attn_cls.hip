@@ -27,6 +27,7 @@ struct AttnCls {
   float* lse;                             // [nseq][H][S]: entry 0 of each (sequence, head) is written / read
   const op_t* d_o_cls; const op_t* ofw_cls;
   op_t* dqkv; op_t* dqkv_cls; long ldd;
+  int zero_dq;                            // backward: write the (zero) dQ of the patch tokens
 };
 
 // lane = (key group kg = lane >> 3, chunk c = lane & 7): one load instruction fetches eight whole 128-byte K (or V) rows, lane (kg, c)
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * AC_WAVES) void attn_cls_bwd_kernel(AttnCls p) 
       for (int e = 0; e < 8; ++e) { dk[e] = (op_t)(ds * q8[e]); dv[e] = (op_t)(pk * do8[e]); }
       *reinterpret_cast<opx8*>(out + HD) = dk;
       *reinterpret_cast<opx8*>(out + 2 * HD) = dv;
-      if (kc > 0) *reinterpret_cast<opx8*>(out) = (opx8)(op_t)0.f;       // no gradient reaches a patch query
+      if (kc > 0 && p.zero_dq) *reinterpret_cast<opx8*>(out) = (opx8)(op_t)0.f;       // no gradient reaches a patch query
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) accq[e] = fmaf(ds, (float)k8[e], accq[e]);
@@ -177,12 +178,12 @@ extern "C" int pvrl_attn_cls_fwd(const void* qkv, int64_t ld, int64_t nseq, int6
 
 extern "C" int pvrl_attn_cls_bwd(const void* qkv, int64_t ld, int64_t nseq, int64_t S, int64_t H, int64_t T, int64_t cls_base,
                                  float scale, const void* o_cls, const void* d_o_cls, int64_t ldo, const float* lse, void* dqkv,
-                                 void* dqkv_cls, int64_t ldd, void* stream) {
+                                 void* dqkv_cls, int64_t ldd, int zero_patch_dq, void* stream) {
   AttnCls p = {};
   p.qkv = (const op_t*)qkv; p.ld = ld; p.H = (int)H; p.nseq = (int)nseq;
   p.mp.mode = 1; p.mp.S = (int)S; p.mp.T = (int)T; p.mp.cls_base = cls_base;
   p.scale = scale; p.ofw_cls = (const op_t*)o_cls; p.d_o_cls = (const op_t*)d_o_cls; p.ldo = ldo; p.lse = const_cast<float*>(lse);
-  p.dqkv = (op_t*)dqkv; p.dqkv_cls = (op_t*)dqkv_cls; p.ldd = ldd;
+  p.dqkv = (op_t*)dqkv; p.dqkv_cls = (op_t*)dqkv_cls; p.ldd = ldd; p.zero_dq = zero_patch_dq;
   if (nseq == 0) return PVRL_OK;
   if (int e = check(p)) return e;
   if (!o_cls || !d_o_cls || !dqkv || !dqkv_cls || (ldd % 8) || ((uintptr_t)dqkv & 15) || ((uintptr_t)dqkv_cls & 15)) return PVRL_EINVAL;

@@ -821,12 +821,19 @@ class EncoderEngine(GraphReplay):
 
         # ---- spatial branch (vit.py:137-151), all rows; cls of clip b is token 0 of its T sequences ----
         h_s, mean_s, rstd_s = ops.layernorm_fwd(x1, P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
-        qkv_s = ops.gemm_nt(h_s, self._weight(blk.attn.qkv.weight).w, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
         o_s = torch.empty((R + B * T, C), device=dev, dtype=OP16)
         cls_attn = prune and self.prune_attn
-        if cls_attn:       # the last block: only the cls query's output is read (csrc/attn_cls.hip); o_s[:R] stays undefined
+        wqkv = self._weight(blk.attn.qkv.weight).w
+        if cls_attn:
+            # the last block: only the cls query's output is read (csrc/attn_cls.hip) -- keys and values of every token, queries of the
+            # B cls rows; the patch rows' query third of qkv_s and o_s[:R] stay undefined and are never read
+            qkv_s = torch.empty((M, 3 * C), device=dev, dtype=OP16)
+            bq = P(blk.attn.qkv.bias)
+            ops.gemm_nt(h_s, wqkv[C:], L.PVRL_EPI_BF16, bias=bq[C:], out0=qkv_s[:, C:])
+            ops.gemm_nt(h_s[R:], wqkv[:C], L.PVRL_EPI_BF16, bias=bq[:C], out0=qkv_s[R:, :C])
             _, lse_s = ops.attn_cls_fwd(qkv_s, B * T, N + 1, H, self.scale, T, R, o_cls=o_s[R:])
         else:
+            qkv_s = ops.gemm_nt(h_s, wqkv, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
             _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
         x2 = torch.empty_like(x0)
         wproj = self._weight(blk.attn.proj.weight).w
@@ -1036,13 +1043,14 @@ class EncoderEngine(GraphReplay):
             lnbwd(dh, s["x2"][R:], s["st_m"], blk.norm2, dx[R:], dx[R:])
             dpc = ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T)
             wq.append(wgrad_c(dpc, s["o_s"][R:], blk.attn.proj))
-            ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
+            if not s.get("cls_attn"):
+                ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
             if s.get("cls_attn"):
                 do = ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)      # [B * T, C]: the cls queries' dO
             else:
                 do = torch.zeros((R + B * T, C), device=dev, dtype=OP16)        # no gradient reaches the patch queries' outputs
                 ops.gemm_nt(dpc, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16, out0=do[R:])
-            del du, dpc, wq
+            del du, dpc
         else:
             # ---- MLP ----   (dy = bf16(s3 * dx) arrives from the caller)
             wgrad(dy, s["g"], blk.mlp.fc2)
@@ -1060,13 +1068,27 @@ class EncoderEngine(GraphReplay):
             del dps
         dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=OP16)
         if s.get("cls_attn"):
-            ops.attn_cls_bwd(s["qkv_s"], s["o_s"][R:], do, s["lse_s"], B * T, N + 1, H, self.scale, T, R, dqkv[:M], dqkv[M:])
+            # dQ is non-zero for the cls rows alone: the query third of dqkv's patch rows is neither written nor read -- the qkv weight
+            # gradient's query rows are sums over the B cls rows (into the block's small grouped launch), the data gradient of the patch
+            # rows a K = 2 C product
+            ops.attn_cls_bwd(s["qkv_s"], s["o_s"][R:], do, s["lse_s"], B * T, N + 1, H, self.scale, T, R, dqkv[:M], dqkv[M:],
+                             zero_patch_dq=False)
+            ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
+            (dw, bw), (dbias, _) = gs.target(blk.attn.qkv.weight, fused=True), gs.target(blk.attn.qkv.bias, fused=True)
+            wq.append((dqkv[R:M, :C], s["h_s"][R:], dw[:C], dbias[:C], bw, gs.inv, gs.bad))
+            ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
+            self._wgrad(dqkv[:M, C:], s["h_s"], dw[C:], dbias[C:], bw, gscale=gs.inv, nonfinite=gs.bad)
+            wt = self._weight(blk.attn.qkv.weight).t
+            dh = torch.empty((M, C), device=dev, dtype=OP16)
+            ops.gemm_nt(dqkv[:R, C:], wt[:, C:], L.PVRL_EPI_BF16, out0=dh[:R])
+            ops.gemm_nt(dqkv[R:M], wt, L.PVRL_EPI_BF16, out0=dh[R:])
+            del wq
         else:
             ops.attn_bwd(s["qkv_s"], s["o_s"][:R], s["o_s"][R:], do[:R], do[R:], s["lse_s"], B * T, N + 1, H, self.scale,
                          mode=1, T=T, cls_base=R, dqkv=dqkv[:M], dqkv_cls=dqkv[M:])
-        ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
-        wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
-        dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
+            ops.group_reduce(dqkv[M:], B, T, out=dqkv[R:M])
+            wgrad(dqkv[:M], s["h_s"], blk.attn.qkv)
+            dh = ops.gemm_nt(dqkv[:M], self._weight(blk.attn.qkv.weight).t, L.PVRL_EPI_BF16)
         del dqkv, do
         # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
         dz = torch.empty((R, C), device=dev, dtype=OP16)

@@ -395,12 +395,13 @@ def attn_cls_fwd(qkv, nseq, S, H, scale, T, cls_base, o_cls=None, lse=None):
     return o_cls, lse
 
 
-def attn_cls_bwd(qkv, o_cls, d_o_cls, lse, nseq, S, H, scale, T, cls_base, dqkv, dqkv_cls):
-    """backward of attn_cls_fwd: dK / dV of every token, zero dQ for the patch tokens, the cls token's partial rows in dqkv_cls"""
+def attn_cls_bwd(qkv, o_cls, d_o_cls, lse, nseq, S, H, scale, T, cls_base, dqkv, dqkv_cls, zero_patch_dq=True):
+    """backward of attn_cls_fwd: dK / dV of every token, the cls token's partial rows in dqkv_cls; the patch tokens' dQ (zero) is written
+    only with `zero_patch_dq`"""
     _chk2d(qkv, OP16)
     assert _ld(o_cls) == _ld(d_o_cls) and _ld(dqkv) == _ld(dqkv_cls)
     lib().call("pvrl_attn_cls_bwd", _ptr(qkv), _ld(qkv), nseq, S, H, T, cls_base, float(scale), _ptr(o_cls), _ptr(d_o_cls), _ld(o_cls),
-               _ptr(lse), _ptr(dqkv), _ptr(dqkv_cls), _ld(dqkv), _stream())
+               _ptr(lse), _ptr(dqkv), _ptr(dqkv_cls), _ld(dqkv), 1 if zero_patch_dq else 0, _stream())
     return dqkv, dqkv_cls
 
 
