@@ -287,6 +287,8 @@ def main():
         wexec = wtrain
         if args.arch == "vit" and getattr(vt.engine, "prune_last", False):
             wexec = wtrain - 3 * (1.86 + 7.40 + 7.40) * 1e9 * args.frames / 8
+            if getattr(vt.engine, "prune_attn", False):     # ... its spatial attention for the cls query only (0.954 GFLOP of bmm per block
+                wexec -= 3 * (0.95 + 5.58 / 3) * 1e9 * args.frames / 8      # and clip) and the query third of its spatial qkv GEMM (5.58 / 3)
         out = {
             "metric": f"training clips/sec ({args.frames}f x 224^2, ViT-B TimeSformer)" if args.arch == "vit" else
                       f"training clips/sec ({args.frames}f x 224^2, MViTv2-S)", "value": round(value, 3), "unit": "clips/s",
