@@ -170,7 +170,7 @@ extern "C" int pvrl_attn_cls_fwd(const void* qkv, int64_t ld, int64_t nseq, int6
   p.scale = scale; p.o_cls = (op_t*)o_cls; p.ldo = ldo; p.lse = lse;
   if (nseq == 0) return PVRL_OK;
   if (int e = check(p)) return e;
-  if (!o_cls) return PVRL_EINVAL;
+  if (!o_cls || (ldo % 8) || ((uintptr_t)o_cls & 15)) return PVRL_EINVAL;
   hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3((unsigned)cdiv(nseq * H, AC_WAVES)), dim3(64 * AC_WAVES), 0, (hipStream_t)stream, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;
@@ -187,6 +187,7 @@ extern "C" int pvrl_attn_cls_bwd(const void* qkv, int64_t ld, int64_t nseq, int6
   if (nseq == 0) return PVRL_OK;
   if (int e = check(p)) return e;
   if (!o_cls || !d_o_cls || !dqkv || !dqkv_cls || (ldd % 8) || ((uintptr_t)dqkv & 15) || ((uintptr_t)dqkv_cls & 15)) return PVRL_EINVAL;
+  if ((ldo % 8) || ((uintptr_t)o_cls & 15) || ((uintptr_t)d_o_cls & 15)) return PVRL_EINVAL;
   hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3((unsigned)cdiv(nseq * H, AC_WAVES)), dim3(64 * AC_WAVES), 0, (hipStream_t)stream, p);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;

@@ -280,7 +280,7 @@ def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=N
     return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
 
 
-def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None):
+def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None, prune=None):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -294,6 +294,8 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
     vt.load_state_dict({**sd, **{k: v for k, v in vt.state_dict().items() if k.startswith("order_tfm.")}}, strict=True)
     model.to(DEV)
     model.train()
+    if prune is not None:       # (prune_last, prune_attn): the last block on all rows / its attention on all queries (engine defaults: both on)
+        vt.engine.prune_last, vt.engine.prune_attn = prune
     x = torch.randn(B, 3, frames, crop, crop, generator=g)
     teacher = torch.randn(B, K, generator=g) * 4
     dp_ref = dp_hip = None
@@ -353,6 +355,15 @@ def check_train_step_small():
 def check_train_step_droppath_ragged():
     """DropPath masks pinned (rate 0.3), 48x48 crops (9 patches: ragged GEMM / attention tiles), 3 clips."""
     return _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="droppath: ")
+
+
+def check_train_step_last_block_unpruned():
+    """The same two steps with the last block run the reference's way -- projection, MLP, spatial attention and the query projection
+    over all tokens (EncoderEngine.prune_last / prune_attn off; PVRL_PRUNE_LAST=0 / PVRL_PRUNE_ATTN=0) -- and with only the
+    attention part of the pruning off: the paths the default no longer takes."""
+    out = _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="droppath, last block on all rows: ", prune=(False, False))
+    out += _hip_vs_oracle(2, 32, 64, 4, tag="small, last block's attention on all queries: ", rounding_model=False, prune=(True, False))
+    return out
 
 
 def check_train_step_t4():
@@ -625,6 +636,6 @@ def check_hip_graph_replay():
     return out
 
 
-ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged,
+ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged, check_train_step_last_block_unpruned,
               check_train_step_t4, check_train_step_t32, check_train_step_crop256, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
               check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step, check_bench_config_two_clips]
