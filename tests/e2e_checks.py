@@ -280,7 +280,8 @@ def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=N
     return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
 
 
-def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None, prune=None):
+def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None, prune=None,
+                   cls_fp32=None):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -296,6 +297,8 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
     model.train()
     if prune is not None:       # (prune_last, prune_attn): the last block on all rows / its attention on all queries (engine defaults: both on)
         vt.engine.prune_last, vt.engine.prune_attn = prune
+    if cls_fp32 is not None:    # PVRL_CLS_FP32=0: the cls rows' projection / MLP on the 16-bit path
+        vt.engine.cls_fp32 = cls_fp32
     x = torch.randn(B, 3, frames, crop, crop, generator=g)
     teacher = torch.randn(B, K, generator=g) * 4
     dp_ref = dp_hip = None
@@ -363,6 +366,9 @@ def check_train_step_last_block_unpruned():
     attention part of the pruning off: the paths the default no longer takes."""
     out = _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="droppath, last block on all rows: ", prune=(False, False))
     out += _hip_vs_oracle(2, 32, 64, 4, tag="small, last block's attention on all queries: ", rounding_model=False, prune=(True, False))
+    # and the pruned last block with the cls rows on the 16-bit path (PVRL_CLS_FP32=0): its MLP is then three few-row 16-bit GEMMs
+    out += _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="droppath, cls rows 16-bit, pruned: ", rounding_model=False,
+                          cls_fp32=False)
     return out
 
 
