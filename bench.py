@@ -297,7 +297,9 @@ def main():
             "config": {"workload": ("MViTv2-S " if args.arch == "mvit" else "TimeSformer ViT-B ") +
                                    f"{args.frames}x224^2, {B} clips/GPU, K={args.classes} step logits, "
                                    "top-5 KL + all-gather InfoNCE, fwd+bwd+AdamW (BASELINE configs[1]; configs[2] at 8 GPUs)",
-                       "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "last_block": ("cls rows only (projection, MLP, spatial attention: only x[:, 0] of its output is read, "
+                                      "vit.py:418-421; side[1] = all tokens)") if getattr(vt.engine, "prune_last", False) else "all tokens"},
             "comm": None if not dp_path else {"backend": backend, "ranks": dist.get_world_size(),
                                              "rccl": rccl_version(torch) if backend == "nccl" else None,
                                              "cus_per_xcd_left_to_rccl": comm_cus, "compute_cus_per_xcd": os.environ.get("PVRL_COMPUTE_CUS"),
@@ -374,7 +376,8 @@ def parity_probe():
 
 def side_measurements(all_sides=False):
     """The other single-GPU lines, each a child process of this same script under the driver's clock: configs[1] with bf16 operands
-    (the type BASELINE's configs name; not held to 1e-3) and the reference's full pre-training step; with --all-sides also configs[3]
+    (the type BASELINE's configs name; not held to 1e-3), configs[1] with the last block unpruned, and the reference's full pre-training
+    step; with --all-sides also configs[3]
     and configs[4], whose per-kernel profiles are tracked under profiles/."""
     import subprocess
     res = []
@@ -383,6 +386,9 @@ def side_measurements(all_sides=False):
     lines = [
         ("configs[1] with bf16 operands (PVRL_OPERAND=bf16, libpvrl_hip.so): TimeSformer ViT-B 8x224^2, 32 clips/GPU",
          ["--steps", "20", "--warmup", "5", "--parity-probe"], {"PVRL_OPERAND": "bf16"}, None),
+        ("configs[1] with the last block run over all 1,569 tokens of every clip, as the reference runs it (PVRL_PRUNE_LAST=0 "
+         "PVRL_PRUNE_ATTN=0): what `value` would be without skipping the work whose results nothing reads (DESIGN section 3)",
+         ["--steps", "20", "--warmup", "5"], {"PVRL_PRUNE_LAST": "0", "PVRL_PRUNE_ATTN": "0"}, None),
         ("the reference's FULL pre-training step (vit.py:283-352, train_net.py:152-181): 4 videos x 9 clips of 8x224^2, frozen "
          "12-layer CLIP-text teacher + order / diffusion transformer + top-5 KL + MSE + AdamW, head replayed from HIP graphs",
          ["--steps", "10", "--warmup", "6"], {}, full)]
