@@ -33,6 +33,13 @@ from einops import rearrange
 from . import timesformer_oracle as orc
 
 OPERAND = None          # None (no rounding: identical to timesformer_oracle), torch.bfloat16 or torch.float16
+# Round 6: the PATCH rows of the residual stream stored in the operand type between kernels (the cls rows stay
+# fp32).  None: fp32 stream (rounds 1-5); "fwd": the values x0 / x1 / x2 / x3 of the patch rows are 16-bit (GEMM residual epilogues
+# read and write them, LayerNorm reads them); "both": the residual GRADIENT stream dx of the patch rows as well (ln_bwd's dx in / out).
+RESID = None
+# fc1 epilogue variant that was costed and rejected (tests/probe_resid16.py): GELU derivative kept as an n-bit code instead of the
+# 16-bit pre-activation u.  None: the shipped form (16-bit u).
+DGELU_BITS = None
 
 
 def _rnd(t):
@@ -84,6 +91,13 @@ def RB(x):
     return _RoundBwd.apply(x)
 
 
+def RX(x):
+    """patch rows of the residual stream (see RESID)"""
+    if OPERAND is None or RESID is None:
+        return x
+    return (_Round if RESID == "both" else _RoundFwd).apply(x)
+
+
 class GeluStore(torch.autograd.Function):
     """fc1 epilogue (gemm_nt GELU): g = gelu(u) from the fp32 accumulator, u kept as a 16-bit copy; backward multiplies by
     gelu'(stored u) (gemm_nt dGELU epilogue).  Returns the unrounded g (the caller rounds it)."""
@@ -97,7 +111,11 @@ class GeluStore(torch.autograd.Function):
         (u,) = ctx.saved_tensors
         cdf = 0.5 * (1.0 + torch.erf(u * 0.7071067811865476))
         pdf = torch.exp(-0.5 * u * u) * 0.3989422804014327
-        return dg * (cdf + u * pdf)
+        d = cdf + u * pdf
+        if DGELU_BITS is not None:      # gelu' in [-0.13, 1.13] as a uniform n-bit code
+            q = 1.26 / (2 ** DGELU_BITS - 1)
+            d = torch.round((d + 0.13) / q) * q - 0.13
+        return dg * d
 
 
 class AttnMFMA(torch.autograd.Function):
@@ -167,7 +185,7 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
         res_temporal = orc.drop_path_apply(RB(F.linear(o, we, be)), s1)
         res_temporal = rearrange(res_temporal, "(b h w) t m -> b (h w t) m", b=B, h=H, w=W, t=T)
         res_temporal = res_temporal + sd[pre + "temporal_fc.bias"]
-    xt = x[:, 1:, :] + res_temporal
+    xt = RX(x[:, 1:, :] + res_temporal)
     # spatial (:137-151)
     init_cls_token = x[:, 0, :].unsqueeze(1)
     cls_token = init_cls_token.repeat(1, T, 1)
@@ -186,7 +204,7 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
     res_spatial = res_spatial[:, 1:, :]
     res_spatial = rearrange(res_spatial, "(b t) (h w) m -> b (h w t) m", b=B, h=H, w=W, t=T)
     # merge + MLP (:155-157)
-    x = torch.cat((init_cls_token, xt), 1) + torch.cat((cls_token, res_spatial), 1)
+    x = torch.cat((init_cls_token + cls_token, RX(xt + res_spatial)), 1)
     hf = ln(x, "norm2")
     h = R(hf)
     u = RB(lin(h, "mlp.fc1"))
@@ -195,6 +213,8 @@ def block(sd, pre, x, B, T, W, num_heads=12, dp=None):
     if OPERAND is not None:     # the cls rows' MLP in fp32 end to end: LayerNorm output, master weights, exact GELU (csrc/cls_chain.hip)
         y = torch.cat((_value_of(linf(F.gelu(linf(hf[:, :1], "mlp.fc1")), "mlp.fc2"), y[:, :1]), y[:, 1:]), 1)
     x = x + orc.drop_path_apply(y, s3)
+    if OPERAND is not None and RESID is not None:
+        x = torch.cat((x[:, :1], RX(x[:, 1:])), 1)
     return x
 
 
@@ -215,7 +235,7 @@ def forward_features(sd, x, depth, num_heads=12, droppath=None):
     xx = rearrange(xx, "(b t) n m -> (b n) t m", b=B, t=T)
     xx = xx + sd["time_embed"]
     xx = rearrange(xx, "(b n) t m -> b (n t) m", b=B, t=T)
-    xx = torch.cat((cls_tokens, xx), dim=1)
+    xx = torch.cat((cls_tokens, RX(xx)), dim=1)
     for i in range(depth):
         xx = block(sd, f"blocks.{i}.", xx, B, T, W, num_heads, None if droppath is None else droppath[i])
     xx = F.layer_norm(xx, (xx.shape[-1],), sd["norm.weight"], sd["norm.bias"], orc.LN_EPS_VIT)
