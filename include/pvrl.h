@@ -34,6 +34,9 @@ extern "C" {
 #define PVRL_EPI_F32 4       /* out0 f32 = rowscale * (acc + bias)                                    */
 #define PVRL_EPI_DGELU 5     /* out0 bf16 = rowscale * acc * GELU_erf'(aux_bf16)   (MLP backward)     */
 #define PVRL_EPI_DQGELU 6    /* out0 bf16 = rowscale * acc * QuickGELU'(aux_bf16)                     */
+#define PVRL_EPI_RESID_16 7  /* out0 bf16 = aux + rowscale * (acc + bias) + bias2: the residual add on the 16-bit patch rows of the
+                              * split residual stream (pvrl_rows); aux bf16 [M, aux_ld], or -- aux_rowmod != 0 -- the fp32 table
+                              * aux_f32[m % rowmod] of the embedding prologue (vit.py:370-407)            */
 
 /* The 16-bit operand type this library was built with: 0 = bf16 (libpvrl_hip.so), 1 = fp16 (libpvrl_hip_f16.so, built
  * with -DPVRL_OPERAND_F16).  Wherever an entry point below says "bf16" (names, PVRL_EPI_BF16, comments) read "the
@@ -140,6 +143,25 @@ int pvrl_layernorm_bwd(const void* dy, int64_t lddy, int dy_is_f32, const float*
                        int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16, int64_t ldxs, const float* dxs_scale,
                        int64_t dxs_rows, float* dxsum, const float* gscale, float* nonfinite, void* stream);
 
+/* SPLIT residual stream (round 6).  The TimeSformer engine keeps the PATCH rows of the residual stream x (vit.py:129-157: the `x`
+ * every Block.forward reads and returns) and of its gradient in the 16-bit operand type and the B cls rows in fp32: a matrix of M rows
+ * is then two matrices -- rows [0, rows16) in `lo` (16-bit, row stride ldlo), rows [rows16, M) in `hi` (fp32, row stride ldhi; its row 0
+ * is row rows16).  rows16 = 0: the plain fp32 matrix of pvrl_layernorm_fwd / _bwd, which are these entry points with that split.
+ * _bwd_split: x, dx_in and dx_out share ONE rows16; a null part of dx_in reads as zeros. */
+typedef struct pvrl_rows {
+  void* lo; int64_t ldlo;
+  void* hi; int64_t ldhi;
+  int64_t rows16;
+} pvrl_rows;
+int pvrl_layernorm_fwd_split(const void* x16, int64_t ldx16, int64_t rows16, const float* x, int64_t ldx, const float* gamma,
+                             const float* beta, float eps, void* y, int64_t ldy, int out_is_f32, float* mean, float* rstd,
+                             int64_t M, int64_t C, void* stream);
+int pvrl_layernorm_bwd_split(const void* dy, int64_t lddy, int dy_is_f32, const pvrl_rows* x, const float* mean, const float* rstd,
+                             const float* gamma, const pvrl_rows* dx_in, const pvrl_rows* dx_out, float beta_acc, float* dgamma,
+                             float* dbeta, void* workspace, int64_t workspace_bytes, int64_t M, int64_t C, void* dxs_bf16,
+                             int64_t ldxs, const float* dxs_scale, int64_t dxs_rows, float* dxsum, const float* gscale,
+                             float* nonfinite, void* stream);
+
 /* pvrl_layernorm_bwd with dgamma = dbeta = null leaves its per-workgroup partial sums in `workspace` (the caller keeps that workspace
  * to itself) instead of reducing them; this entry point then reduces the partials of MANY LayerNorms in one launch -- an encoder backward
  * has 37, each otherwise followed by its own 7-us reduce: dgamma = beta * dgamma + gscale * sum, dbeta likewise, dxsum with beta_sum. */
@@ -206,6 +228,8 @@ int pvrl_frames_u8_to_f32(const void* frames, const int32_t* params, int64_t B, 
 int pvrl_embed_table(const float* pos, const float* time, const float* bias, float* E, int64_t N, int64_t T, int64_t C,
                      void* stream);
 int pvrl_batch_sum(const float* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream);
+/* ... over the 16-bit patch rows of the split residual gradient stream (pvrl_rows), fp32 sums */
+int pvrl_batch_sum_bf16(const void* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream);
 /* out bf16 = rowscale[m] * in fp32 (DropPath scaling lib/models/vit_utils.py:140-155; bf16 operand casts). */
 int pvrl_cast_scale_bf16(const float* in, int64_t ldi, const float* rowscale, void* out, int64_t ldo, int64_t M,
                          int64_t C, void* stream);

@@ -30,7 +30,7 @@ def operand_torch_dtype():
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "void**": ctypes.c_void_p,
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int*": ctypes.c_void_p, "const void**": ctypes.c_void_p, "const float**": ctypes.c_void_p, "float**": ctypes.c_void_p,
-    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p, "const pvrl_ln_reduce*": ctypes.c_void_p,
+    "const pvrl_tn_problem*": ctypes.c_void_p, "const pvrl_cast_problem*": ctypes.c_void_p, "const pvrl_nt_problem*": ctypes.c_void_p, "const pvrl_ln_reduce*": ctypes.c_void_p, "const pvrl_rows*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -81,6 +81,12 @@ class LnReduce(ctypes.Structure):
     _fields_ = [("part", ctypes.c_void_p), ("M", ctypes.c_int64), ("C", ctypes.c_int64), ("want_sum", ctypes.c_int),
                 ("beta", ctypes.c_float), ("beta_sum", ctypes.c_float), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
                 ("dxsum", ctypes.c_void_p)]
+
+
+class Rows(ctypes.Structure):
+    """`pvrl_rows` of include/pvrl.h: rows [0, rows16) in the 16-bit matrix `lo`, the rest in the fp32 matrix `hi`"""
+    _fields_ = [("lo", ctypes.c_void_p), ("ldlo", ctypes.c_int64), ("hi", ctypes.c_void_p), ("ldhi", ctypes.c_int64),
+                ("rows16", ctypes.c_int64)]
 
 
 class CastProblem(ctypes.Structure):

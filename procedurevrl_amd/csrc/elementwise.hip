@@ -157,6 +157,25 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
   }
 }
 
+// the same over 16-bit rows (the patch rows of the split residual gradient stream, round 6), fp32 sums
+__global__ __launch_bounds__(256) void batch_sum16_kernel(const op_t* __restrict__ dx, long ld, int B, int rows, int C,
+                                                          float* __restrict__ G) {
+  const int c8n = C >> 3;
+  const long total = (long)rows * c8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long r = idx / c8n;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, d = a;
+    for (int b = 0; b < B; ++b) {
+      const opx8 v = *reinterpret_cast<const opx8*>(dx + ((long)b * rows + r) * ld + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] += (float)v[e]; d[e] += (float)v[4 + e]; }
+    }
+    *reinterpret_cast<f32x4*>(G + r * C + c8 * 8) = a;
+    *reinterpret_cast<f32x4*>(G + r * C + c8 * 8 + 4) = d;
+  }
+}
+
 // out bf16[m][c] = rowscale[m] * in fp32[m][c]
 __global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict__ in, long ldi,
                                                          const float* __restrict__ rowscale, op_t* __restrict__ out,
@@ -402,6 +421,14 @@ extern "C" int pvrl_embed_table(const float* pos, const float* time, const float
 extern "C" int pvrl_batch_sum(const float* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream) {
   if (!dx || !G || (C % 4) || (ld % 4)) return PVRL_EINVAL;
   hipLaunchKernelGGL(batch_sum_kernel, dim3(grid_for(rows * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dx,
+                     (long)ld, (int)B, (int)rows, (int)C, G);
+  PVRL_LAUNCH_CHECK();
+  return PVRL_OK;
+}
+
+extern "C" int pvrl_batch_sum_bf16(const void* dx, int64_t ld, int64_t B, int64_t rows, int64_t C, float* G, void* stream) {
+  if (!dx || !G || (C % 8) || (ld % 8)) return PVRL_EINVAL;
+  hipLaunchKernelGGL(batch_sum16_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const op_t*)dx,
                      (long)ld, (int)B, (int)rows, (int)C, G);
   PVRL_LAUNCH_CHECK();
   return PVRL_OK;

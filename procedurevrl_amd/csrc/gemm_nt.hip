@@ -206,7 +206,8 @@ int launch_nt(const GemmNT& p, hipStream_t s) {
   if (nt_wide_enabled() && p.N == 768 && p.M >= 4096 && p.M < 20000) return launch_tile<EPI, 2, 6>(p, s);   // MViT stage 4 (M = 12,576): 99 tiles of 128 x 384 x 2 fill 198 CUs; 256 x 256 tiles 150 (-10 %)
   if (p.M >= 4096 && p.N % 256 == 0) {
     // persistent 8-wave ping-pong kernel (gemm_nt8_core.h); its load stream runs two K-tiles ahead, so K >= 128
-    if (nt8_enabled() && p.K >= 2 * BK) return launch_nt8<EPI>(p, s);
+    // (the fp32-table form of PVRL_EPI_RESID_16 -- the embedding prologue, one launch per step -- lives in the one-tile kernel only)
+    if (nt8_enabled() && p.K >= 2 * BK && !(EPI == PVRL_EPI_RESID_16 && p.aux_rowmod != 0)) return launch_nt8<EPI>(p, s);
     return launch_tile<EPI, 4, 4>(p, s);
   }
   // N = 384 / 1152 and 640 at M >= 100k rows (MViTv2-S stages 1-2): one 128 x 384 / 128 x 320 tile row instead of three / five 128 x 128
@@ -227,11 +228,11 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
                                  const void* aux, int64_t aux_ld, int64_t aux_rowmod, void* out0, int64_t ld0,
                                  void* out1, int64_t ld1, const float* bias2, void* stream) {
   if (M <= 0) return PVRL_OK;
-  if (bias2 && epilogue != PVRL_EPI_RESID_F32) return PVRL_EINVAL;
+  if (bias2 && epilogue != PVRL_EPI_RESID_F32 && epilogue != PVRL_EPI_RESID_16) return PVRL_EINVAL;
   if (!A || !W || !out0 || N <= 0 || K <= 0 || (N % 128) || (K % BK)) return PVRL_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ld0 % 8)) return PVRL_EINVAL;
   if ((epilogue == PVRL_EPI_GELU || epilogue == PVRL_EPI_QGELU) && (!out1 || (ld1 % 8))) return PVRL_EINVAL;
-  if ((epilogue == PVRL_EPI_RESID_F32 || epilogue == PVRL_EPI_DGELU || epilogue == PVRL_EPI_DQGELU) &&
+  if ((epilogue == PVRL_EPI_RESID_F32 || epilogue == PVRL_EPI_RESID_16 || epilogue == PVRL_EPI_DGELU || epilogue == PVRL_EPI_DQGELU) &&
       (!aux || (aux_ld % 8)))
     return PVRL_EINVAL;
   GemmNT p;
@@ -249,6 +250,7 @@ extern "C" int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     case PVRL_EPI_F32: return launch_nt<PVRL_EPI_F32>(p, s);
     case PVRL_EPI_DGELU: return launch_nt<PVRL_EPI_DGELU>(p, s);
     case PVRL_EPI_DQGELU: return launch_nt<PVRL_EPI_DQGELU>(p, s);
+    case PVRL_EPI_RESID_16: return launch_nt<PVRL_EPI_RESID_16>(p, s);
     default: return PVRL_EINVAL;
   }
 }

@@ -111,7 +111,10 @@ template <int AUX, typename T> __device__ __forceinline__ T bld16(rsrc_t r, unsi
 //   c0, c1  first column (inside the tile) of the block's two 32-column groups: wn * 64, wn * 64 + 32 for the 16-wave kernel;
 //           32 wn and 128 + 32 wn for the 8-wave kernel, whose wave columns are split over the two W half-tiles
 //   BATCH   row tiles whose residual / stored pre-activation loads go out together (one memory round trip per batch)
-template <int EPI, int BATCH = 2>
+//   TAB     PVRL_EPI_RESID_16 only: aux is the fp32 row-modulo table of the embedding prologue, not 16-bit residual rows (a template
+//           parameter chosen once per tile by nt_epilogue_sel: the two forms share no load, and a load behind a run-time branch is
+//           followed by a full wait)
+template <int EPI, int BATCH = 2, bool TAB = false>
 __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int rb, int c0, int c1, int lane) {
   constexpr bool F32OUT = (EPI == PVRL_EPI_RESID_F32 || EPI == PVRL_EPI_F32);
   constexpr int ST = PVRL_NT_ST_AUX, LD = PVRL_NT_LD_AUX;
@@ -204,13 +207,32 @@ __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][
     for (int mt = 0; mt < 4; ++mt) rs4[mt] = p.rowscale ? p.rowscale[min(m0 + rb + mt * 16 + i, p.M - 1)] : 1.f;
     constexpr bool TWO = EPI == PVRL_EPI_GELU || EPI == PVRL_EPI_QGELU;
     constexpr bool DACT = EPI == PVRL_EPI_DGELU || EPI == PVRL_EPI_DQGELU;
+    // PVRL_EPI_RESID_16 (round 6): the residual add on the 16-bit patch rows of the split residual stream -- out = aux + rs * (acc +
+    // bias) + bias2, aux and out 16-bit: 16 B per lane and column group each way where the fp32-residual epilogue moves 2 x 32 B
+    // (231 MB less per 50k-row launch).  aux_rowmod != 0: aux is the fp32 pos / time table of the embedding prologue instead (one
+    // launch per step: its loads go out row tile by row tile).
+    constexpr bool RES16 = EPI == PVRL_EPI_RESID_16;
+    constexpr bool tab = RES16 && TAB;
+    float b2lane = 0.f;      // the second bias: each lane keeps ONE column of the block's 64, the others come by ds_bpermute (see above)
+    if constexpr (RES16) {
+      if (p.bias2) {
+        b2lane = p.bias2[n0 + (lane < 32 ? c0 + lane : c1 + lane - 32)];
+        if (!p.rowscale) {                 // no row factor: rs * (acc + bias) + bias2 = acc + (bias + bias2)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[c][e] += __shfl(b2lane, 32 * c + 8 * q + e, 64);
+        }
+      }
+    }
+    const bool b2_late = RES16 && p.bias2 && p.rowscale;
     const rsrc_t r0 = tile_rsrc(p.out0, m0, p.ld0, 2, rows);
     const rsrc_t r1 = TWO ? tile_rsrc(p.out1, m0, p.ld1, 2, rows) : r0;
-    const rsrc_t ra = DACT ? tile_rsrc(p.aux, m0, p.aux_ld, 2, rows) : r0;
+    const rsrc_t ra = (DACT || RES16) ? (tab ? tile_rsrc(p.aux, 0, p.aux_ld, 4, p.aux_rowmod) : tile_rsrc(p.aux, m0, p.aux_ld, 2, rows)) : r0;
 #pragma unroll
     for (int bt = 0; bt < 4 / BATCH; ++bt) {
       opx8 uv[BATCH][2];
-      if constexpr (DACT) {   // the stored pre-activations of BATCH row tiles: one round trip
+      if constexpr ((DACT || RES16) && !tab) {   // the stored pre-activations / the 16-bit residual rows of BATCH row tiles: one round trip
 #pragma unroll
         for (int h = 0; h < BATCH; ++h) {
           const unsigned ab = (unsigned)(rb + (BATCH * bt + h) * 16 + i) * (unsigned)p.aux_ld * 2u;
@@ -254,6 +276,27 @@ __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][
             }
             bst16<ST>(r0, o0off, u0);
             bst16<ST>(r1, ml * (unsigned)p.ld1 * 2u + (unsigned)ncol[c] * 2u, g0);
+          } else if constexpr (RES16) {
+            float a[8];
+            if constexpr (tab) {
+              const int mr = (min(m0 + (int)ml, p.M - 1) + p.m_off) % p.aux_rowmod;
+              const unsigned ab = (unsigned)mr * (unsigned)p.aux_ld * 4u + (unsigned)ncol[c] * 4u;
+              const f32x4 t0 = bld16<0, f32x4>(ra, ab), t1 = bld16<0, f32x4>(ra, ab + 16u);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { a[e] = t0[e]; a[4 + e] = t1[e]; }
+            } else {
+              const opx8 ua = uv[h][c];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = (float)ua[e];
+            }
+            if (b2_late) {          // (one branch, its eight ds_bpermute in flight together)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] += __shfl(b2lane, 32 * c + 8 * q + e, 64);
+            }
+            opx8 o0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o0[e] = (op_t)(rs * v[e] + a[e]);
+            bst16<ST>(r0, o0off, o0);
           } else {  // PVRL_EPI_DGELU / PVRL_EPI_DQGELU : out = rs * acc * act'(u)
             const opx8 ua = uv[h][c];
             opx8 o0;
@@ -271,9 +314,17 @@ __device__ __forceinline__ void nt_epilogue_at(const GemmNT& p, f32x4 (&acc)[4][
 }
 
 // the 16-wave kernels' form: wave (wm, wn) owns rows [64 wm, +64) x columns [64 wn, +64) of its tile
+// picks the table form of PVRL_EPI_RESID_16 (a kernel-uniform choice)
+template <int EPI, int BATCH>
+__device__ __forceinline__ void nt_epilogue_sel(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int rb, int c0, int c1, int lane) {
+  if constexpr (EPI == PVRL_EPI_RESID_16) {
+    if (p.aux_rowmod != 0) { nt_epilogue_at<EPI, BATCH, true>(p, acc, m0, n0, rb, c0, c1, lane); return; }
+  }
+  nt_epilogue_at<EPI, BATCH, false>(p, acc, m0, n0, rb, c0, c1, lane);
+}
 template <int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
-  nt_epilogue_at<EPI, 2>(p, acc, m0, n0, wm * 64, wn * 64, wn * 64 + 32, lane);
+  nt_epilogue_sel<EPI, 2>(p, acc, m0, n0, wm * 64, wn * 64, wn * 64 + 32, lane);
 }
 
 // ---- the ragged last round (256x256 tiles only) --------------------------------------------------------------------

@@ -64,6 +64,13 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_nt_skinny_kernel(GemmNT p) {
       float v = rs * (s + b) + reinterpret_cast<const float*>(p.aux)[ar * p.aux_ld + n];
       if (p.bias2 && p.rowscale) v += p.bias2[n];
       reinterpret_cast<float*>(p.out0)[(long)m * p.ld0 + n] = v;
+    } else if constexpr (EPI == PVRL_EPI_RESID_16) {
+      if (p.bias2 && !p.rowscale) b += p.bias2[n];
+      const float a = p.aux_rowmod ? reinterpret_cast<const float*>(p.aux)[(long)((m + p.m_off) % p.aux_rowmod) * p.aux_ld + n]
+                                   : (float)reinterpret_cast<const op_t*>(p.aux)[(long)m * p.aux_ld + n];
+      float v = rs * (s + b) + a;
+      if (p.bias2 && p.rowscale) v += p.bias2[n];
+      reinterpret_cast<op_t*>(p.out0)[(long)m * p.ld0 + n] = (op_t)v;
     } else if constexpr (EPI == PVRL_EPI_F32) {
       reinterpret_cast<float*>(p.out0)[(long)m * p.ld0 + n] = rs * (s + b);
     } else if constexpr (EPI == PVRL_EPI_BF16) {

@@ -183,6 +183,34 @@ class _W:
         self.be = None      # fused temporal map only: fp32 [N] bias W_fc b_proj
 
 
+class _X:
+    """One stage of the encoder's residual stream (or of its gradient): patch rows `p` [R, C], cls rows `c` [B, C] fp32.
+    Split stream (EncoderEngine.resid16, round 6): `p` is its own tensor in the 16-bit operand type -- GEMM residual epilogues
+    (PVRL_EPI_RESID_16) read and write it, the LayerNorm kernels take the two parts as one matrix (ops.SplitRows / pvrl_rows).
+    Otherwise `p` and `c` are views of ONE fp32 buffer `full` [R + B, C] (rounds 1-5)."""
+    __slots__ = ("p", "c", "full")
+
+    def __init__(self, p, c, full=None):
+        self.p, self.c, self.full = p, c, full
+
+    @staticmethod
+    def new(R, B, C, device, split, zero=False, zero_p=True):
+        mk = torch.zeros if zero else torch.empty
+        if split:
+            return _X((mk if zero_p else torch.empty)((R, C), device=device, dtype=OP16), mk((B, C), device=device, dtype=F32))
+        full = mk((R + B, C), device=device, dtype=F32)
+        return _X(full[:R], full[R:], full)
+
+    def all(self, p_zero=False):
+        """every row, as the LayerNorm entry points take it (`p_zero`: the patch rows are known to be zero and are not read)"""
+        if self.full is not None:
+            return self.full
+        return ops.SplitRows(None if p_zero else self.p, self.c, n_lo=self.p.shape[0])
+
+    def patch(self):
+        return self.p if self.full is not None else ops.SplitRows(self.p, None)
+
+
 class GraphReplay:
     """HIP-graph replay of an encoder engine's training / inference step.
 
@@ -409,6 +437,11 @@ class EncoderEngine(GraphReplay):
         # tokens of every clip there.  Same features, loss and gradients; PVRL_PRUNE_LAST=0: A/B runs.
         self.prune_last = os.environ.get("PVRL_PRUNE_LAST", "1") == "1"
         self.prune_attn = os.environ.get("PVRL_PRUNE_ATTN", "1") == "1"     # ... and its spatial attention the cls query only (attn_cls.hip)
+        # SPLIT residual stream (round 6): the patch rows of x and of its gradient dx live in the 16-bit operand type between kernels,
+        # the B cls rows stay fp32 -- per block 18 passes over the 50k token rows move 77 instead of 154 MB.  What it costs in error is
+        # what the rounding-model oracle says (profiles/r6_resid16_rounding.txt: logits 2.84e-4 -> 2.96e-4, worst gradient 1.09e-3 ->
+        # 1.16e-3 at 12 blocks, fp16 operands).  PVRL_RESID16=0: the fp32 stream of rounds 1-5 (A/B runs).
+        self.resid16 = os.environ.get("PVRL_RESID16", "1") == "1"
         self._wq = []
         self._wpost = []
         self._side_keep = []
@@ -768,10 +801,11 @@ class EncoderEngine(GraphReplay):
             a_pe = ops.patchify(frames.contiguous())
         pos, tim = self._pos_time(N, T, Wp)
         E = ops.embed_table(pos, tim, m.patch_embed.proj.bias.detach(), N, T)
-        x = torch.empty((M, C), device=dev, dtype=F32)
+        x = _X.new(R, B, C, dev, self.resid16)
+        sv["split"] = self.resid16
         wpe = self._weight(m.patch_embed.proj.weight, need_t=False)
-        ops.gemm_nt(a_pe, wpe.w, L.PVRL_EPI_RESID_F32, aux=E, aux_rowmod=N * T, out0=x[:R])
-        x[R:] = (m.cls_token.detach()[0, 0] + pos[0]).unsqueeze(0)
+        ops.gemm_nt(a_pe, wpe.w, self._epi_resid(), aux=E, aux_rowmod=N * T, out0=x.p)
+        x.c[:] = (m.cls_token.detach()[0, 0] + pos[0]).unsqueeze(0)
         sv["a_pe"] = a_pe if save else None
 
         if droppath is None:
@@ -779,7 +813,7 @@ class EncoderEngine(GraphReplay):
         for i, blk in enumerate(m.blocks):
             x = self._block_fwd(blk, x, sv, droppath[i], save, last=i == len(m.blocks) - 1)
 
-        feat, mean, rstd = ops.layernorm_fwd(x[R:], m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
+        feat, mean, rstd = ops.layernorm_fwd(x.c, m.norm.weight.detach(), m.norm.bias.detach(), self.eps,
                                              out_dtype=F32)
         self._refreshed = False
         if save:
@@ -788,13 +822,30 @@ class EncoderEngine(GraphReplay):
             self.saved = sv
         return feat
 
+    def stream_from_rows(self, x_rows, B):
+        """fp32 [B*N*T + B, C] (patch rows, then cls rows) -> a stage of the residual stream as this engine keeps it (tests / probes)"""
+        R = x_rows.shape[0] - B
+        if not self.resid16:
+            full = x_rows.contiguous()
+            return _X(full[:R], full[R:], full)
+        return _X(x_rows[:R].to(OP16).contiguous(), x_rows[R:].contiguous())
+
+    @staticmethod
+    def stream_to_rows(x):
+        return x.full if x.full is not None else torch.cat([x.p.float(), x.c], 0)
+
+    def _epi_resid(self):
+        L = lib()
+        return L.PVRL_EPI_RESID_16 if self.resid16 else L.PVRL_EPI_RESID_F32
+
     def _block_fwd(self, blk, x0, sv, dp, save, last=False):
         """`last`: the encoder's last block (with prune_last: the patch rows of x2 / x3 are neither computed nor defined)"""
         prune = last and self.prune_last
         L = lib()
         B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
         C, H = self.C, self.H
-        dev = x0.device
+        dev = x0.c.device
+        split, epi_res = sv["split"], self._epi_resid()
         s1_tok = dp["s1_tok"] if dp else None
         s2_seq = dp["s2_seq"] if dp else None
         s2_tok = dp["s2_tok"] if dp else None
@@ -802,7 +853,7 @@ class EncoderEngine(GraphReplay):
         P = lambda t: t.detach()
 
         # ---- temporal branch (vit.py:129-135), rows [0, R) ----
-        h_t, mean_t, rstd_t = ops.layernorm_fwd(x0[:R], P(blk.temporal_norm1.weight), P(blk.temporal_norm1.bias), self.eps)
+        h_t, mean_t, rstd_t = ops.layernorm_fwd(x0.patch(), P(blk.temporal_norm1.weight), P(blk.temporal_norm1.bias), self.eps)
         qkv_t = ops.gemm_nt(h_t, self._weight(blk.temporal_attn.qkv.weight).w, L.PVRL_EPI_BF16,
                             bias=P(blk.temporal_attn.qkv.bias))
         lse_t = None
@@ -810,17 +861,21 @@ class EncoderEngine(GraphReplay):
             o_t = ops.attn_t8_fwd(qkv_t, B * N, H, self.scale)
         else:
             o_t, _, lse_t = ops.attn_fwd(qkv_t, B * N, T, H, self.scale, mode=0)
-        x1 = torch.empty_like(x0)
+        if split:       # the cls rows pass the temporal branch unchanged: the same tensor (nothing writes a stage's rows twice)
+            x1 = _X(torch.empty_like(x0.p), x0.c)
+        else:
+            x1 = _X.new(R, B, C, dev, False)
         fe = self._fused_temporal(blk)          # proj then temporal_fc as one linear map
         ev = self._fe_events.pop(id(blk), None)
         if ev is not None:                      # W_e of this block was built on the side stream (_prefetch_fused_temporal)
             torch.cuda.current_stream().wait_event(ev)
-        ops.gemm_nt(o_t, fe.w, L.PVRL_EPI_RESID_F32, bias=fe.be, rowscale=s1_tok, bias2=P(blk.temporal_fc.bias),
-                    aux=x0[:R], out0=x1[:R])
-        x1[R:] = x0[R:]
+        ops.gemm_nt(o_t, fe.w, epi_res, bias=fe.be, rowscale=s1_tok, bias2=P(blk.temporal_fc.bias),
+                    aux=x0.p, out0=x1.p)
+        if not split:
+            x1.c[:] = x0.c
 
         # ---- spatial branch (vit.py:137-151), all rows; cls of clip b is token 0 of its T sequences ----
-        h_s, mean_s, rstd_s = ops.layernorm_fwd(x1, P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
+        h_s, mean_s, rstd_s = ops.layernorm_fwd(x1.all(), P(blk.norm1.weight), P(blk.norm1.bias), self.eps)
         o_s = torch.empty((R + B * T, C), device=dev, dtype=OP16)
         cls_attn = prune and self.prune_attn
         wqkv = self._weight(blk.attn.qkv.weight).w
@@ -835,44 +890,48 @@ class EncoderEngine(GraphReplay):
         else:
             qkv_s = ops.gemm_nt(h_s, wqkv, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
             _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
-        x2 = torch.empty_like(x0)
+        x2 = _X.new(R, B, C, dev, split)      # (pruned last block: its patch rows are neither computed nor defined)
         wproj = self._weight(blk.attn.proj.weight).w
         if not prune:
-            ops.gemm_nt(o_s[:R], wproj, L.PVRL_EPI_RESID_F32, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1[:R],
-                        out0=x2[:R])
+            ops.gemm_nt(o_s[:R], wproj, epi_res, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1.p, out0=x2.p)
         if self.cls_fp32:
             # the cls rows' own chain in fp32 on the master weights (csrc/cls_chain.hip): the projection is linear, so the mean over
             # the T frames (vit.py:147-149) is taken first -- B rows instead of B * T
             om = ops.group_reduce(o_s[R:], B, T, scale=s2_seq, alpha=1.0 / T)
             ops.cls_linear(om, P(blk.attn.proj.weight), P(blk.attn.proj.bias), biasscale=dp["s2_mean"] if dp else None,
-                           aux=x1[R:], out=x2[R:])
+                           aux=x1.c, out=x2.c)
         else:
             pc = ops.gemm_nt(o_s[R:], wproj, L.PVRL_EPI_F32, bias=P(blk.attn.proj.bias))
-            ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1[R:], out=x2[R:])
+            ops.group_reduce(pc, B, T, scale=s2_seq, alpha=1.0 / T, resid=x1.c, out=x2.c)
 
         # ---- MLP (vit.py:155-157) ----
-        x3 = torch.empty_like(x0)
+        x3 = _X.new(R, B, C, dev, split)
         s3c = s3_all[R:] if s3_all is not None else None
+        w2 = self._weight(blk.mlp.fc2.weight).w
         if prune:
             # the B cls rows only; h_m / st_m / u / g are then [B, .] tensors (what the backward of this block reads, _block_bwd)
             h_m = mean_m = rstd_m = u = g = None
             if save or not self.cls_fp32:
-                h_m, mean_m, rstd_m = ops.layernorm_fwd(x2[R:], P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
+                h_m, mean_m, rstd_m = ops.layernorm_fwd(x2.c, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
                 u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
             if not self.cls_fp32:
-                ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
-                            rowscale=s3c, aux=x2[R:], out0=x3[R:])
+                ops.gemm_nt(g, w2, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias), rowscale=s3c, aux=x2.c, out0=x3.c)
         else:
-            h_m, mean_m, rstd_m = ops.layernorm_fwd(x2, P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
+            h_m, mean_m, rstd_m = ops.layernorm_fwd(x2.all(), P(blk.norm2.weight), P(blk.norm2.bias), self.eps)
             u, g = ops.gemm_nt(h_m, self._weight(blk.mlp.fc1.weight).w, L.PVRL_EPI_GELU, bias=P(blk.mlp.fc1.bias))
-            ops.gemm_nt(g, self._weight(blk.mlp.fc2.weight).w, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias),
-                        rowscale=s3_all, aux=x2, out0=x3)
+            if split:       # the patch rows with the 16-bit residual epilogue; the cls rows are the fp32 chain's below (or their own GEMM)
+                ops.gemm_nt(g[:R], w2, epi_res, bias=P(blk.mlp.fc2.bias), rowscale=s3_all[:R] if s3_all is not None else None,
+                            aux=x2.p, out0=x3.p)
+                if not self.cls_fp32:
+                    ops.gemm_nt(g[R:], w2, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias), rowscale=s3c, aux=x2.c, out0=x3.c)
+            else:
+                ops.gemm_nt(g, w2, L.PVRL_EPI_RESID_F32, bias=P(blk.mlp.fc2.bias), rowscale=s3_all, aux=x2.full, out0=x3.full)
         if self.cls_fp32:       # (the 16-bit path's cls rows of h_m / u / g stay what the backward reads; x3's are replaced)
-            hc, _, _ = ops.layernorm_fwd(x2[R:], P(blk.norm2.weight), P(blk.norm2.bias), self.eps, out_dtype=F32,
+            hc, _, _ = ops.layernorm_fwd(x2.c, P(blk.norm2.weight), P(blk.norm2.bias), self.eps, out_dtype=F32,
                                          save_stats=False)
             gc = ops.cls_linear(hc, P(blk.mlp.fc1.weight), P(blk.mlp.fc1.bias), gelu=True)
-            ops.cls_linear(gc, P(blk.mlp.fc2.weight), P(blk.mlp.fc2.bias), rowscale=s3c, biasscale=s3c, aux=x2[R:],
-                           out=x3[R:])
+            ops.cls_linear(gc, P(blk.mlp.fc2.weight), P(blk.mlp.fc2.bias), rowscale=s3c, biasscale=s3c, aux=x2.c,
+                           out=x3.c)
         if save:
             sv["blocks"].append(dict(x0=x0, x1=x1, x2=x2, h_t=h_t, st_t=(mean_t, rstd_t), qkv_t=qkv_t, o_t=o_t,
                                      lse_t=lse_t, h_s=h_s, st_s=(mean_s, rstd_s), qkv_s=qkv_s, o_s=o_s,
@@ -942,25 +1001,36 @@ class EncoderEngine(GraphReplay):
         self._ln_defer = []
         if SCALED_GRADS:
             dfeat = gs.begin_scaled(dfeat)
-        dx = torch.zeros((M, self.C), device=dfeat.device, dtype=F32)
+        last = len(m.blocks) - 1
+        pruned = bool(sv["blocks"][last].get("pruned"))
+        split = sv["split"]
+        # the residual gradient stream: zero outside the cls rows until the last block's spatial branch.  Split stream + pruned last
+        # block: the patch rows are not even cleared -- the first kernel that would read them (that block's norm1 backward) takes them
+        # as zeros (`dxp_zero`)
+        dxp_zero = split and pruned
+        dx = _X.new(R, M - R, self.C, dfeat.device, split, zero=True, zero_p=not dxp_zero)
         mean, rstd = sv["norm_stats"]
         (dg, bg), (db, bb) = gs.target(m.norm.weight, fused=True), gs.target(m.norm.bias, fused=True)
-        ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"][R:], mean, rstd, m.norm.weight.detach(), dg, db,
-                          dx_out=dx[R:], beta_acc=bg, gscale=gs.inv, nonfinite=gs.bad)
+        ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"].c, mean, rstd, m.norm.weight.detach(), dg, db,
+                          dx_out=dx.c, beta_acc=bg, gscale=gs.inv, nonfinite=gs.bad)
         # dy = bf16(DropPath-scale * dx) is the operand of each block's first backward GEMMs; after the first block it is
         # emitted by the previous block's last LayerNorm-backward kernel instead of a separate cast pass.
-        last = len(m.blocks) - 1
         s3 = sv["blocks"][last]["dp"]["s3_all"] if sv["blocks"][last]["dp"] else None
-        if sv["blocks"][last].get("pruned"):      # dx is zero outside the cls rows here: the last block's MLP / projection backward
-            dy = ops.cast_scale(dx[R:], s3[R:] if s3 is not None else None)     # runs on those rows alone (_block_bwd)
+        if pruned:                                # dx is zero outside the cls rows here: the last block's MLP / projection backward
+            dy = ops.cast_scale(dx.c, s3[R:] if s3 is not None else None)       # runs on those rows alone (_block_bwd)
+        elif split:
+            dy = torch.zeros((M, self.C), device=dfeat.device, dtype=OP16)
+            ops.cast_scale(dx.c, s3[R:] if s3 is not None else None, out=dy[R:])
         else:
-            dy = ops.cast_scale(dx, s3)
-        return dict(sv=sv, gs=gs, dx=dx, dy=dy)
+            dy = ops.cast_scale(dx.full, s3)
+        return dict(sv=sv, gs=gs, dx=dx, dy=dy, dxp_zero=dxp_zero)
 
     def _bwd_block(self, st, i):
         sv = st["sv"]
         nxt = sv["blocks"][i - 1]["dp"] if i > 0 else None
-        st["dy"] = self._block_bwd(self.m.blocks[i], sv["blocks"][i], sv, st["dx"], st["gs"], st["dy"], i > 0, nxt)
+        st["dy"] = self._block_bwd(self.m.blocks[i], sv["blocks"][i], sv, st["dx"], st["gs"], st["dy"], i > 0, nxt,
+                                   dxp_zero=st.get("dxp_zero", False))
+        st["dxp_zero"] = False
         sv["blocks"][i] = None  # free activations as we go
 
     def _bwd_end(self, st):
@@ -972,8 +1042,8 @@ class EncoderEngine(GraphReplay):
         w = m.patch_embed.proj.weight
         (dw, bw), (dbias, _) = gs.target(w, fused=True), gs.target(m.patch_embed.proj.bias, fused=True)
         self._wgrad(dz, sv["a_pe"], dw.view(C, -1), dbias, bw, gscale=gs.inv, nonfinite=gs.bad)
-        G = ops.batch_sum(dx[:R], B, N * T).view(N, T, C)
-        dcls_rows = dx[R:].sum(0)
+        G = ops.batch_sum(dx.p, B, N * T).view(N, T, C)
+        dcls_rows = dx.c.sum(0)
         if gs.inv is not None:       # the three small embedding gradients below are sums of these: the scale is taken out here
             G = G * gs.inv           # (a non-finite value in dx reaches the patch-embed weight gradient above, which raises gs.bad)
             dcls_rows = dcls_rows * gs.inv
@@ -1001,11 +1071,11 @@ class EncoderEngine(GraphReplay):
         else:
             tgt.add_(g.view_as(tgt))
 
-    def _block_bwd(self, blk, s, sv, dx, gs, dy, has_prev, prev_dp):
+    def _block_bwd(self, blk, s, sv, dx, gs, dy, has_prev, prev_dp, dxp_zero=False):
         L = lib()
         B, T, N, R, M = sv["B"], sv["T"], sv["N"], sv["R"], sv["M"]
         C, H = self.C, self.H
-        dev = dx.device
+        dev = dx.c.device
         dp = s["dp"]
         s1_tok = dp["s1_tok"] if dp else None
         s2_seq = dp["s2_seq"] if dp else None
@@ -1040,8 +1110,8 @@ class EncoderEngine(GraphReplay):
             du = ops.gemm_nt(dy, self._weight(blk.mlp.fc2.weight).t, L.PVRL_EPI_DGELU, aux=s["u"])
             wq.append(wgrad_c(du, s["h_m"], blk.mlp.fc1))
             dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
-            lnbwd(dh, s["x2"][R:], s["st_m"], blk.norm2, dx[R:], dx[R:])
-            dpc = ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T)
+            lnbwd(dh, s["x2"].c, s["st_m"], blk.norm2, dx.c, dx.c)
+            dpc = ops.group_bcast(dx.c, B, T, scale=s2_seq, alpha=1.0 / T)
             wq.append(wgrad_c(dpc, s["o_s"][R:], blk.attn.proj))
             if not s.get("cls_attn"):
                 ops.gemm_tn_grouped(wq, ws_tag="tn_cls")
@@ -1059,10 +1129,10 @@ class EncoderEngine(GraphReplay):
             dh = ops.gemm_nt(du, self._weight(blk.mlp.fc1.weight).t, L.PVRL_EPI_BF16)
             del du
             dps = torch.empty((R + B * T, C), device=dev, dtype=OP16)
-            lnbwd(dh, s["x2"], s["st_m"], blk.norm2, dx, dx, dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
+            lnbwd(dh, s["x2"].all(), s["st_m"], blk.norm2, dx.all(), dx.all(), dxs=dps[:R], dxs_scale=s2_tok)   # also emits bf16(s2 * dx[:R])
 
             # ---- spatial ----
-            ops.group_bcast(dx[R:], B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
+            ops.group_bcast(dx.c, B, T, scale=s2_seq, alpha=1.0 / T, out=dps[R:])
             wgrad(dps, s["o_s"], blk.attn.proj)
             do = ops.gemm_nt(dps, self._weight(blk.attn.proj.weight).t, L.PVRL_EPI_BF16)
             del dps
@@ -1093,7 +1163,8 @@ class EncoderEngine(GraphReplay):
         # also emits dz = bf16(s1 * dx[:R]) and, into temporal_fc.bias.grad, the unscaled column sums of dx[:R]
         dz = torch.empty((R, C), device=dev, dtype=OP16)
         dbf, bbf = gs.target(blk.temporal_fc.bias, fused=True)
-        lnbwd(dh, s["x1"], s["st_s"], blk.norm1, dx, dx, dxs=dz, dxs_scale=s1_tok, dxsum=dbf, dxsum_beta=bbf)
+        lnbwd(dh, s["x1"].all(), s["st_s"], blk.norm1, dx.all(p_zero=dxp_zero), dx.all(), dxs=dz, dxs_scale=s1_tok, dxsum=dbf,
+              dxsum_beta=bbf)
 
         # ---- temporal (rows [0, R); cls rows pass straight through): proj + temporal_fc as ONE map W_e (_fused_temporal)
         fe = self._fused_temporal(blk)
@@ -1115,8 +1186,8 @@ class EncoderEngine(GraphReplay):
         # (previous block's MLP backward with that block's DropPath scale, or the patch-embed weight gradient)
         s3p = prev_dp["s3_all"] if (has_prev and prev_dp) else None
         dy_next = torch.empty((M if has_prev else R, C), device=dev, dtype=OP16)
-        lnbwd(dh, s["x0"][:R], s["st_t"], blk.temporal_norm1, dx[:R], dx[:R], dxs=dy_next[:R], dxs_scale=s3p)
+        lnbwd(dh, s["x0"].patch(), s["st_t"], blk.temporal_norm1, dx.patch(), dx.patch(), dxs=dy_next[:R], dxs_scale=s3p)
         if has_prev:
-            ops.cast_scale(dx[R:], s3p[R:] if s3p is not None else None, out=dy_next[R:])
+            ops.cast_scale(dx.c, s3p[R:] if s3p is not None else None, out=dy_next[R:])
         self.flush_wgrads()
         return dy_next

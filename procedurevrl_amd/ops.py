@@ -15,7 +15,7 @@ F32 = torch.float32
 
 # When set to a list, gemm launches are bracketed with events on the launch stream (bench.py roofline leg).
 KERNEL_TIMING = None
-_EPI_NAMES = {0: "op16", 1: "gelu", 2: "qgelu", 3: "resid_f32", 4: "f32", 5: "dgelu", 6: "dqgelu"}
+_EPI_NAMES = {0: "op16", 1: "gelu", 2: "qgelu", 3: "resid_f32", 4: "f32", 5: "dgelu", 6: "dqgelu", 7: "resid_16"}
 
 
 def _timed(name, flops, fn):
@@ -96,6 +96,8 @@ def gemm_nt(A, W, epi, bias=None, rowscale=None, aux=None, aux_rowmod=0, out0=No
     f32_out = epi in (L.PVRL_EPI_RESID_F32, L.PVRL_EPI_F32)
     if out0 is None:
         out0 = torch.empty((M, N), device=A.device, dtype=F32 if f32_out else OP16)
+    if out0.dtype != (F32 if f32_out else OP16) or (epi == L.PVRL_EPI_RESID_16 and aux.dtype != (F32 if aux_rowmod else OP16)):
+        raise PvrlError(f"gemm_nt epilogue {_EPI_NAMES[epi]}: out0 {out0.dtype}, aux {None if aux is None else aux.dtype}")
     two = epi in (L.PVRL_EPI_GELU, L.PVRL_EPI_QGELU)
     if two and out1 is None:
         out1 = torch.empty((M, N), device=A.device, dtype=OP16)
@@ -270,9 +272,52 @@ def gemm_tn_grouped(problems, ws_tag="tn_group"):
 # ----------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------
+class SplitRows:
+    """A matrix whose first rows live in a 16-bit tensor `lo` [rows16, C] and whose remaining rows in an fp32 tensor `hi` [M - rows16, C]
+    (`pvrl_rows`, include/pvrl.h): a stage of the encoder's split residual stream -- patch rows 16-bit, cls rows fp32.  Either part may
+    be None where an entry point allows it (a dx_in part that is known to be zero)."""
+    __slots__ = ("lo", "hi", "n_lo", "n_hi")
+
+    def __init__(self, lo, hi, n_lo=None, n_hi=None):
+        self.lo, self.hi = lo, hi
+        self.n_lo = lo.shape[0] if lo is not None else int(n_lo or 0)
+        self.n_hi = hi.shape[0] if hi is not None else int(n_hi or 0)
+        if lo is not None:
+            _chk2d(lo, OP16)
+        if hi is not None:
+            _chk2d(hi, F32)
+
+    @property
+    def shape(self):
+        t = self.lo if self.lo is not None else self.hi
+        return (self.n_lo + self.n_hi, t.shape[1])
+
+    @property
+    def device(self):
+        return (self.lo if self.lo is not None else self.hi).device
+
+    def c_rows(self):
+        from ._lib import Rows
+        r = Rows()
+        r.lo, r.ldlo = (self.lo.data_ptr(), _ld(self.lo)) if self.lo is not None else (None, 0)
+        r.hi, r.ldhi = (self.hi.data_ptr(), _ld(self.hi)) if self.hi is not None else (None, 0)
+        r.rows16 = self.n_lo
+        return r
+
+
 def layernorm_fwd(x, gamma, beta, eps, out_dtype=OP16, out=None, save_stats=True, stats=None):
-    """`stats` (optional): (mean, rstd) fp32 [M] tensors to write the row statistics into"""
+    """`stats` (optional): (mean, rstd) fp32 [M] tensors to write the row statistics into.  `x`: fp32 [M, C], or a SplitRows."""
     L = lib()
+    if isinstance(x, SplitRows):
+        M, C = x.shape
+        if out is None:
+            out = torch.empty((M, C), device=x.device, dtype=out_dtype)
+        mean = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+        rstd = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+        L.call("pvrl_layernorm_fwd_split", _ptr(x.lo), _ld(x.lo) if x.lo is not None else 0, x.n_lo, _ptr(x.hi),
+               _ld(x.hi) if x.hi is not None else 0, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ld(out),
+               1 if out.dtype == F32 else 0, _ptr(mean), _ptr(rstd), M, C, _stream())
+        return out, mean, rstd
     _chk2d(x, F32)
     M, C = x.shape
     if out is None:
@@ -295,6 +340,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
     `defer` (a list): the per-workgroup partial sums of dgamma / dbeta / dxsum stay in a private workspace and an entry is appended
     for `layernorm_bwd_reduce_batched`, which reduces many LayerNorms' partials in one launch."""
     L = lib()
+    if isinstance(x, SplitRows):
+        return _layernorm_bwd_split(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in, dx_out, beta_acc, dxs, dxs_scale, dxsum,
+                                    dxsum_beta, gscale, nonfinite, defer)
     _chk2d(dy); _chk2d(x, F32)
     M, C = x.shape
     if dx_out is None:
@@ -325,6 +373,39 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in=None, dx_out=No
         if beta_acc != 0.0:
             raise PvrlError("layernorm_bwd: dxsum_beta = 0 with beta_acc != 0 is not supported")
         dxsum.mul_(float(dxsum_beta)).add_(tgt)
+    return dx_out
+
+
+def _layernorm_bwd_split(dy, x, mean, rstd, gamma, dgamma, dbeta, dx_in, dx_out, beta_acc, dxs, dxs_scale, dxsum, dxsum_beta,
+                         gscale, nonfinite, defer):
+    """layernorm_bwd over a split matrix (pvrl_layernorm_bwd_split): x, dx_in (optional; a None part reads as zeros) and dx_out are
+    SplitRows with the same split"""
+    L = lib()
+    _chk2d(dy)
+    M, C = x.shape
+    assert isinstance(dx_out, SplitRows) and dx_out.n_lo == x.n_lo and (dx_in is None or (isinstance(dx_in, SplitRows) and dx_in.n_lo == x.n_lo))
+    xr, dor = x.c_rows(), dx_out.c_rows()
+    dir_ = dx_in.c_rows() if dx_in is not None else None
+    nbytes = L.call("pvrl_layernorm_bwd_workspace_bytes", M, C)
+    deferred = defer is not None
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if deferred else workspace(nbytes, x.device, "ln")
+    tgt = dxsum
+    if dxsum is not None:
+        assert dxs is not None and dxsum.dtype == F32 and dxsum.is_contiguous() and dxsum.numel() == C
+        if not deferred and (beta_acc if dxsum_beta is None else dxsum_beta) != beta_acc:      # the kernel has one beta for all three sums
+            if beta_acc != 0.0:
+                raise PvrlError("layernorm_bwd: dxsum_beta = 0 with beta_acc != 0 is not supported")
+            tgt = torch.empty_like(dxsum)
+    L.call("pvrl_layernorm_bwd_split", _ptr(dy), _ld(dy), 1 if dy.dtype == F32 else 0, ctypes.addressof(xr), _ptr(mean), _ptr(rstd),
+           _ptr(gamma), ctypes.addressof(dir_) if dir_ is not None else None, ctypes.addressof(dor), float(beta_acc),
+           None if deferred else _ptr(dgamma), None if deferred else _ptr(dbeta), _ptr(ws), ws.numel(), M, C, _ptr(dxs),
+           _ld(dxs) if dxs is not None else 0, _ptr(dxs_scale), dxs.shape[0] if dxs is not None else 0, _ptr(tgt),
+           None if deferred else _ptr(gscale), None if deferred else _ptr(nonfinite), _stream())
+    if tgt is not dxsum:
+        dxsum.mul_(float(dxsum_beta)).add_(tgt)
+    if deferred:
+        defer.append(dict(part=ws, M=M, C=C, beta=float(beta_acc), beta_sum=float(beta_acc if dxsum_beta is None else dxsum_beta),
+                          dgamma=dgamma, dbeta=dbeta, dxsum=dxsum))
     return dx_out
 
 
@@ -490,11 +571,16 @@ def embed_table(pos, time, bias, N, T):
 
 
 def batch_sum(dx, B, rows):
+    """G[r] = sum_b dx[b * rows + r] (fp32); dx fp32 or the operand type (the 16-bit patch rows of the split gradient stream)"""
     L = lib()
-    _chk2d(dx, F32)
+    _chk2d(dx)
     C = dx.shape[1]
     G = torch.empty((rows, C), device=dx.device, dtype=F32)
-    L.call("pvrl_batch_sum", _ptr(dx), _ld(dx), B, rows, C, _ptr(G), _stream())
+    if dx.dtype == OP16:
+        L.call("pvrl_batch_sum_bf16", _ptr(dx), _ld(dx), B, rows, C, _ptr(G), _stream())
+    else:
+        _chk2d(dx, F32)
+        L.call("pvrl_batch_sum", _ptr(dx), _ld(dx), B, rows, C, _ptr(G), _stream())
     return G
 
 

@@ -100,19 +100,20 @@ def check_block_golden():
     vt.to(DEV)
     eng = vt.engine
     R = B * N * T
-    sv = dict(B=B, T=T, N=N, R=R, M=R + B, Wp=W, blocks=[])
-    x = to_rows(f["x"]).to(DEV)
-    y = eng._block_fwd(vt.blocks[0], x, sv, None, True)
+    sv = dict(B=B, T=T, N=N, R=R, M=R + B, Wp=W, blocks=[], split=eng.resid16)
+    x = eng.stream_from_rows(to_rows(f["x"]).to(DEV), B)
+    y = eng.stream_to_rows(eng._block_fwd(vt.blocks[0], x, sv, None, True))
     out = [("block fwd vs reference", rel(from_rows(y, B), f["y"]), TOL_ACT)]
     gs = vt.grad_store()
     for p in vt.parameters():
         p.grad = None
     from procedurevrl_amd import ops
-    dx = to_rows(f["dy"]).to(DEV).clone()
-    eng._block_bwd(vt.blocks[0], sv["blocks"][0], sv, dx, gs, ops.cast_scale(dx, None), False, None)
+    dy_rows = to_rows(f["dy"]).to(DEV)
+    dx = eng.stream_from_rows(dy_rows.clone(), B)
+    eng._block_bwd(vt.blocks[0], sv["blocks"][0], sv, dx, gs, ops.cast_scale(dy_rows, None), False, None)
     eng._finish_deferred(gs)           # (the fused temporal chains and the LayerNorm partial reduces of all blocks run at the end of a backward)
     eng.join_side_stream()
-    out.append(("block bwd dx vs reference", rel(from_rows(dx, B), f["dx"]), TOL_GRAD))
+    out.append(("block bwd dx vs reference", rel(from_rows(eng.stream_to_rows(dx), B), f["dx"]), TOL_GRAD))
     named = dict(vt.blocks[0].named_parameters())
     for k, g in f["grads"].items():
         out.append((f"block grad {k}", rel(named[k].grad, g), TOL_GRAD))

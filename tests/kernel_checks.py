@@ -512,6 +512,91 @@ def check_layernorm():
     return out
 
 
+def check_split_residual_stream():
+    """Round 6: the patch rows of the residual stream (and of its gradient) in the 16-bit operand type, the cls rows fp32 (pvrl_rows).
+    PVRL_EPI_RESID_16 (16-bit residual in / out; the fp32 pos / time table form), pvrl_layernorm_fwd_split / _bwd_split and
+    pvrl_batch_sum_bf16 vs fp32 math on the rounded inputs: they differ from it by the one rounding of a 16-bit output."""
+    from procedurevrl_amd import ops
+    from procedurevrl_amd._lib import lib
+    L = lib()
+    out = []
+    g = torch.Generator().manual_seed(61)
+    # every tile family: few rows (skinny kernel), 128 x 128, 256 x 128, the persistent 256 x 256 kernel with a ragged last panel
+    for (M, N, K) in [(130, 768, 768), (300, 128, 64), (2500, 768, 256), (50208 - 32, 768, 128), (4230, 768, 3072)]:
+        A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05
+        bias = torch.randn(N, generator=g); b2 = torch.randn(N, generator=g)
+        rs = torch.rand(M, generator=g) + 0.5
+        resid = torch.randn(M, N, generator=g) * 3
+        ref = bf(A) @ bf(W).t()
+        Ad, Wd, rd = A.to(dev(), BF), W.to(dev(), BF), resid.to(dev(), BF)
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_16, bias=bias.to(dev()), rowscale=rs.to(dev()), aux=rd)
+        want = bf(resid) + rs[:, None] * (ref + bias)
+        out.append((f"gemm_nt resid_16 {M}x{N}x{K}", rel(o, want), TOL_BF16))
+        out.append((f"gemm_nt resid_16 {M}x{N}x{K}: the rounding of the fp32 result, elementwise (max |diff| / |ref|)",
+                    float((o.float().cpu() - bf(want)).abs().max() / want.abs().max()), 5e-3 if OPERAND == "bf16" else 6e-4))
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_16, bias=bias.to(dev()), rowscale=rs.to(dev()), aux=rd, bias2=b2.to(dev()))
+        out.append((f"gemm_nt resid_16 + unscaled bias2 {M}x{N}x{K}", rel(o, bf(resid) + rs[:, None] * (ref + bias) + b2), TOL_BF16))
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_16, bias=bias.to(dev()), aux=rd, bias2=b2.to(dev()))
+        out.append((f"gemm_nt resid_16 bias + bias2, no row scale {M}x{N}x{K}", rel(o, bf(resid) + ref + bias + b2), TOL_BF16))
+        rm = 1568 if M > 4000 else 7
+        E = torch.randn(rm, N, generator=g)
+        o = ops.gemm_nt(Ad, Wd, L.PVRL_EPI_RESID_16, bias=bias.to(dev()), aux=E.to(dev()), aux_rowmod=rm)
+        out.append((f"gemm_nt resid_16 fp32 table (rows mod {rm}) {M}x{N}x{K}", rel(o, E[torch.arange(M) % rm] + ref + bias), TOL_BF16))
+    # LayerNorm over a split matrix: M = R + B rows, the first R 16-bit
+    for (R, B, C, eps) in [(1000, 3, 768, 1e-6), (5008, 32, 768, 1e-6), (64, 2, 512, 1e-5), (12, 1, 768, 1e-6), (1, 1, 768, 1e-6)]:
+        M = R + B
+        x = torch.randn(M, C, generator=g) * 2 + 0.3
+        xq = torch.cat([bf(x[:R]), x[R:]], 0)                     # what the split matrix holds
+        gam = torch.randn(C, generator=g); bet = torch.randn(C, generator=g)
+        xs = ops.SplitRows(x[:R].to(dev(), BF), x[R:].to(dev()))
+        ref = F.layer_norm(xq, (C,), gam, bet, eps)
+        y, mean, rstd = ops.layernorm_fwd(xs, gam.to(dev()), bet.to(dev()), eps, out_dtype=torch.float32)
+        out.append((f"ln_fwd split {R}+{B}x{C}", rel(y, ref), TOL_F32))
+        out.append((f"ln_fwd split mean {R}+{B}x{C}", rel(mean, xq.mean(1)), TOL_F32))
+        y2, _, _ = ops.layernorm_fwd(ops.SplitRows(x[:R].to(dev(), BF), None), gam.to(dev()), bet.to(dev()), eps, out_dtype=torch.float32)
+        out.append((f"ln_fwd split, 16-bit rows only {R}x{C}", rel(y2, ref[:R]), TOL_F32))
+        dy = bf(torch.randn(M, C, generator=g))
+        dxin = torch.randn(M, C, generator=g)
+        dq = torch.cat([bf(dxin[:R]), dxin[R:]], 0)
+        xr = xq.clone().requires_grad_(True)
+        gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+        F.layer_norm(xr, (C,), gr, br, eps).backward(dy)
+        want = xr.grad + dq
+        dg = torch.zeros(C, device=dev()); db = torch.zeros(C, device=dev())
+        dsum = torch.zeros(C, device=dev())
+        rows = max(1, R - 5)
+        sc = torch.rand(M, generator=g) + 0.5
+        dxs = torch.zeros(rows, C, device=dev(), dtype=BF)
+        dxo = ops.SplitRows(torch.zeros(R, C, device=dev(), dtype=BF), torch.zeros(B, C, device=dev()))
+        ops.layernorm_bwd(dy.to(dev(), BF), xs, mean, rstd, gam.to(dev()), dg, db,
+                          dx_in=ops.SplitRows(dxin[:R].to(dev(), BF), dxin[R:].to(dev())), dx_out=dxo, dxs=dxs, dxs_scale=sc.to(dev()),
+                          dxsum=dsum)
+        out.append((f"ln_bwd split dx, 16-bit rows {R}+{B}x{C}", rel(dxo.lo, want[:R]), TOL_BF16))
+        out.append((f"ln_bwd split dx, fp32 rows {R}+{B}x{C}", rel(dxo.hi, want[R:]), TOL_F32))
+        out.append((f"ln_bwd split dgamma {R}+{B}x{C}", rel(dg, gr.grad), 1e-4))
+        out.append((f"ln_bwd split dbeta {R}+{B}x{C}", rel(db, br.grad), 1e-4))
+        out.append((f"ln_bwd split scaled 16-bit copy {R}+{B}x{C}", rel(dxs, (sc[:, None] * want)[:rows]), TOL_BF16))
+        out.append((f"ln_bwd split column sums of the emitted rows {R}+{B}x{C}", rel(dsum, want[:rows].sum(0)), 1e-4))
+        # a dx_in part that is known to be zero is not read (the pruned last block: no gradient has reached the patch rows yet)
+        dxo2 = ops.SplitRows(torch.zeros(R, C, device=dev(), dtype=BF), torch.zeros(B, C, device=dev()))
+        ops.layernorm_bwd(dy.to(dev(), BF), xs, mean, rstd, gam.to(dev()), dg, db, dx_in=ops.SplitRows(None, dxin[R:].to(dev()), n_lo=R),
+                          dx_out=dxo2)
+        out.append((f"ln_bwd split, zero patch part of dx_in: 16-bit rows {R}+{B}x{C}", rel(dxo2.lo, xr.grad[:R]), TOL_BF16))
+        out.append((f"ln_bwd split, zero patch part of dx_in: fp32 rows {R}+{B}x{C}", rel(dxo2.hi, want[R:]), TOL_F32))
+        # deferred partial sums + the batched reduce, as the engine runs it
+        items = []
+        d_g, d_b = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+        ops.layernorm_bwd(dy.to(dev(), BF), xs, mean, rstd, gam.to(dev()), d_g, d_b,
+                          dx_in=ops.SplitRows(dxin[:R].to(dev(), BF), dxin[R:].to(dev())), dx_out=dxo, defer=items)
+        ops.layernorm_bwd_reduce_batched(items)
+        out.append((f"ln_bwd split deferred reduce == immediate {R}+{B}x{C}", float((d_g != dg).sum() + (d_b != db).sum()), 0.0))
+    Bc, rows_, C = 5, 24, 768
+    dx = torch.randn(Bc * rows_, C, generator=g)
+    G = ops.batch_sum(dx.to(dev(), BF), Bc, rows_)
+    out.append(("batch_sum over 16-bit rows", rel(G, bf(dx).view(Bc, rows_, C).sum(0)), TOL_F32))
+    return out
+
+
 def _ref_attn(q, k, v, scale, mask=None):
     s = (q @ k.transpose(-1, -2)) * scale
     if mask is not None:
@@ -856,5 +941,5 @@ def check_input_pipeline():
     return out
 
 
-ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_small_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_attn_t8, check_attn_cls,
+ALL_CHECKS = [check_input_pipeline, check_gemm_nt, check_gemm_nt_batched, check_small_batched, check_grad_scale_begin, check_gemm_f32_small, check_cls_linear, check_gemm_tn, check_gemm_tn_rows_behind_the_end, check_gemm_tn_repeatable, check_gemm_tn_into, check_gemm_tn_grouped, check_gemm_tn_grouped_block_size, check_cast_weights_multi, check_gemv_rows, check_layernorm, check_split_residual_stream, check_attn_t8, check_attn_cls,
               check_attn_mfma_contig, check_attn_mfma_spatial, check_attn_bwd_repeatable, check_elementwise, check_loss]

@@ -26,13 +26,15 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.parse_header():
         assert hasattr(cdll, name), f"{name} declared in include/pvrl.h but not exported"
     L = _lib.lib()
-    assert L.PVRL_EPI_RESID_F32 == 3 and L.PVRL_EPI_DQGELU == 6
+    assert L.PVRL_EPI_RESID_F32 == 3 and L.PVRL_EPI_DQGELU == 6 and L.PVRL_EPI_RESID_16 == 7
 
 
 def test_pure_size_queries_run_without_a_gpu():
     L = _lib.lib()
     assert L.call("pvrl_gemm_tn_workspace_bytes", 768, 768, 8) == 8 * (768 * 768 + 768) * 4 + 256
-    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 25 * 3 * 768 * 4
+    # one workgroup per 4 rows + one (a split matrix, pvrl_rows, always has a workgroup for each of its parts), at most 512
+    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 100, 768) == 26 * 3 * 768 * 4
+    assert L.call("pvrl_layernorm_bwd_workspace_bytes", 50208, 768) == 512 * 3 * 768 * 4
 
 
 def test_grouped_weight_gradient_plan_runs_without_a_gpu():

@@ -16,7 +16,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "procedurevrl_amd", "csrc", "gemm_nt.hip")
-NST = {0: 16, 1: 32, 2: 32, 3: 32, 4: 32, 5: 16, 6: 16}      # PVRL_EPI_* -> stores per wave of one whole tile
+NST = {0: 16, 1: 32, 2: 32, 3: 32, 4: 32, 5: 16, 6: 16, 7: 16}      # PVRL_EPI_* -> stores per wave of one whole tile
 
 
 @pytest.fixture(scope="module")
