@@ -569,7 +569,8 @@ def timed_full_step(videos=2, frames=8, classes=9871, budget_s=60.0, threads=Non
             forward_features(sd, xe, 12)
             te.append(time.perf_counter() - t0)
     dte = sorted(te[1:])[1]
-    return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+    return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port", "timed_steps": len(timed),
+            "step_s": [round(t, 2) for t in timed],
             "eval_leg": {"value": round(2 / dte, 4), "unit": "clips/s", "sample": f"2 clips x {frames}f x 224^2, forward_features only "
                          f"(no gradients), median of 3 after 1 warm-up, {dte:.2f} s per pass"},
             "sample": f"BASELINE configs[0]: {videos} videos x 9 = {clips} clips x {frames}f x 224^2, the reference's FULL pre-training step "

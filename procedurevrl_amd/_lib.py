@@ -102,9 +102,12 @@ class PvrlError(RuntimeError):
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
+            other = os.path.join(_HERE, "csrc", "libpvrl_hip_f16.so" if OPERAND == "bf16" else "libpvrl_hip.so")
+            hint = (f"; {os.path.basename(other)} IS there: PVRL_OPERAND={'f16' if OPERAND == 'bf16' else 'bf16'} selects it "
+                    "(the default is the fp16-operand library since round 5)") if os.path.exists(other) else ""
             raise PvrlError(
-                f"{LIB_PATH} is missing: build it with `python -m procedurevrl_amd.csrc.build_ext` "
-                "(there is no CPU or PyTorch fallback for the HIP path)")
+                f"{LIB_PATH} (PVRL_OPERAND={OPERAND}) is missing: build it with `python -m procedurevrl_amd.csrc.build_ext` "
+                f"(there is no CPU or PyTorch fallback for the HIP path){hint}")
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self._fn = {}

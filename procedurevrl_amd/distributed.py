@@ -213,6 +213,11 @@ class GradReducer:
         self._want_resync = False
         self.host_syncs = 0      # flag read-backs that blocked the host (tests / diagnostics)
         self.resyncs = 0
+        # `diag` (bench.py --gpus N): per step, HIP events around (i) every chunk's collective on the communication stream and (ii) the
+        # main stream's wait for that stream in finish() -- what a scaling run needs to tell exposed link time from compute (diag_summary)
+        self.diag = False
+        self._diag_steps = []    # [(e_wait0, e_wait1, [(bytes, e_ready, e_done), ...])]
+        self._diag_cur = []
         vt.engine.grad_hook = self._hook if self.enabled else None
         vt.engine.grad_hook_group = self._hook_group if self.enabled else None      # (engines that run the hook per group of blocks)
 
@@ -282,6 +287,10 @@ class GradReducer:
             c = self._staging(gs, a, b) if half else t
             if half:
                 c.copy_(t)                       # cast, reduced and consumed on the communication stream; the slice is this chunk's own
+            if self.diag:                        # "ready": everything the chunk depends on has run
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(comm)
+                self._diag_cur.append([c.numel() * c.element_size(), e0, None])
             self.handles.append((self._collective(c), t if half else None, c if half else None))
 
     def _wait_all(self, device):
@@ -294,13 +303,58 @@ class GradReducer:
         else:
             comm = self._comm_stream(device)
             with torch.cuda.stream(comm):
-                for hs, t, c in self.handles:
+                for j, (hs, t, c) in enumerate(self.handles):
                     for h in hs:
                         h.wait()                # the communication stream waits for the collective ...
                     if c is not None:
                         t.copy_(c)              # ... and widens the 16-bit sum back into the fp32 buffer
-            torch.cuda.current_stream().wait_stream(comm)
+                    if self.diag and j < len(self._diag_cur):
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record(comm)
+                        self._diag_cur[j][2] = e1
+            main = torch.cuda.current_stream()
+            if self.diag:                       # how long the main stream sits in this wait = communication NOT hidden under the backward
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record(main)
+                main.wait_stream(comm)
+                w1.record(main)
+                self._diag_steps.append((w0, w1, self._diag_cur))
+                self._diag_cur = []
+            else:
+                main.wait_stream(comm)
         self.handles = []
+
+    def diag_reset(self):
+        self._diag_steps, self._diag_cur = [], []
+
+    def diag_summary(self):
+        """-> dict for bench.py's `comm` object (call after a device synchronisation): per step the time the main stream waited for the
+        communication stream (`exposed_ms_per_step`), and per chunk the time from "its inputs are ready AND the previous chunk is done" to
+        "its collective is done" on the communication stream (`allreduce_ms_per_chunk`, with the chunk sizes), i.e. the link + RCCL
+        kernel time of that chunk as it ran next to the backward."""
+        if not self._diag_steps:
+            return None
+        exposed, per_chunk, sizes = [], None, None
+        for w0, w1, chunks in self._diag_steps:
+            exposed.append(w0.elapsed_time(w1))
+            ms, prev = [], None
+            for nbytes, e0, e1 in chunks:
+                if e1 is None:
+                    continue
+                d = e0.elapsed_time(e1)
+                if prev is not None:            # queued behind the previous chunk: count from its end
+                    d = min(d, max(0.0, prev.elapsed_time(e1)))
+                ms.append(d)
+                prev = e1
+            if per_chunk is None:
+                per_chunk, sizes = [0.0] * len(ms), [round(c[0] / 2 ** 20, 1) for c in chunks]
+            if len(ms) == len(per_chunk):
+                per_chunk = [a + b for a, b in zip(per_chunk, ms)]
+        n = len(self._diag_steps)
+        return {"exposed_ms_per_step": round(sum(exposed) / n, 3), "exposed_ms_max_step": round(max(exposed), 3),
+                "allreduce_ms_per_chunk": [round(a / n, 3) for a in (per_chunk or [])], "chunk_mb": sizes or [],
+                "allreduce_ms_per_step": round(sum(per_chunk or []) / n, 3), "steps": n,
+                "grad_coll": self.grad_coll, "grad_comm": self.grad_comm}
 
     def _settle(self, gs, k):
         """parameter k is about to be reduced: its slot of the flat buffer must hold THIS step's gradient of this rank
@@ -419,6 +473,7 @@ class GradReducer:
                 self._reduce(cur, a)
             cur = max(cur, b)
         self._wait_all(gs.flat.device)                          # the current (main) stream waits for the collectives
+        gs.reduced_over_ranks = dist.get_world_size() > 1       # (optimizer.FusedOptimizer: scan the whole buffer, not only the unchecked part)
         self.done = []
         if self.find_unused == "off":
             used = [True] * len(had)

@@ -55,6 +55,8 @@ class GradStore:
         self.ctl = self.flat[off + len(sizes):off + len(sizes) + 1]
         self.bad = self.flat[off + len(sizes) + 1:off + len(sizes) + 2]
         self.fused_checked = set()     # parameters whose gradient producers raise `bad` themselves (target(..., fused=True))
+        self._unchecked = set()        # ... parameters with at least one writer that does not (target(..., checks=False))
+        self.reduced_over_ranks = False   # set by distributed.GradReducer.finish(): the buffer holds SUMS over ranks (the optimiser then scans all of it)
         self.views = [self.flat[o:o + s].view(p.shape) for o, s, p in zip(self.offsets, sizes, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.scale = None       # fp16 flavour: device scalar S while an engine's backward runs with S-scaled gradients
@@ -65,10 +67,12 @@ class GradStore:
         """[a, b) of parameter i in the flat buffer, padding included"""
         return self.offsets[i], (self.offsets[i + 1] if i + 1 < len(self.offsets) else self.end)
 
-    def target(self, p, fused=False):
+    def target(self, p, fused=False, checks=True):
         """-> (grad tensor to write into, beta).  beta = 0 overwrites, 1 accumulates.
-        `fused`: the caller's kernel computes  grad = beta * grad + self.inv * (its S-scaled result)  itself (`gscale`) and raises
-        `self.bad` on a non-finite value (`nonfinite`): nothing is registered for unscale(), what is already there stays in true units."""
+        `fused`: the caller's kernel computes  grad = beta * grad + self.inv * (its S-scaled result)  itself (`gscale`): nothing is
+        registered for unscale(), what is already there stays in true units.  `checks` (with `fused`): that kernel also raises `self.bad`
+        on a non-finite value it writes (`nonfinite`), so the optimiser's scan may skip the parameter (`fused_checked`); a writer that
+        takes no `nonfinite` argument says checks=False and its parameter stays in the scan."""
         i = self.index[id(p)]
         v = self.views[i]
         if p.grad is None:
@@ -79,7 +83,10 @@ class GradStore:
         else:       # a foreign .grad tensor (someone else allocated it): accumulate into it
             t, beta = p.grad, 1.0
         if fused:
-            if t is v:
+            if not checks:                       # one unchecked writer is enough to keep the parameter in the scan, whatever the order
+                self._unchecked.add(i)
+                self.fused_checked.discard(i)
+            elif t is v and i not in self._unchecked:
                 self.fused_checked.add(i)
             return t, beta
         if self.scale is not None:
@@ -247,6 +254,17 @@ class GraphReplay:
 
     grad_hook_group = None      # optional: the hook for a list of blocks at once (distributed.GradReducer merges their all-reduces)
 
+    def _group_of(self, i, nb):
+        """-> (lo, hi): the blocks [lo, hi] whose gradient hook runs together with block i's (`hook_group` blocks per group: fewer,
+        larger collectives).  The LAST group of a backward -- blocks 0 .. hook_group - 1 -- runs per block (PVRL_HOOK_TAIL_SPLIT=0:
+        A/B): nothing is left to overlap its collective with but the embedding stage, so the exposed tail round stays one block's
+        ~45 MB instead of three blocks' ~135 MB."""
+        grp = max(1, int(getattr(self, "hook_group", 1)))
+        if i < grp and getattr(self, "hook_tail_split", True):
+            return i, i
+        lo = (i // grp) * grp
+        return lo, min(lo + grp, nb) - 1
+
     def _run_hooks(self, blocks):
         if not blocks or self.grad_hook is None:
             return
@@ -364,11 +382,10 @@ class GraphReplay:
                 # one graph per GROUP of `hook_group` blocks (the first also holds the final-norm stage, the last the embedding stage):
                 # the hook runs for a group's blocks after its replay.  A capture cannot end with side-stream work in flight, so each
                 # stage joins its weight gradients
-                grp = max(1, int(getattr(self, "hook_group", 1)))
                 state = None
                 i = nb - 1
                 while i >= 0:
-                    lo = (i // grp) * grp
+                    lo = self._group_of(i, nb)[0]
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, pool=self._gpool, capture_error_mode="thread_local"):
                         if state is None:
@@ -423,6 +440,7 @@ class EncoderEngine(GraphReplay):
         # with a gradient hook (data parallel): blocks per group -- the hook runs (and the deferred launches go out, batched) once per
         # group of this many blocks instead of per block: four all-reduce rounds of ~135 MB per backward instead of twelve of 45
         self.hook_group = max(1, int(os.environ.get("PVRL_HOOK_GROUP", "3")))
+        self.hook_tail_split = os.environ.get("PVRL_HOOK_TAIL_SPLIT", "1") == "1"      # the backward's last group per block (_group_of)
         self._fused_fresh = set()
         self._chain = []
         self._ln_defer = []
@@ -442,6 +460,11 @@ class EncoderEngine(GraphReplay):
         # what the rounding-model oracle says (profiles/r6_resid16_rounding.txt: logits 2.84e-4 -> 2.96e-4, worst gradient 1.09e-3 ->
         # 1.16e-3 at 12 blocks, fp16 operands).  PVRL_RESID16=0: the fp32 stream of rounds 1-5 (A/B runs).
         self.resid16 = os.environ.get("PVRL_RESID16", "1") == "1"
+        # Debug aid (VERDICT r5 weak #11 / ADVICE): with the last block pruned, the patch rows of its x2 / x3, the patch queries of its qkv,
+        # o_s[:R], the patch rows of the gradient stream ahead of its norm1 backward and the query third of its dqkv are never written --
+        # correct only while nothing reads them.  PVRL_DEBUG_NAN_UNDEFINED=1 fills every such region with NaN, so a reader that should
+        # not exist turns the loss / gradients NaN (tests/e2e_checks.check_train_step_undefined_rows_nan_filled runs the suite's steps so).
+        self.debug_nan_undefined = os.environ.get("PVRL_DEBUG_NAN_UNDEFINED", "0") == "1"
         self._wq = []
         self._wpost = []
         self._side_keep = []
@@ -574,7 +597,8 @@ class EncoderEngine(GraphReplay):
         # dW_e / db_e are in the backward's S-scaled units (fp16 flavour; their 16-bit copies above must stay mid-range); the scale
         # is taken out where the four parameter gradients are written: a row scale of 1 / S in the GEMM epilogues, `gscale` below
         rs = gs.inv_row if gs.inv is not None else None
-        tg = [(gs.target(lin_w, fused=True), A, W) for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t))]   # [out,mid] = dW_e.W_p^T ; [mid,in] = W_f^T.dW_e
+        # (gemm_nt_batched / rank1_add / gemv_rows take no `nonfinite` argument: checks=False keeps these parameters in the optimiser's scan)
+        tg = [(gs.target(lin_w, fused=True, checks=False), A, W) for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t))]   # [out,mid] = dW_e.W_p^T ; [mid,in] = W_f^T.dW_e
         if self.batch_fused and tg[0][0][1] == tg[1][0][1]:                   # both in one launch (72 tiles instead of 2 x 36)
             beta = tg[0][0][1]
             ops.gemm_nt_batched([dict(A=A, W=W, rowscale=rs, out0=g, aux=g if beta else None) for (g, _), A, W in tg],
@@ -586,8 +610,8 @@ class EncoderEngine(GraphReplay):
                 else:
                     ops.gemm_nt(A, W, L.PVRL_EPI_RESID_F32, rowscale=rs, aux=g, out0=g)
         # proj's bias rides through temporal_fc too (b_e = W_fc b_proj): its share of dW_fc is the outer product db_e x b_proj
-        ops.rank1_add(gs.target(wf, fused=True)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
-        gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True)
+        ops.rank1_add(gs.target(wf, fused=True, checks=False)[0], dbe, blk.temporal_attn.proj.bias.detach(), gscale=gs.inv)
+        gb, beta = gs.target(blk.temporal_attn.proj.bias, fused=True, checks=False)
         ops.gemv_rows(ef.t, dbe, out=gb, beta=beta, gscale=gs.inv)            # [mid] = W_fc^T db_e (bf16 operand copy)
 
     def _build_fused_all(self):
@@ -647,15 +671,15 @@ class EncoderEngine(GraphReplay):
             wf, wp = blk.temporal_fc.weight, blk.temporal_attn.proj.weight
             ef, ep = self._weight(wf), self._weight(wp)
             for lin_w, A, W in ((wf, dwe_b, ep.w), (wp, ef.t, dwe_t)):
-                g, beta = gs.target(lin_w, fused=True)
+                g, beta = gs.target(lin_w, fused=True, checks=False)
                 groups[beta].append(dict(A=A, W=W, rowscale=rs, out0=g, aux=g if beta else None))
         if groups[0.0]:
             ops.gemm_nt_batched(groups[0.0], L.PVRL_EPI_F32)
         if groups[1.0]:
             ops.gemm_nt_batched(groups[1.0], L.PVRL_EPI_RESID_F32)
-        ops.rank1_add_batched([gs.target(blk.temporal_fc.weight, fused=True)[0] for blk, _, _ in chain], [dbe for _, _, dbe in chain],
+        ops.rank1_add_batched([gs.target(blk.temporal_fc.weight, fused=True, checks=False)[0] for blk, _, _ in chain], [dbe for _, _, dbe in chain],
                               [blk.temporal_attn.proj.bias.detach() for blk, _, _ in chain], gscale=gs.inv)
-        tb = [gs.target(blk.temporal_attn.proj.bias, fused=True) for blk, _, _ in chain]
+        tb = [gs.target(blk.temporal_attn.proj.bias, fused=True, checks=False) for blk, _, _ in chain]
         ops.gemv_rows_batched([self._weight(blk.temporal_fc.weight).t for blk, _, _ in chain], [dbe for _, _, dbe in chain],
                               [t for t, _ in tb], [b for _, b in tb], gscale=gs.inv)
 
@@ -820,6 +844,12 @@ class EncoderEngine(GraphReplay):
             sv["x_final"] = x
             sv["norm_stats"] = (mean, rstd)
             self.saved = sv
+            if SCALED_GRADS:
+                # fp16 operands: a 16-bit forward activation past 65504 (qkv, the MLP's u / g, attention outputs) is an inf that reaches
+                # every later block's cls row through the attention, i.e. these B x C features: one few-microsecond check raises the
+                # optimiser's skip flag on the device, in the step that overflowed, whatever the caller does with its loss
+                gs = self.grad_store()
+                lib().call("pvrl_nonfinite_flag_f32", ops._ptr(feat), feat.numel(), ops._ptr(gs.bad), ops._stream())
         return feat
 
     def stream_from_rows(self, x_rows, B):
@@ -833,6 +863,12 @@ class EncoderEngine(GraphReplay):
     @staticmethod
     def stream_to_rows(x):
         return x.full if x.full is not None else torch.cat([x.p.float(), x.c], 0)
+
+    def _undef(self, t):
+        """`t` is deliberately left unwritten (see debug_nan_undefined)"""
+        if self.debug_nan_undefined and t is not None and t.numel():
+            t.fill_(float("nan"))
+        return t
 
     def _epi_resid(self):
         L = lib()
@@ -883,6 +919,8 @@ class EncoderEngine(GraphReplay):
             # the last block: only the cls query's output is read (csrc/attn_cls.hip) -- keys and values of every token, queries of the
             # B cls rows; the patch rows' query third of qkv_s and o_s[:R] stay undefined and are never read
             qkv_s = torch.empty((M, 3 * C), device=dev, dtype=OP16)
+            self._undef(qkv_s[:R, :C])
+            self._undef(o_s[:R])
             bq = P(blk.attn.qkv.bias)
             ops.gemm_nt(h_s, wqkv[C:], L.PVRL_EPI_BF16, bias=bq[C:], out0=qkv_s[:, C:])
             ops.gemm_nt(h_s[R:], wqkv[:C], L.PVRL_EPI_BF16, bias=bq[:C], out0=qkv_s[R:, :C])
@@ -891,6 +929,8 @@ class EncoderEngine(GraphReplay):
             qkv_s = ops.gemm_nt(h_s, wqkv, L.PVRL_EPI_BF16, bias=P(blk.attn.qkv.bias))
             _, _, lse_s = ops.attn_fwd(qkv_s, B * T, N + 1, H, self.scale, mode=1, T=T, cls_base=R, o=o_s[:R], o_cls=o_s[R:])
         x2 = _X.new(R, B, C, dev, split)      # (pruned last block: its patch rows are neither computed nor defined)
+        if prune:
+            self._undef(x2.p)
         wproj = self._weight(blk.attn.proj.weight).w
         if not prune:
             ops.gemm_nt(o_s[:R], wproj, epi_res, bias=P(blk.attn.proj.bias), rowscale=s2_tok, aux=x1.p, out0=x2.p)
@@ -906,6 +946,8 @@ class EncoderEngine(GraphReplay):
 
         # ---- MLP (vit.py:155-157) ----
         x3 = _X.new(R, B, C, dev, split)
+        if prune:
+            self._undef(x3.p)
         s3c = s3_all[R:] if s3_all is not None else None
         w2 = self._weight(blk.mlp.fc2.weight).w
         if prune:
@@ -978,12 +1020,13 @@ class EncoderEngine(GraphReplay):
 
     def _backward(self, dfeat):
         st = self._bwd_begin(dfeat)
-        nb, grp = len(self.m.blocks), self.hook_group
+        nb = len(self.m.blocks)
         for i in range(nb - 1, -1, -1):
             self._bwd_block(st, i)
-            if self.grad_hook is not None and i % grp == 0:
+            lo, hi = self._group_of(i, nb)
+            if self.grad_hook is not None and i == lo:
                 self._bwd_group_end(st)      # the group's deferred chains / reduces: its blocks' parameter gradients are final now,
-                self._run_hooks(range(min(i + grp, nb) - 1, i - 1, -1))      # the reducer may start their all-reduce
+                self._run_hooks(range(hi, lo - 1, -1))      # the reducer may start their all-reduce
         self._bwd_end(st)
 
     def _bwd_group_end(self, st):
@@ -1009,6 +1052,8 @@ class EncoderEngine(GraphReplay):
         # as zeros (`dxp_zero`)
         dxp_zero = split and pruned
         dx = _X.new(R, M - R, self.C, dfeat.device, split, zero=True, zero_p=not dxp_zero)
+        if dxp_zero:
+            self._undef(dx.p)
         mean, rstd = sv["norm_stats"]
         (dg, bg), (db, bb) = gs.target(m.norm.weight, fused=True), gs.target(m.norm.bias, fused=True)
         ops.layernorm_bwd(dfeat.contiguous(), sv["x_final"].c, mean, rstd, m.norm.weight.detach(), dg, db,
@@ -1065,7 +1110,7 @@ class EncoderEngine(GraphReplay):
 
     @staticmethod
     def _acc(gs, p, g):
-        tgt, beta = gs.target(p, fused=True)      # (g is in true units already; see _bwd_end)
+        tgt, beta = gs.target(p, fused=True, checks=False)      # (g is in true units already; see _bwd_end.  torch copy_ / add_: no flag raised)
         if beta == 0.0:
             tgt.copy_(g.view_as(tgt))
         else:
@@ -1138,6 +1183,7 @@ class EncoderEngine(GraphReplay):
             del dps
         dqkv = torch.empty((M + B * T, 3 * C), device=dev, dtype=OP16)
         if s.get("cls_attn"):
+            self._undef(dqkv[:R, :C])
             # dQ is non-zero for the cls rows alone: the query third of dqkv's patch rows is neither written nor read -- the qkv weight
             # gradient's query rows are sums over the B cls rows (into the block's small grouped launch), the data gradient of the patch
             # rows a K = 2 C product

@@ -121,7 +121,10 @@ class FusedOptimizer(torch.optim.Optimizer):
             self.bad_steps = torch.zeros(1, device=gs.flat.device)
         skip = vp(gs.bad.data_ptr())
         if self.check_grads:       # gradients written by kernels that do not raise the flag themselves (head, glue, MViT engine)
-            rest = [p for i, p in enumerate(gs.params) if i not in gs.fused_checked]
+            # ... and, under data parallelism, EVERYTHING: what sits in the buffer now are sums over ranks (an overflow of the sum, an inf
+            # from the 16-bit payload's staging), which no producer kernel has seen -- one ~0.1 ms pass
+            scan_all = getattr(gs, "reduced_over_ranks", False)
+            rest = [p for i, p in enumerate(gs.params) if scan_all or i not in gs.fused_checked]
             for a, b, _ in self._runs(gs, rest, had_grad, by_step=False):
                 L.call("pvrl_nonfinite_flag_f32", vp(base_g + 4 * a), b - a, skip, stream)
         for g in self.param_groups:

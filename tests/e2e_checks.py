@@ -282,7 +282,7 @@ def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=N
 
 
 def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None, prune=None,
-                   cls_fp32=None):
+                   cls_fp32=None, debug_nan=None):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -300,6 +300,8 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
         vt.engine.prune_last, vt.engine.prune_attn = prune
     if cls_fp32 is not None:    # PVRL_CLS_FP32=0: the cls rows' projection / MLP on the 16-bit path
         vt.engine.cls_fp32 = cls_fp32
+    if debug_nan is not None:   # PVRL_DEBUG_NAN_UNDEFINED=1: every deliberately unwritten region of the pruned last block filled with NaN
+        vt.engine.debug_nan_undefined = debug_nan
     x = torch.randn(B, 3, frames, crop, crop, generator=g)
     teacher = torch.randn(B, K, generator=g) * 4
     dp_ref = dp_hip = None
@@ -373,6 +375,36 @@ def check_train_step_last_block_unpruned():
     return out
 
 
+def check_train_step_undefined_rows_nan_filled():
+    """The pruned last block leaves regions of its buffers unwritten (the patch rows of x2 / x3 and of the incoming gradient stream, the
+    patch queries of qkv / dqkv, o_s[:R]): correct only while nothing reads them.  Here they are filled with NaN
+    (EncoderEngine.debug_nan_undefined) and the steps of the suite -- with and without pinned DropPath draws, eager and through
+    HIP-graph capture + replay -- must come out exactly as finite and as close to the oracle as before."""
+    out = _hip_vs_oracle(2, 32, 64, 4, tag="NaN-filled undefined rows, small: ", rounding_model=False, debug_nan=True)
+    out += _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="NaN-filled undefined rows, droppath: ", rounding_model=False, debug_nan=True)
+    # ... and through the graph-replayed step (no pinned draws): features finite and equal, replay after replay
+    from procedurevrl_amd.datasets import synthetic_label_emb
+    cfg = make_cfg(2, 32, 64)
+    model = build(cfg, synthetic_label_emb(64, 512, seed=1)).to(DEV).train()
+    vt = model.model
+    vt.engine.debug_nan_undefined = True
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(4, 3, 8, 32, 32, device=DEV, generator=g)
+    teacher = torch.randn(4, 64, device=DEV, generator=g) * 4
+    from procedurevrl_amd.functional import kl_topk_loss
+    losses, finite = [], True
+    for _ in range(vt.engine.GRAPH_WARMUP + 3):
+        for p in model.parameters():
+            p.grad = None
+        loss = kl_topk_loss(model(x), teacher, 5)
+        loss.backward()
+        losses.append(float(loss))
+        finite &= all(bool(torch.isfinite(p.grad).all()) for p in vt.parameters() if p.grad is not None)
+    out.append(("NaN-filled undefined rows, graph replay: non-finite loss or gradient (1 = yes)", 0.0 if finite and all(l == l for l in losses) else 1.0, 0.0))
+    out.append(("NaN-filled undefined rows, graph replay: loss differs between replays", max(abs(l - losses[0]) for l in losses), 0.0))
+    return out
+
+
 def check_train_step_t4():
     """T = 4 frames: temporal attention takes the general MFMA path instead of the T=8 kernel."""
     return _hip_vs_oracle(1, 32, 64, 2, frames=4, seed=7, tag="T=4: ")
@@ -403,9 +435,13 @@ def check_timed_config_train_step():
     return [(l, e, TOL_LOGITS_FULL if "logits vs oracle" in l else t) for l, e, t in res]
 
 
-def check_bench_config_two_clips():
+def check_bench_config_two_clips(frames=8):
     """bench.py --parity-probe: the benchmark's model (12 blocks, 8 x 224^2, K = 9871) on 2 clips, one training step vs the
-    oracle -- cheap enough (a few seconds of CPU) to ride along with a timed run of either library flavour"""
+    oracle -- cheap enough (a few seconds of CPU) to ride along with a timed run of either library flavour.  `frames` = 32
+    (configs[3]): ONE clip of 6,273 tokens."""
+    if frames > 8:
+        res = _hip_vs_oracle(12, 224, 9871, 1, frames=frames, seed=19, tag=f"1 clip of {frames} frames (bench model): ", rounding_model=False)
+        return [(l, e, TOL_LOGITS_FULL if "logits vs oracle" in l else t) for l, e, t in res]
     res = _hip_vs_oracle(12, 224, 9871, 2, seed=19, tag="2 clips (bench model): ", rounding_model=False)
     return [(l, e, TOL_LOGITS_FULL if "logits vs oracle" in l else t) for l, e, t in res]
 
@@ -441,8 +477,16 @@ def check_text_tower_full_size():
             teacher = vt.get_pseudo_labels(torch.device(DEV), {"clip_text_ids": ids.to(DEV), "clip_vis_feat": vis.to(DEV)})
         out.append(("text tower 12 layers ctx 77: embeddings vs oracle", rel(emb, emb_ref), TOL_ACT))
         out.append(("text tower: teacher logits K=9871 vs oracle", rel(teacher, teacher_ref), TOL_ACT))
-        out.append(("text tower: teacher top-5 sets differ (rows)",
-                    float((teacher.topk(5, 1)[1].sort(1)[0].cpu() != teacher_ref.topk(5, 1)[1].sort(1)[0]).any(1).float().sum()), 2.0))
+        # the KL target keeps the teacher's top-5 entries (train_net.py:152-160): a flipped 5th entry changes it discontinuously.  A
+        # row's set is DECIDABLE when the reference's 5th and 6th logits are further apart than twice the largest logit error
+        # observed in this very comparison; on those rows the sets must be identical.
+        t_cpu = teacher.float().cpu()
+        top6 = teacher_ref.topk(6, 1)[0]
+        decidable = (top6[:, 4] - top6[:, 5]) > 2.0 * float((t_cpu - teacher_ref).abs().max())
+        differ = (t_cpu.topk(5, 1)[1].sort(1)[0] != teacher_ref.topk(5, 1)[1].sort(1)[0]).any(1)
+        out.append(("text tower: teacher top-5 sets differ on rows with a decidable 5th entry (rows)", float((differ & decidable).float().sum()), 0.0))
+        out.append(("text tower: rows whose 5th / 6th teacher logits are closer than twice the max logit error (fraction)",
+                    float((~decidable).float().mean()), 0.25))
     return out
 
 
@@ -479,7 +523,9 @@ def check_forecast_eval_golden():
     model.to(DEV).eval()
     with torch.no_grad():
         probs = model(f["x"].to(DEV))
-    return [("forecast eval probabilities vs reference", rel(probs, f["probs"]), 3 * TOL_ACT),
+    # probabilities = softmax over K of logits / 0.02: a logit error d moves a probability by the factor e^d, so their relative error is the
+    # ABSOLUTE logit error (~1e-3 x |logit| ~ 50 x 1e-3 x cos).  Observed on MI355X: 1.2e-3 (fp16) -- held to 1.5x that; bf16 8x more.
+    return [("forecast eval probabilities vs reference", rel(probs, f["probs"]), 1.8e-3 if OPERAND != "bf16" else 3e-2),
             ("forecast eval argmax agreement (fraction differing)", float((probs.argmax(1).cpu() != f["probs"].argmax(1)).float().mean()), 0.0)]
 
 
@@ -643,6 +689,6 @@ def check_hip_graph_replay():
     return out
 
 
-ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged, check_train_step_last_block_unpruned,
+ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged, check_train_step_last_block_unpruned, check_train_step_undefined_rows_nan_filled,
               check_train_step_t4, check_train_step_t32, check_train_step_crop256, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
               check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step, check_bench_config_two_clips]

@@ -507,6 +507,42 @@ def check_mvit_s_full_size_step_vs_oracle():
     return out
 
 
+def bench_parity_two_clips(frames=16):
+    """bench.py --arch mvit --parity-probe: MViTv2-S at its timed geometry (16 x 224^2, 16 blocks) on 2 clips -- features, a fixed
+    linear functional of them (the "loss") and the gradients of every encoder parameter vs the CPU oracle.  -> dict for the bench line."""
+    g = _load("mvit_s")
+    model, sd = _build_mvit(g, frames, 224)
+    vt = model.model
+    model.train()
+    gen = torch.Generator().manual_seed(19)
+    x = torch.randn(2, 3, frames, 224, 224, generator=gen)
+    gout = torch.randn(2, 768, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    try:
+        torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+    ref = mo.forward_features(p, x, g["mvit"])
+    lref = 0.5 * (ref * ref).sum() + (ref * gout).sum()          # (a positive, well-conditioned functional: no cancellation in its value)
+    lref.backward()
+    feat = vt.forward_features(x.to(DEV))
+    loss = 0.5 * (feat * feat).sum() + (feat * gout.to(DEV)).sum()
+    loss.backward()
+    worst, wk = 0.0, ""
+    gmax = max(float(v.grad.norm()) / v.numel() ** 0.5 for v in p.values() if v.grad is not None)
+    for n, q in vt.video_encoder.named_parameters():
+        # (gradients that are zero in exact arithmetic -- the last block's key-side biases: softmax ignores a vector added to every
+        #  key -- are rounding noise in both implementations: only tensors whose reference rms is within 1e-4 of the largest count)
+        if n in p and p[n].grad is not None and q.grad is not None and float(p[n].grad.norm()) / p[n].numel() ** 0.5 > 1e-4 * gmax:
+            e = rel(q.grad, p[n].grad)
+            if e > worst:
+                worst, wk = e, n
+    return {"features_rel_err": float(f"{rel(feat, ref):.3e}"), "loss_rel_err": float(f"{abs(float(loss) - float(lref)) / abs(float(lref)):.3e}"),
+            "worst_grad_rel_err": float(f"{worst:.3e}"), "worst_grad": wk,
+            "sample": f"2 clips of {frames} x 224^2, MViTv2-S encoder (16 blocks): features, the functional 0.5 |f|^2 + <f, fixed weights> "
+                      "and every encoder gradient of it vs oracle/mvit_oracle.py (fp32 CPU)"}
+
+
 def check_mvit_timed_config_train_step():
     """MViTv2-S at the size bench.py times it (BASELINE configs[4]): 32 clips of 16 x 224^2 in ONE HIP step -- M up to 803k
     token rows, the padded split-M weight-gradient reductions and the pool kernels at B = 32 -- against the oracle run in
@@ -543,7 +579,7 @@ def check_mvit_timed_config_train_step():
         r = p[n].grad
         err = float((params[n].grad.detach().float().cpu() - r).norm())
         obs.append(f"{n} {err / float(r.norm()):.3e}")
-        tol = TIMED_GRAD_TOL["patch_embed" if n.startswith("patch_embed") else "rel_pos" if "rel_pos" in n else "other"]
+        tol = 1.5 * TIMED_GRAD_OBS[n]            # per tensor: 1.5x the value observed on MI355X (a regression that doubles one fails)
         out.append((f"mvit-S 32 clips d {n} (rel err {err / float(r.norm()):.2e}; abs err / allowed)",
                     err / (tol * float(r.norm()) + 1e-5 * r.numel() ** 0.5), 1.0))
     try:        # observed values, for setting the bounds (scratch output)
@@ -554,11 +590,16 @@ def check_mvit_timed_config_train_step():
     return out
 
 
-# per-tensor bounds of the 32-clip step = 1.5x the values observed on MI355X (round 3, gpurun_out/r3_mvit_timed_obs_*.txt):
-#   bf16: stem 6.2e-2, rel_pos_h / rel_pos_w 6.3e-2 (signed sums over the 25,088 queries of 32 clips: cancellation), rel_pos_t
-#         4.8e-2, every other checked parameter <= 2.5e-2, features 6.0e-3
-#   fp16: stem 2.1e-2, rel_pos_h / rel_pos_w 2.2e-2, rel_pos_t 1.5e-2, others <= 8.0e-3, features 7.4e-4
-TIMED_GRAD_TOL = ({"patch_embed": 3.2e-2, "rel_pos": 3.3e-2, "other": 1.2e-2} if F16 else
-                  {"patch_embed": 9.3e-2, "rel_pos": 9.5e-2, "other": 3.8e-2})
+# per-tensor relative errors of the 32-clip step OBSERVED on MI355X (fp16: round 6, gpurun_out/r3_mvit_timed_obs_f16.txt of the run that
+# set them; bf16: round 3); the check allows 1.5x each.  The stem and the rel_pos_h / rel_pos_w tables (signed sums over the 25,088
+# queries of 32 clips: cancellation) carry the largest values; features: 7.4e-4 (fp16) / 6.0e-3 (bf16).
+TIMED_GRAD_OBS = ({"patch_embed.proj.weight": 2.12e-2, "blocks.0.attn.qkv.weight": 7.9e-3, "blocks.0.attn.pool_q.weight": 6.2e-3,
+                   "blocks.0.attn.rel_pos_h": 2.12e-2, "blocks.0.attn.rel_pos_w": 2.16e-2, "blocks.1.proj.weight": 7.9e-3,
+                   "blocks.1.attn.rel_pos_t": 1.47e-2, "blocks.3.attn.pool_k.weight": 2.6e-3, "blocks.7.mlp.fc1.weight": 1.52e-3,
+                   "blocks.14.attn.qkv.bias": 6.6e-4, "blocks.15.mlp.fc2.weight": 8.4e-4, "norm.weight": 7.7e-4, "cls_token": 1.32e-3} if F16 else
+                  {"patch_embed.proj.weight": 6.13e-2, "blocks.0.attn.qkv.weight": 2.41e-2, "blocks.0.attn.pool_q.weight": 2.03e-2,
+                   "blocks.0.attn.rel_pos_h": 6.32e-2, "blocks.0.attn.rel_pos_w": 6.41e-2, "blocks.1.proj.weight": 2.43e-2,
+                   "blocks.1.attn.rel_pos_t": 4.73e-2, "blocks.3.attn.pool_k.weight": 1.6e-2, "blocks.7.mlp.fc1.weight": 9.3e-3,
+                   "blocks.14.attn.qkv.bias": 5.2e-3, "blocks.15.mlp.fc2.weight": 7.2e-3, "norm.weight": 6.0e-3, "cls_token": 1.01e-2})
 
 ALL_CHECKS = [check_mvit_timed_config_train_step, check_mvit_s_full_size_step_vs_oracle, check_mvit_hip_graph_replay, check_mvit_encoder_small_golden, check_mvit_droppath_golden, check_mvit_e2e_golden, check_mvit_pretrain_steps, check_mvit_s_features, check_mvit_im2col_ln, check_mvit_pool, check_mvit_maxpool_rel, check_mvit_attention]

@@ -157,3 +157,11 @@ def test_bench_eight_ranks_the_drivers_command():
     assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 16 and out["comm"]["ranks"] == 8
     assert out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak" and out["value"] > 0
     assert out["comm"]["compute_cus_per_xcd"] == "31" and out["comm"]["nccl_max_nchannels"] == "8"
+    # what the first real 8-GPU run needs to be diagnosable in one shot: the main stream's wait for the communication
+    # stream per step (rank 0 and the slowest rank), the per-chunk collective times with their sizes, the hardware-queue setting, and
+    # the 2-clip parity probe on rank 0
+    c = out["comm"]
+    assert c["steps"] == 2 and c["exposed_ms_per_step"] >= 0.0 and c["exposed_ms_per_step_max_over_ranks"] >= c["exposed_ms_per_step"] - 1e-9
+    assert len(c["allreduce_ms_per_chunk"]) == len(c["chunk_mb"]) >= 2 and all(t >= 0.0 for t in c["allreduce_ms_per_chunk"])
+    assert abs(sum(c["chunk_mb"]) - c["grad_allreduce_mb"]) < 1.0 and "hw_queues" in c and c["hook_group"] >= 1
+    assert out["parity"]["meets_1e-3_on_logits_and_loss"] is True, out["parity"]

@@ -107,3 +107,67 @@ def test_pvrl_comm_cabi_world2(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_comm_worker, args=(2, str(tmp_path / "uid"), str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok0").read() == "True" and open(tmp_path / "ok1").read() == "True"
+
+
+def _infonce_worker(rank, world, port, out_dir, backend="nccl"):
+    """`backend` = "gloo": both ranks on device 0 (tests/test_two_rank_gloo_gpu.py runs it on the 1-GPU boxes)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    from procedurevrl_amd import distributed as du
+    from procedurevrl_amd.losses import MILNCELoss
+    out = {}
+    # AllGather forward / backward on the reference's own 2-rank inputs (tests/golden/allgather.pt), now over RCCL
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "allgather.pt"), weights_only=False)[rank]
+    x = gold["x"].to(dev).requires_grad_(True)
+    y = du.AllGather.apply(x)
+    (y * gold["w"].to(dev)).sum().backward()
+    out["ag_fwd"] = bool(torch.equal(y.detach().cpu(), gold["y"]))
+    out["ag_bwd"] = bool(torch.equal(x.grad.cpu(), gold["grad"]))
+    # the contrastive leg: each rank holds half of the videos / candidate texts of tests/golden/milnce.pt, gathers the other half
+    # (forward all-gather, backward = the local slice: lib/utils/distributed.py:13-29) and evaluates MILNCELoss on the global batch
+    m = torch.load(os.path.join(ROOT, "tests", "golden", "milnce.pt"), weights_only=False)
+    n, nt = m["v"].shape[0] // world, m["t"].shape[0] // world
+    v = m["v"][rank * n:(rank + 1) * n].to(dev).requires_grad_(True)
+    t = m["t"][rank * nt:(rank + 1) * nt].to(dev).requires_grad_(True)
+    loss = MILNCELoss()(du.AllGather.apply(v), du.AllGather.apply(t))
+    loss.backward()
+    out.update(loss=float(loss), dv=v.grad.cpu(), dt=t.grad.cpu())
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@needs2
+def test_allgather_infonce_two_ranks(tmp_path):
+    """AllGather + MILNCELoss at world 2 over RCCL: the gathered tensors and the slice-backward equal the reference's own 2-rank run
+    (tests/golden/allgather.pt), the global InfoNCE loss equals the reference's value on the whole batch (tests/golden/milnce.pt) on
+    both ranks, and each rank's dV / dT is ITS slice of the single-process gradient (oracle, fp32 CPU)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from oracle import timesformer_oracle as orc
+    mp.spawn(_infonce_worker, args=(2, _port(), str(tmp_path)), nprocs=2, join=True)
+    check_infonce_results(tmp_path)
+
+
+def check_infonce_results(tmp_path):
+    from oracle import timesformer_oracle as orc
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+    m = torch.load(os.path.join(ROOT, "tests", "golden", "milnce.pt"), weights_only=False)
+    v, t = m["v"].clone().requires_grad_(True), m["t"].clone().requires_grad_(True)
+    ref = orc.milnce(v, t)
+    ref.backward()
+    assert abs(float(ref) - m["loss"]) <= 1e-5 * abs(m["loss"])
+    n, nt = v.shape[0] // 2, t.shape[0] // 2
+    for k in range(2):
+        assert r[k]["ag_fwd"] and r[k]["ag_bwd"]
+        assert abs(r[k]["loss"] - m["loss"]) <= 1e-5 * abs(m["loss"]), (k, r[k]["loss"], m["loss"])
+        for got, want in ((r[k]["dv"], v.grad[k * n:(k + 1) * n]), (r[k]["dt"], t.grad[k * nt:(k + 1) * nt])):
+            assert float((got - want).norm() / want.norm()) <= 1e-4

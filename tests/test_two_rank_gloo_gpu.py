@@ -76,3 +76,18 @@ def test_two_rank_data_parallel_steps_with_staged_graphs(tmp_path, grad_coll):
         assert torch.equal(a, b), f"step {k}: ranks disagree after the all-reduce"
         err = float((a - want).abs().max()) / scale
         assert err <= 1e-6, f"step {k}: all-reduced gradients differ from the sum of the ranks' gradients ({err:.2e})"
+
+
+@pytest.mark.gpu
+def test_allgather_infonce_two_ranks_gloo(tmp_path):
+    """The contrastive leg of configs[2] -- AllGather of the video / text embeddings + MILNCELoss on the global batch -- with two
+    processes on ONE GPU over gloo: the worker and the checks of tests/test_rccl_multi_gpu.py::test_allgather_infonce_two_ranks (which
+    runs the moment a box shows two GPUs), everything but the RCCL transport."""
+    import sys
+    import torch.multiprocessing as mp
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import test_rccl_multi_gpu as tr
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(tr._infonce_worker, args=(2, port, str(tmp_path), "gloo"), nprocs=2, join=True)
+    tr.check_infonce_results(tmp_path)
