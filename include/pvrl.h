@@ -13,11 +13,16 @@
  *   - the caller owns every buffer, including workspaces; nothing is allocated, nothing
  *     synchronises, no global state; every call is asynchronous on `stream`.
  *   - return 0 on success, PVRL_EINVAL (-1) on a bad argument, <= -2 on a HIP launch error.
- *   - bf16 tensors are raw 16-bit brain floats; "ld*" are leading dimensions in ELEMENTS.
- *   - token layout of the TimeSformer encoder (one buffer of B*N*T + B rows, C = 768):
+ *   - "bf16" in entry-point names, PVRL_EPI_* names and comments means THE LIBRARY'S 16-BIT OPERAND TYPE: fp16 in the default
+ *     library (libpvrl_hip_f16.so, what procedurevrl_amd loads unless PVRL_OPERAND=bf16 -- the flavour that meets the 1e-3 parity
+ *     bar), bf16 in libpvrl_hip.so.  Same layouts, same MFMA rate; pvrl_operand_dtype() tells which.  "ld*" are leading dimensions
+ *     in ELEMENTS.
+ *   - token layout of the TimeSformer encoder (B*N*T + B rows, C = 768):
  *       rows [0, B*N*T)      patch tokens ordered (b, n, t), t innermost
  *       rows [B*N*T, +B)     the cls token of each clip
- *     (the reference keeps [B, 1 + N*T, C] with token index 1 + n*T + t, vit.py:396-407)
+ *     (the reference keeps [B, 1 + N*T, C] with token index 1 + n*T + t, vit.py:396-407).  Since round 6 the residual stream and its
+ *     gradient are SPLIT: the patch rows live in a 16-bit matrix, the cls rows in an fp32 one (`pvrl_rows`, PVRL_EPI_RESID_16);
+ *     every other activation between kernels is 16-bit, statistics / head / losses / parameter gradients are fp32.
  */
 #ifndef PVRL_H_
 #define PVRL_H_
@@ -44,10 +49,10 @@ extern "C" {
  * (5 exponent bits; procedurevrl_amd/engine.py GradStore.begin_scaled does this per engine). */
 int pvrl_operand_dtype(void);
 
-/* C[M,N] = epilogue(A[M,K] . W[N,K]^T), bf16 operands, fp32 accumulate on MFMA.
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T), 16-bit operands (see above), fp32 accumulate on MFMA.
  * Replaces nn.Linear forward (vit.py:54-60,75-92,133; tfm_model.py:35-41) and, with the
- * transposed bf16 weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M.  bias2 (fp32 [N] or null,
- * PVRL_EPI_RESID_F32 only) is added after the row scale: x + rs * (o W_e^T + b_e) + b_fc of the fused temporal branch.
+ * transposed 16-bit weight copy as W, its data gradient.  N % 128 == 0, K % 64 == 0, any M.  bias2 (fp32 [N] or null,
+ * PVRL_EPI_RESID_F32 / PVRL_EPI_RESID_16 only) is added after the row scale: x + rs * (o W_e^T + b_e) + b_fc of the fused temporal branch.
  * M <= 192 with K % 256 == 0 (the order / diffusion stack's 36- and 144-row products, tfm_model.py:129-204) runs a few-row kernel whose
  * workgroups split K over their waves (csrc/gemm_nt_skinny.h): same arithmetic up to the order of the fp32 sums over k. */
 int pvrl_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
