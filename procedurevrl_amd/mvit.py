@@ -235,6 +235,7 @@ class MViTEngine(GraphReplay):
         # only the cls row of the last block's output is read (norm + x[:, 0], slowfast_mvit/mvit.py:400-407): its projection and MLP run
         # on the B cls rows alone, forward and backward (engine.EncoderEngine.prune_last; PVRL_PRUNE_LAST=0: A/B runs)
         self.prune_last = os.environ.get("PVRL_PRUNE_LAST", "1") == "1"
+        self.dxn16 = os.environ.get("PVRL_MVIT_DXN16", "1") == "1"
         self._graph_init()
 
     # -------------------------------------------------------------- HIP graphs (engine.GraphReplay)
@@ -546,7 +547,9 @@ class MViTEngine(GraphReplay):
                         self._acc_target(norm.weight), self._acc_target(norm.bias))
         wqkv = self._wpad(a.qkv.weight, a.qkv.bias)
         self._wgrad(dqkv, s["xn"], a.qkv.weight, a.qkv.bias, wqkv)
-        dxn = ops.gemm_nt(dqkv, wqkv.t, L.PVRL_EPI_F32)
+        # (16-bit where nothing is added to it before norm1's backward reads it -- 13 of MViTv2-S's 16 blocks; round 6: the fp32 form wrote and
+        #  re-read 411 MB on block 0's 803k rows.  PVRL_MVIT_DXN16=0: A/B)
+        dxn = ops.gemm_nt(dqkv, wqkv.t, L.PVRL_EPI_BF16 if (dim == dout and self.dxn16) else L.PVRL_EPI_F32)
         # ---- skip path
         dxs = om.maxpool_bwd(s["xs"], dx1, B, thw, sq[1], dout, argmax=s["amax"]) if s["pooled"] else dx1
         dres = None
