@@ -287,11 +287,27 @@ class GradReducer:
             c = self._staging(gs, a, b) if half else t
             if half:
                 c.copy_(t)                       # cast, reduced and consumed on the communication stream; the slice is this chunk's own
-            if self.diag:                        # "ready": everything the chunk depends on has run
+            if self.diag:                        # "ready": everything the chunk depends on has run (and the previous chunk is done)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record(comm)
                 self._diag_cur.append([c.numel() * c.element_size(), e0, None])
-            self.handles.append((self._collective(c), t if half else None, c if half else None))
+            hs = self._collective(c)
+            if dist.get_backend() == "nccl":
+                # RCCL: Work.wait() only orders the CURRENT stream -- the communication stream -- behind the collective (no host block),
+                # so it is issued right here: the 16-bit payload is widened as soon as its sum is there instead of in finish(), and an
+                # event behind the wait stamps the collective's end where it happens (issued in finish(), every chunk's "end" was the
+                # moment the host got there: round 6's first --world1-rccl line read 22.7 ms for the first chunk and 0.01 for the rest)
+                for h in hs:
+                    h.wait()
+                if half:
+                    t.copy_(c)
+                if self.diag:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(comm)
+                    self._diag_cur[-1][2] = e1
+                self.handles.append(([], None, None))
+            else:                                # gloo (tests): wait() blocks the HOST -- deferred to finish() so that the backward keeps being issued
+                self.handles.append((hs, t if half else None, c if half else None))
 
     def _wait_all(self, device):
         if device.type != "cuda":
@@ -308,7 +324,7 @@ class GradReducer:
                         h.wait()                # the communication stream waits for the collective ...
                     if c is not None:
                         t.copy_(c)              # ... and widens the 16-bit sum back into the fp32 buffer
-                    if self.diag and j < len(self._diag_cur):
+                    if self.diag and j < len(self._diag_cur) and self._diag_cur[j][2] is None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record(comm)
                         self._diag_cur[j][2] = e1
