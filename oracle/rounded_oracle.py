@@ -20,11 +20,14 @@ Rounding points (kernel that rounds -> where it appears below):
             attention output o                                   `R(o)`
             temporal branch: proj and temporal_fc folded into ONE matrix W_e = R(RW(W_fc) @ RW(W_proj)) (engine._fused_temporal)
             MLP: pre-activation u stored 16-bit for backward, g = R(gelu(u_fp32))    `GeluStore`
+            residual stream (round 6, RESID = "fwd" | "both"): the PATCH rows of x after the embedding prologue and after each of a
+            block's three residual adds are stored in the operand type (PVRL_EPI_RESID_16 epilogues; the cls rows stay fp32)  `RX`
             EXCEPT the cls rows (round 5, csrc/cls_chain.hip): their attn.proj (from the 16-bit o) and their whole MLP run in fp32 on
             the master weights -- `linf`; their backward takes the 16-bit path, as in the kernels (`_value_of`)
   backward  the gradient operand of every GEMM is the 16-bit copy of (DropPath scale x fp32 residual gradient), or the
             16-bit output of the previous backward GEMM / attention kernel          backward half of `R`, and `RB`
             dGELU uses the 16-bit stored u; dS and P are rounded for the dQ/dK/dV MFMAs  `GeluStore`, `AttnMFMA`
+            RESID = "both": the residual GRADIENT stream of the patch rows is 16-bit as well (ln_bwd's dx in / out)   backward half of `RX`
 """
 import torch
 import torch.nn.functional as F

@@ -267,22 +267,30 @@ def _oracle_step_micro(sd_cpu, frames, label, teacher, depth, micro):
     return torch.cat(logits_all), loss_all, {k: p.grad for k, p in params.items()}
 
 
-def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=None):
-    """`rounded` = torch.bfloat16 / torch.float16: the oracle with the HIP datapath's rounding points (oracle/rounded_oracle.py)"""
+def _oracle_step(sd_cpu, frames, label, teacher, depth, droppath=None, rounded=None, resid=None):
+    """`rounded` = torch.bfloat16 / torch.float16: the oracle with the HIP datapath's rounding points (oracle/rounded_oracle.py);
+    `resid` = "both": ... including the 16-bit patch rows of the split residual stream and of its gradient (EncoderEngine.resid16)"""
     params = {k: v.clone().requires_grad_(True) for k, v in sd_cpu.items()}
     if rounded is None:
         feat = orc.forward_features(params, frames, depth, droppath=droppath)
+        emb, logits = orc.head_logits(params, feat, label, 0.02)
+        loss, _, _ = orc.pretrain_loss(logits, teacher, None, 5)
+        loss.backward()
     else:
-        with rorc.operand(rounded):
-            feat = rorc.forward_features(params, frames, depth, droppath=droppath)
-    emb, logits = orc.head_logits(params, feat, label, 0.02)
-    loss, _, _ = orc.pretrain_loss(logits, teacher, None, 5)
-    loss.backward()
+        rorc.RESID = resid
+        try:
+            with rorc.operand(rounded):
+                feat = rorc.forward_features(params, frames, depth, droppath=droppath)
+                emb, logits = orc.head_logits(params, feat, label, 0.02)
+                loss, _, _ = orc.pretrain_loss(logits, teacher, None, 5)
+                loss.backward()
+        finally:
+            rorc.RESID = None
     return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
 
 
 def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", rounding_model=True, micro=None, prune=None,
-                   cls_fp32=None, debug_nan=None):
+                   cls_fp32=None, debug_nan=None, resid16=None):
     from procedurevrl_amd.engine import EncoderEngine
     from procedurevrl_amd.functional import kl_topk_loss
     g = torch.Generator().manual_seed(seed)
@@ -300,6 +308,8 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
         vt.engine.prune_last, vt.engine.prune_attn = prune
     if cls_fp32 is not None:    # PVRL_CLS_FP32=0: the cls rows' projection / MLP on the 16-bit path
         vt.engine.cls_fp32 = cls_fp32
+    if resid16 is not None:     # PVRL_RESID16=0: the fp32 residual stream of rounds 1-5
+        vt.engine.resid16 = resid16
     if debug_nan is not None:   # PVRL_DEBUG_NAN_UNDEFINED=1: every deliberately unwritten region of the pruned last block filled with NaN
         vt.engine.debug_nan_undefined = debug_nan
     x = torch.randn(B, 3, frames, crop, crop, generator=g)
@@ -341,7 +351,8 @@ def _hip_vs_oracle(depth, crop, K, B, frames=8, seed=3, drop_path=0.0, tag="", r
         # chaotic map, so after a few serial roundings two implementations of the same datapath decorrelate element by
         # element: what must agree is the SIZE of the error -- if a kernel added anything beyond operand rounding, the HIP
         # path's distance from the fp32 oracle would exceed the rounding model's.
-        lg_r, loss_r, grads_r = _oracle_step(sd, x, label, teacher, depth, dp_ref, rounded=OPERAND_DTYPE)
+        lg_r, loss_r, grads_r = _oracle_step(sd, x, label, teacher, depth, dp_ref, rounded=OPERAND_DTYPE,
+                                             resid="both" if vt.engine.resid16 else None)
         e_model = rel(lg_r, logits_ref)
         out.append((f"{tag}logits error / rounding-model error ({rel(pred, logits_ref):.2e} / {e_model:.2e})",
                     rel(pred, logits_ref) / e_model, TOL_RATIO))
@@ -372,6 +383,15 @@ def check_train_step_last_block_unpruned():
     # and the pruned last block with the cls rows on the 16-bit path (PVRL_CLS_FP32=0): its MLP is then three few-row 16-bit GEMMs
     out += _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="droppath, cls rows 16-bit, pruned: ", rounding_model=False,
                           cls_fp32=False)
+    return out
+
+
+def check_train_step_fp32_residual_stream():
+    """The A/B path of round 6's split residual stream: PVRL_RESID16=0 keeps ONE fp32 stream buffer (rounds 1-5) -- the two steps of the
+    suite through it, the unpruned last block included, against the oracle and the rounding model without the stream's rounding points."""
+    out = _hip_vs_oracle(2, 32, 64, 4, tag="fp32 residual stream, small: ", resid16=False)
+    out += _hip_vs_oracle(2, 48, 100, 3, seed=5, drop_path=0.3, tag="fp32 residual stream, droppath, last block on all rows: ",
+                          rounding_model=False, prune=(False, False), resid16=False)
     return out
 
 
@@ -689,6 +709,6 @@ def check_hip_graph_replay():
     return out
 
 
-ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged, check_train_step_last_block_unpruned, check_train_step_undefined_rows_nan_filled,
+ALL_CHECKS = [check_pretrain_head_engine, check_step_is_bit_reproducible, check_hip_graph_replay, check_decoded_clips_train_step, check_block_golden, check_e2e_golden, check_train_step_small, check_train_step_droppath_ragged, check_train_step_last_block_unpruned, check_train_step_fp32_residual_stream, check_train_step_undefined_rows_nan_filled,
               check_train_step_t4, check_train_step_t32, check_train_step_crop256, check_forecast_eval_golden, check_embed_resize_golden, check_full_size,
               check_train_step_t32_full_res, check_text_tower_full_size, check_timed_config_train_step, check_bench_config_two_clips]

@@ -386,3 +386,41 @@ def test_clip_text_oracle_matches_hf_clip_port():
         want = hf(input_ids=ids).text_embeds
         got = orc.clip_encode_text(sd, "text_model.", ids, layers)
     assert rel(got, want) < 2e-5, rel(got, want)
+
+
+def test_rounded_oracle_split_residual_stream_switch():
+    """Round 6's rounding points -- the patch rows of the residual stream (and of its gradient) stored in the operand type, RESID = "fwd" /
+    "both" -- are inert without an operand type (the model stays THE oracle), change values only on the patch rows' path, and cost what
+    one more 16-bit rounding per residual add costs (features within 2x of the stream-less model's error), not more."""
+    from oracle import rounded_oracle as rorc
+    f = load("features")
+    e = load("e2e")
+    full = orc.seeded_state(e2e_state(e), f["seed"])
+    sd = {k[len("model."):]: v for k, v in full.items()}
+    try:
+        with torch.no_grad():
+            a = orc.forward_features(sd, f["x"], e["depth"])
+            rorc.RESID = "both"
+            off = rorc.forward_features(sd, f["x"], e["depth"])             # no operand type: nothing is rounded
+            with rorc.operand(torch.float16):
+                both = rorc.forward_features(sd, f["x"], e["depth"])
+                rorc.RESID = None
+                none = rorc.forward_features(sd, f["x"], e["depth"])
+        assert rel(off, a) < 1e-6
+        assert 0 < rel(both, none) < 1e-3                                     # the switch does something, and something small
+        assert rel(both, a) < 2.0 * rel(none, a) + 1e-5, (rel(both, a), rel(none, a))
+        # gradients: "fwd" leaves the gradient stream alone, "both" rounds it -- both stay a 16-bit datapath's distance from fp32
+        outs = {}
+        for mode in (None, "fwd", "both"):
+            p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            rorc.RESID = mode
+            with rorc.operand(torch.float16):
+                (rorc.forward_features(p, f["x"], e["depth"]) * 64.0).sum().backward()
+            outs[mode] = p["blocks.0.mlp.fc1.weight"].grad
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        (orc.forward_features(p, f["x"], e["depth"]) * 64.0).sum().backward()
+        ref = p["blocks.0.mlp.fc1.weight"].grad
+        for mode in ("fwd", "both"):
+            assert rel(outs[mode], ref) < 2.0 * rel(outs[None], ref) + 1e-4, (mode, rel(outs[mode], ref), rel(outs[None], ref))
+    finally:
+        rorc.RESID = None
