@@ -9,8 +9,12 @@ import pytest
 import torch
 
 
-@pytest.mark.gpu
-def test_nccl_world1_training_step_matches_no_dist_step():
+def _world1_worker(rank, port, out_path):
+    """runs in its OWN process: a 1-rank RCCL group leaves communicator / watchdog threads behind that have no business in the pytest
+    process (one of four full-suite runs of round 6 ended with the interpreter aborting minutes after this test had passed in-process)"""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
     import torch.distributed as dist
     import e2e_checks as ec
     from procedurevrl_amd import distributed as du
@@ -44,7 +48,6 @@ def test_nccl_world1_training_step_matches_no_dist_step():
         return float(stats[0]), gs.flat[:gs.end].clone()      # (the tail past `end` holds the reducer's used-parameter flags)
 
     l0, g0 = run(False)
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -52,8 +55,26 @@ def test_nccl_world1_training_step_matches_no_dist_step():
         l1, g1 = run(True)
         dist.barrier()
         torch.cuda.synchronize()
+        torch.save(dict(l0=l0, l1=l1, g0=g0.cpu(), g1=g1.cpu()), out_path)     # (before the teardown: the results are the test)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_world1_training_step_matches_no_dist_step(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "world1.pt")
+    for attempt in range(2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        try:
+            mp.spawn(_world1_worker, args=(port, out), nprocs=1, join=True)
+            break
+        except Exception as e:      # a child that died in RCCL's teardown AFTER it saved its results: once is a flake, twice is a failure
+            if not os.path.exists(out) or attempt == 1:
+                raise
+            print("world-1 RCCL child died after saving its results, retrying once:", repr(e)[:200])
+    r = torch.load(out)
+    l0, l1, g0, g1 = r["l0"], r["l1"], r["g0"], r["g1"]
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     # the step is bit-reproducible (e2e_checks.check_step_is_bit_reproducible) and a 1-rank all-reduce / all-gather is
     # the identity: the two gradient buffers must agree exactly
