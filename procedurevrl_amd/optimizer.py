@@ -44,12 +44,15 @@ class FusedOptimizer(torch.optim.Optimizer):
         # kernels are queued (pvrl_flag_roll also counts the dropped step in `bad_steps`) -- its life cycle belongs to the step,
         # whatever loop calls it.  No host sync per iteration: a training loop reads `dropped_steps()` where it reads its statistics.
         # The HOST's per-parameter step counts (`param_steps`, Adam's bias correction) advance for a dropped step too: the host does not
-        # know it was dropped.  The reference raises at that iteration and so does `train_epoch` at its next log point; a loop that chooses
-        # to continue after `dropped_steps()` > 0 runs with a bias correction that is one step ahead per dropped step.
+        # know it was dropped -- until it asks: `dropped_steps()` (the loop's log point, `state_dict()`) takes every drop it finds back
+        # from the counts, so at most the steps between two such calls run with a bias correction one step ahead per dropped step.
+        # The reference raises at the bad iteration; `train_epoch` at its next log point.
         # `check_grads` (default for the fp16-operand flavour, whose scaled backward can overflow where the loss cannot) additionally
         # scans the gradients of parameters whose producers do not check themselves (GradStore.fused_checked lists the others).
         self.check_grads = os.environ.get("PVRL_CHECK_GRADS", "1" if OPERAND == "f16" else "0") == "1"
         self.bad_steps = None      # device counter of dropped steps
+        self._dropped_seen = 0     # ... as of the last dropped_steps() call
+        self._pending_idx = None   # parameters that had a gradient in EVERY step() since then (None: no step yet)
 
     @property
     def skip_flag(self):
@@ -62,8 +65,19 @@ class FusedOptimizer(torch.optim.Optimizer):
         bad.copy_(torch.maximum(bad, (~loss.detach().isfinite()).to(bad.dtype).reshape(1)))
 
     def dropped_steps(self):
-        """number of optimiser steps dropped so far because of a non-finite loss / gradient (host sync)"""
-        return 0 if self.bad_steps is None else int(self.bad_steps.item())
+        """number of optimiser steps dropped so far because of a non-finite loss / gradient (host sync).  Also RECONCILES the host's
+        per-parameter step counts (Adam's bias correction, the `step` of a checkpoint): the host advances them at every step() -- it
+        does not know a step was dropped on the device -- so every drop found here is taken back from the parameters that had a
+        gradient in the steps since the last call (`state_dict()` calls this first)."""
+        n = 0 if self.bad_steps is None else int(self.bad_steps.item())
+        k = n - self._dropped_seen
+        if k > 0 and self.param_steps is not None:
+            idx = range(len(self.param_steps)) if self._pending_idx is None else self._pending_idx
+            for i in idx:
+                self.param_steps[i] = max(0, self.param_steps[i] - k)
+        self._dropped_seen = n
+        self._pending_idx = None
+        return n
 
     # -- flat storage -----------------------------------------------------------------------
     def _ensure_flat(self):
@@ -127,6 +141,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             rest = [p for i, p in enumerate(gs.params) if scan_all or i not in gs.fused_checked]
             for a, b, _ in self._runs(gs, rest, had_grad, by_step=False):
                 L.call("pvrl_nonfinite_flag_f32", vp(base_g + 4 * a), b - a, skip, stream)
+        stepped = set()
         for g in self.param_groups:
             for a, b, done in self._runs(gs, g["params"], had_grad):
                 n, o = b - a, 4 * a
@@ -143,6 +158,8 @@ class FusedOptimizer(torch.optim.Optimizer):
                 i = gs.index.get(id(p))
                 if i is not None and had_grad[i]:
                     ps[i] += 1
+                    stepped.add(i)
+        self._pending_idx = stepped if self._pending_idx is None else (self._pending_idx & stepped)
         L.call("pvrl_flag_roll", skip, vp(self.bad_steps.data_ptr()), stream)      # count a dropped step, re-arm the flag
         self._bump(gs)
         return None
@@ -167,6 +184,7 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     # -- torch.optim-compatible state (checkpoint `optimizer_state`, lib/utils/checkpoint.py:126-131) ---------
     def state_dict(self):
+        self.dropped_steps()       # (host sync) the step counts saved below are the updates actually applied
         sd = {"param_groups": [], "state": {}, "fused": {"steps": self.steps, "method": self.method}}
         k = 0
         gs = self.vt.grad_store() if self.flat_p is not None else None

@@ -177,7 +177,9 @@ def test_non_finite_step_is_dropped_on_the_device(method):
     gs.views[5].view(-1)[3] = float("inf")
     opt.step()
     after = snap()
+    assert opt.param_steps[5] == 2, "the host counted the dropped step (it cannot know yet)"
     assert opt.dropped_steps() == 1
+    assert opt.param_steps[5] == 1 and set(opt.param_steps) == {1}, "dropped_steps() takes the dropped step back from the host's counts"
     assert float(opt.skip_flag) == 0.0, "step() re-arms the flag it consumed"
     assert all(b is None or torch.equal(a, b) for a, b in zip(after, before)), "a step with an inf gradient changed weights or state"
     # (b) the loop's loss flag alone (optimizer.note_loss), gradients finite
