@@ -4,15 +4,15 @@ This is the host side of the hot path `VisionTransformer.forward_features`
 (reference lib/models/vit.py:365-423) and its autograd backward, restated as an explicit
 schedule of C-ABI kernel launches (include/pvrl.h) on torch's current HIP stream.
 
-Token layout (one fp32 residual stream buffer x[M, 768], M = B*N*T + B):
-    rows [0, R)   patch tokens ordered (b, n, t), t innermost      R = B*N*T
-    rows [R, M)   the cls token of clip b
+Token layout (the residual stream x has M = B*N*T + B rows of 768 channels):
+    rows [0, R)   patch tokens ordered (b, n, t), t innermost      R = B*N*T     16-bit operand type since round 6 (`_X`, resid16)
+    rows [R, M)   the cls token of clip b                                        fp32
 The reference keeps [B, 1 + N*T, C] and re-gathers it with einops for every branch
 (vit.py:130-151); here temporal sequences are 8 consecutive rows, spatial sequences are
 addressed in place by the attention kernel, and the cls rows are a small suffix, so the
 three residual branches of a block are 3 LayerNorms + 7 GEMMs + 2 attention launches and no
-copy kernels.  Activations are bf16 GEMM operands; the residual stream, LayerNorm
-statistics, softmax statistics and all parameter gradients are fp32.
+copy kernels.  Activations are GEMM operands in the library's 16-bit type (fp16 by default); the cls rows of the residual stream,
+LayerNorm statistics, softmax statistics and all parameter gradients are fp32.
 """
 import math
 import os
