@@ -40,6 +40,11 @@ class PretrainHeadEngine:
         self.saved = None
         self._tconst = None
 
+    def release_graphs(self):       # (engine.GraphReplay.release_graphs)
+        from .engine import drop_graphs_quietly
+        drop_graphs_quietly(self._graphs)
+        self._gkey = None
+
     # ------------------------------------------------------------------ plumbing
     def params(self):
         o = self.o

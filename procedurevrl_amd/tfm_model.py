@@ -231,6 +231,10 @@ class ClipTextModel(nn.Module):
     def bind(self, owner):
         self._owner = [owner]
 
+    def release_graphs(self):       # (engine.GraphReplay.release_graphs)
+        from .engine import drop_graphs_quietly
+        drop_graphs_quietly(self._graphs)
+
     @torch.no_grad()
     def encode_text(self, text):
         """text int64 [n, 77] -> fp32 [n, embed_dim]; frozen, forward only.  The ~110 launches of the tower are replayed
