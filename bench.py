@@ -362,7 +362,15 @@ def main():
     status = 0
     if rank == 0:
         if want_parity:
+            # the timed model's captured graphs and pools go NOW, with the device idle, not whenever the garbage collector gets to them in
+            # the middle of the probe's own GPU work (that teardown aborted / hung the HIP runtime in the test suite)
+            import gc
+            torch.cuda.synchronize()
+            if hasattr(vt.engine, "release_graphs"):
+                vt.engine.release_graphs()
             del model, vt, optimizer, reducer, frames, teacher
+            gc.collect()
+            torch.cuda.synchronize()
             torch.cuda.empty_cache()
             try:
                 out["parity"] = parity_probe(args.arch, args.frames)
