@@ -372,3 +372,34 @@ def test_finetune_metrics_and_losses_match_their_definitions():
     cfg.MIXUP.ENABLED = True
     with pytest.raises(NotImplementedError):
         tn.finetune_loss(pv, lv, cfg)
+
+
+def test_hook_groups_cover_every_block_once_and_split_the_tail():
+    """engine.GraphReplay._group_of: the data-parallel gradient hook runs per group of `hook_group` blocks (one merged collective each),
+    and per block for the backward's LAST group (blocks 0 .. hook_group - 1: nothing is left to hide its collective under).  Whatever
+    the depth and group size, walking the blocks from the last to the first must visit every block exactly once, in order."""
+    from procedurevrl_amd.engine import GraphReplay
+
+    class E(GraphReplay):
+        pass
+
+    for nb in (1, 2, 3, 12, 16):
+        for grp in (1, 2, 3, 5):
+            for split in (True, False):
+                e = E()
+                e.hook_group, e.hook_tail_split = grp, split
+                seen, i, groups = [], nb - 1, []
+                while i >= 0:
+                    lo, hi = e._group_of(i, nb)
+                    assert lo <= i <= hi < nb and e._group_of(lo, nb) == (lo, hi)
+                    if i == hi:
+                        groups.append((lo, hi))
+                    seen.append(i)
+                    i -= 1
+                assert seen == list(range(nb - 1, -1, -1))
+                covered = [b for lo, hi in groups for b in range(hi, lo - 1, -1)]
+                assert covered == list(range(nb - 1, -1, -1)), (nb, grp, split, groups)
+                if split and nb > grp:
+                    assert groups[-min(grp, nb):] == [(b, b) for b in range(min(grp, nb) - 1, -1, -1)]
+                if not split and grp > 1 and nb >= grp:
+                    assert groups[-1] == (0, grp - 1)
