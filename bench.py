@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--parity-probe", action="store_true",
                     help="after the timed region: 2 clips of the SAME full-size model (12 blocks, 8x224^2, K=9871), one training "
                          "step vs the CPU oracle (checker only) -> `parity` in the JSON line (logits / loss / worst gradient error)")
+    ap.add_argument("--from-host", action="store_true",
+                    help="PCIe-inclusive variant (DESIGN section 5; never the headline `value`): every step's clips start in pinned HOST memory "
+                         "and are copied to one of two device buffers on a copy stream while the previous step computes")
     ap.add_argument("--no-parity-probe", action="store_true", help="skip the 2-clip parity probe that the default run and every --gpus N run append")
     ap.add_argument("--arch", default="vit", choices=["vit", "mvit"],
                     help="vit = TimeSformer ViT-B, the BASELINE metric (configs[1]); mvit = MViTv2-S 16x224^2 (configs[4], side number)")
@@ -160,9 +163,30 @@ def main():
     text_emb = l2norm(torch.randn(B, 512, device=dev, generator=g))        # stand-in for the frozen CLIP-text embeddings
     nce = MILNCELoss()
 
+    host_frames = copy_stream = None
+    if args.from_host:
+        host_frames = frames.cpu().pin_memory()
+        copy_stream = torch.cuda.Stream(device=dev)
+        dev_bufs = [frames, torch.empty_like(frames)]
+        staged = {"i": 0, "ev": None}
+
+        def stage():            # the NEXT step's batch: host -> device on the copy stream, behind the consumer of the buffer it overwrites
+            staged["i"] ^= 1
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                dev_bufs[staged["i"]].copy_(host_frames, non_blocking=True)
+                staged["ev"] = copy_stream.record_event()
+        stage()
+
     def step():
         optimizer.zero_grad(set_to_none=True)
-        pred = model(frames)
+        if args.from_host:
+            torch.cuda.current_stream().wait_event(staged["ev"])
+            cur = dev_bufs[staged["i"]]
+            pred = model(cur)
+            stage()
+        else:
+            pred = model(frames)
         loss = kl_topk_loss(pred, teacher, 5)                                # step matching (tools/train_net.py:152-160)
         v = vt.last_video_emb                                                # unit-norm clip embeddings [B, 512]
         v_all, t_all = (AllGather.apply(v), AllGather.apply(text_emb)) if dp_path else (v, text_emb)
@@ -324,6 +348,7 @@ def main():
                                              "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                                              "hook_group": getattr(vt.engine, "hook_group", None),
                                              **(comm_diag or {})},
+            "inputs": "pinned host memory, copied per step on a copy stream (PCIe-inclusive)" if args.from_host else "resident in HBM",
             "loss": float(loss.item()), "hip_graphs": bool(graphs), "hbm_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3), "sustained": sustained, "value_note": value_note,
             "end_to_end": {"tflops_per_gpu": round(value / world * wexec / 1e12, 2),
